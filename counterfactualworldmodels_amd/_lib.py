@@ -1,0 +1,161 @@
+"""ctypes binding of libcwm_hip.so (C ABI: include/cwm_hip.h).
+
+There is no CPU fallback: if the library cannot be loaded every entry point raises.
+`import torch` must happen before the library is loaded so that both share one HIP runtime
+(libamdhip64.so.7 is resolved by soname to the copy torch already mapped).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+import torch  # noqa: F401  (loads libamdhip64 first; see module docstring)
+
+from . import build as _build
+
+MODE_FAST = 1
+MODE_PARITY = 2
+ERR_INVALID = -1
+ERR_HIP = -2
+ERR_MASK = -3
+KCLASS_GEMM = 0
+KCLASS_ATTENTION = 1
+
+_MODES = {"fast": MODE_FAST, "parity": MODE_PARITY, MODE_FAST: MODE_FAST, MODE_PARITY: MODE_PARITY}
+
+
+def mode_id(mode) -> int:
+    try:
+        return _MODES[mode]
+    except KeyError:
+        raise ValueError("mode must be 'fast' or 'parity', got %r" % (mode,))
+
+
+class CwmConfig(C.Structure):
+    _fields_ = [
+        ("img_h", C.c_int32),
+        ("img_w", C.c_int32),
+        ("patch", C.c_int32),
+        ("num_frames", C.c_int32),
+        ("in_chans", C.c_int32),
+        ("enc_dim", C.c_int32),
+        ("enc_depth", C.c_int32),
+        ("enc_heads", C.c_int32),
+        ("dec_dim", C.c_int32),
+        ("dec_depth", C.c_int32),
+        ("dec_heads", C.c_int32),
+        ("mlp_ratio", C.c_int32),
+        ("ln_eps", C.c_float),
+    ]
+
+
+class CwmForwardArgs(C.Structure):
+    _fields_ = [
+        ("x_dev", C.c_void_p),
+        ("x_stride_b", C.c_int64),
+        ("x_stride_c", C.c_int64),
+        ("x_stride_t", C.c_int64),
+        ("normalize", C.c_int32),
+        ("mask_dev", C.c_void_p),
+        ("batch", C.c_int32),
+        ("n_vis", C.c_int32),
+        ("y_tokens_dev", C.c_void_p),
+        ("y_video_dev", C.c_void_p),
+        ("xraw_dev", C.c_void_p),
+        ("mode", C.c_int32),
+        ("check", C.c_int32),
+        ("stream", C.c_void_p),
+    ]
+
+
+class CwmKernelStats(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("total_flops", C.c_double)]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/cwm_hip.h
+SIGNATURES = {
+    "cwm_model_create": (C.c_int, [C.POINTER(CwmConfig), C.POINTER(C.c_void_p)]),
+    "cwm_model_destroy": (None, [C.c_void_p]),
+    "cwm_model_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "cwm_model_missing_weights": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "cwm_forward": (C.c_int, [C.c_void_p, C.POINTER(CwmForwardArgs)]),
+    "cwm_timing_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "cwm_timing_collect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(CwmKernelStats)]),
+    "cwm_split_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cwm_linear": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+    "cwm_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cwm_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "cwm_mask_to_perm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "cwm_unembed": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    ),
+    "cwm_last_error": (C.c_char_p, []),
+    "cwm_version": (C.c_char_p, []),
+}
+
+_lib: Optional[C.CDLL] = None
+_lock = threading.Lock()
+
+
+class CwmHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+def library_path() -> str:
+    return os.environ.get("CWM_HIP_LIB", _build.LIB_PATH)
+
+
+def get_lib() -> C.CDLL:
+    """Load (building if absent and hipcc is available) libcwm_hip.so.  Raises if impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            try:
+                _build.build_library()
+            except Exception as e:  # no silent fallback
+                raise RuntimeError(
+                    "libcwm_hip.so is missing at %s and could not be built (%s). "
+                    "Run `python -m counterfactualworldmodels_amd.build`." % (path, e)
+                )
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = get_lib().cwm_last_error()
+        raise CwmHipError(rc, (msg.decode() if msg else "") + " [cwm_hip rc=%d]" % rc)
+
+
+def require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "counterfactualworldmodels_amd runs its predictor on an AMD GPU through libcwm_hip.so; "
+            "no HIP device is visible and there is no CPU fallback."
+        )
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_handle(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,267 @@
+// Flash-style multi-head self-attention for CDNA4 (gfx950), head_dim = 64, non-causal, any N.
+//
+// Replaces the materialised  softmax(q k^T) v  of `Attention.forward`
+// (reference: cwm/models/VideoMAE/utils.py:108-113; the optional CUDA flash-attn import at :71-73).
+//
+// Layout / dataflow (one workgroup = 4 waves = 128 query rows of one (batch, head); a wave owns 32 rows):
+//   S^T[key][q] = K[key][:] . Q[q][:]       mfma_f32_32x32x16_bf16, A = K tile (LDS), B = Q (registers)
+//   -> every lane holds 16 keys of ONE query column, so the online-softmax row max / row sum are
+//      in-register reductions plus a single lane^32 exchange (wave shuffle)
+//   O^T[d][q]  += V^T[d][key] . P^T[key][q]  A = V^T tile (LDS), B = the S^T accumulator itself,
+//      converted to bf16 in place (accumulator-as-operand; k order permuted, matched on the V^T reads)
+//   -> the running rescale factor alpha[q] is lane-local as well.
+// K and V^T tiles (64 keys) are double-buffered in LDS with register-staged prefetch of tile t+1
+// issued before the MFMAs of tile t.  LDS images are XOR-swizzled for conflict-free ds_read_b128 /
+// ds_read_b64.  PLANES==2 is the split-bf16 "parity" mode (hi*hi + hi*lo + lo*hi for both products).
+#include "common.h"
+#include "kernels.h"
+
+namespace cwm {
+
+__device__ __forceinline__ int lds_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int PLANES>
+__global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
+    constexpr int TILE_BYTES = 64 * 64 * 2;              // one 64x64 bf16 tile
+    constexpr int STAGE_BYTES = TILE_BYTES * 2 * PLANES;  // K planes, then V^T planes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int qcol = lane & 31, hh = lane >> 5;
+    const int N = p.n_tok;
+    const int bh = blockIdx.y;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    const bf16* Qb = p.q + (size_t)bh * N * 64;
+    const bf16* Kb = p.k + (size_t)bh * N * 64;
+    const bf16* Vb = p.vt + (size_t)bh * 64 * p.n_pad;
+
+    // ---- Q fragments (B operand): lane (q = qcol, half hh) holds Q[q][16 s + 8 hh + 0..7] --------
+    bf16x8 qf[PLANES][4];
+    {
+        const int qrow = min(q0 + qcol, N - 1);
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                qf[pl][s] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)pl * p.qk_plane + (size_t)qrow * 64 + s * 16 + hh * 8);
+    }
+
+    // ---- staging bookkeeping: 512 16-byte chunks per tile, 2 per thread --------------------------
+    int st_row[2], st_chunk[2], st_koff[2], st_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256;
+        st_row[i] = idx >> 3;
+        st_chunk[i] = idx & 7;
+        st_koff[i] = lds_off128(st_row[i], st_chunk[i]);
+        st_voff[i] = lds_off128(st_row[i], st_chunk[i]);
+    }
+    uint4 rk[PLANES][2], rv[PLANES][2];
+    auto load_tiles = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int krow = min(kt * 64 + st_row[i], N - 1);
+            const int key0 = kt * 64 + st_chunk[i] * 8;
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) {
+                rk[pl][i] = *reinterpret_cast<const uint4*>(Kb + (size_t)pl * p.qk_plane + (size_t)krow * 64 + st_chunk[i] * 8);
+                uint4 v = *reinterpret_cast<const uint4*>(Vb + (size_t)pl * p.vt_plane + (size_t)st_row[i] * p.n_pad + key0);
+                if (key0 + 8 > N) {  // zero the keys past the sequence end (P is 0 there, 0 * garbage must stay 0)
+                    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (key0 + e >= N) w[e >> 1] &= (e & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                rv[pl][i] = v;
+            }
+        }
+    };
+    auto store_tiles = [&](int stage) {
+        char* base = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) {
+                *reinterpret_cast<uint4*>(base + pl * TILE_BYTES + st_koff[i]) = rk[pl][i];
+                uint4 v = rv[pl][i];
+                if (st_row[i] & 16) v = make_uint4(v.z, v.w, v.x, v.y);  // swap the 8-byte halves (bank spread)
+                *reinterpret_cast<uint4*>(base + (PLANES + pl) * TILE_BYTES + st_voff[i]) = v;
+            }
+    };
+
+    // ---- fragment read offsets -------------------------------------------------------------------
+    // K (A operand of S^T): row = key kb*32 + qcol, 16-byte chunk = 2 s + hh
+    int k_off[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) k_off[kb][s] = lds_off128(kb * 32 + qcol, 2 * s + hh);
+    // V^T (A operand of O^T): row = d = db*32 + qcol; k-step ks needs keys 16 ks + 4 hh + {0..3}
+    // (chunk 2 ks, half hh) and 16 ks + 8 + 4 hh + {0..3} (chunk 2 ks + 1, half hh)
+    int v_off[2][4][2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int d = db * 32 + qcol;
+                v_off[db][ks][c] = lds_off128(d, 2 * ks + c) + ((hh ^ ((d >> 4) & 1)) << 3);
+            }
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float kLog2e = 1.4426950408889634f;
+
+    const int nkt = (N + 63) / 64;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tiles(kt + 1);
+        const char* base = smem + cur * STAGE_BYTES;
+
+        // ---- S^T = K Q^T ------------------------------------------------------------------------
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(base + k_off[kb][s]);
+                if constexpr (PLANES == 2) {
+                    const bf16x8 kl = *reinterpret_cast<const bf16x8*>(base + TILE_BYTES + k_off[kb][s]);
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][s], sacc[kb], 0, 0, 0);
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sacc[kb], 0, 0, 0);
+                }
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sacc[kb], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax (per query column; lanes l and l^32 share a query) ------------------
+        if (kt == nkt - 1 && (N & 63)) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= N) sacc[kb][r] = -INFINITY;
+                }
+        }
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+        m_run = m_new;
+        const float mc = m_new * kLog2e;
+        float rowsum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], kLog2e, -mc));
+                sacc[kb][r] = pv;
+                rowsum += pv;
+            }
+        l_run = l_run * alpha + rowsum;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+
+        // ---- O^T += V^T P^T  (P^T fragment of k-step ks = kb*2+s is sacc[kb][8s .. 8s+7]) --------
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kb = ks >> 1, s = ks & 1;
+            bf16x8 ph, plo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = sacc[kb][8 * s + j];
+                const bf16 hi = (bf16)pv;
+                ph[j] = hi;
+                if constexpr (PLANES == 2) plo[j] = (bf16)(pv - (float)hi);
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const char* vb = base + PLANES * TILE_BYTES;
+                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vb + v_off[db][ks][0]);
+                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vb + v_off[db][ks][1]);
+                const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                if constexpr (PLANES == 2) {
+                    const bf16x4 l0 = *reinterpret_cast<const bf16x4*>(vb + TILE_BYTES + v_off[db][ks][0]);
+                    const bf16x4 l1 = *reinterpret_cast<const bf16x4*>(vb + TILE_BYTES + v_off[db][ks][1]);
+                    const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, plo, oacc[db], 0, 0, 0);
+                }
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, oacc[db], 0, 0, 0);
+            }
+        }
+
+        if (kt + 1 < nkt) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store O[q][h*64 + d] ----------------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + qcol;
+    if (q < N) {
+        bf16* orow = p.o + ((size_t)b * N + q) * p.ldo + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 hi4, lo4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = oacc[db][4 * g + e] * inv;
+                    const bf16 hi = (bf16)v;
+                    hi4[e] = hi;
+                    if constexpr (PLANES == 2) lo4[e] = (bf16)(v - (float)hi);
+                }
+                const int d0 = db * 32 + 8 * g + 4 * hh;
+                *reinterpret_cast<bf16x4*>(orow + d0) = hi4;
+                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(orow + p.o_plane + d0) = lo4;
+            }
+    }
+}
+
+int launch_attention(const AttnParams& p, int planes, hipStream_t stream) {
+    CWM_REQUIRE(planes == 1 || planes == 2, "attention: planes must be 1 or 2");
+    CWM_REQUIRE(p.n_tok > 0 && p.n_pad >= ((p.n_tok + 63) / 64) * 64 && p.n_pad % 8 == 0,
+                "attention: n_pad=%d must cover n_tok=%d rounded up to 64", p.n_pad, p.n_tok);
+    CWM_REQUIRE(p.ldo % 4 == 0, "attention: ldo must be a multiple of 4");
+    const dim3 grid((p.n_tok + 127) / 128, p.batch * p.heads);
+    const size_t smem = (size_t)2 * (64 * 64 * 2) * 2 * planes;
+    if (planes == 1) {
+        hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(256), smem, stream, p);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            CWM_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr = true;
+        }
+        hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(256), smem, stream, p);
+    }
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace cwm

@@ -1,0 +1,60 @@
+// Shared device/host helpers for the CDNA4 (gfx950) VMAE predictor kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cwm {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kWave = 64;
+
+// Split an fp32 value into bf16 hi + bf16 lo (hi + lo carries ~16 significand bits).
+__device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
+    hi = (bf16)v;
+    lo = (bf16)(v - (float)hi);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id (guide §5.5 T1): blocks b and b+8 share an
+// XCD under round-robin dispatch, so give every XCD a contiguous chunk of the logical tile order.
+// Speed only; any placement is correct.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int q = nwg / nx, r = nwg % nx;
+    int xcd = bid % nx, idx = bid / nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace cwm
+
+// ---- host-side error plumbing (C ABI never throws) ------------------------------------------
+void cwm_set_error(const char* fmt, ...);
+
+#define CWM_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            cwm_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return -2;                                                                       \
+        }                                                                                    \
+    } while (0)
+
+#define CWM_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            cwm_set_error(__VA_ARGS__);   \
+            return -1;                    \
+        }                                 \
+    } while (0)

@@ -1,0 +1,300 @@
+// HBM-bound edge kernels of the VMAE predictor path (gfx950): LayerNorm, mask -> token permutation
+// (bit-exact index op), frame load + imagenet-normalise + tubelet patch gather, decoder mask-token
+// fill, patch un-embed scatter, fp32 -> bf16 (hi, lo) split.
+#include "common.h"
+#include "kernels.h"
+
+namespace cwm {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm (eps 1e-6, affine) -> bf16 hi(/lo) planes.  Reference: nn.LayerNorm call sites
+// VideoMAE/utils.py:148-149 (norm1/norm2), vmae.py:172 (encoder.norm), :251 (decoder.norm on the
+// last Nm tokens).  One wave per row, row kept in registers, two-pass mean/variance in fp32.
+// ---------------------------------------------------------------------------------------------
+template <int PLANES>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p) {
+    constexpr int MAXI = 8;  // D <= 1024
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.rows) return;
+    int in_row = r;
+    if (p.rows_out_per_b > 0) {
+        const int b = r / p.rows_out_per_b;
+        in_row = b * p.rows_in_per_b + p.in_offset + (r - b * p.rows_out_per_b);
+    }
+    const float* x = p.x + (size_t)in_row * p.ldx;
+    float2 v[MAXI];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int idx = lane * 2 + i * 128;
+        if (idx < p.D) {
+            v[i] = *reinterpret_cast<const float2*>(x + idx);
+            s += v[i].x + v[i].y;
+        } else {
+            v[i] = make_float2(0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(s) / (float)p.D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int idx = lane * 2 + i * 128;
+        if (idx < p.D) {
+            const float a = v[i].x - mean, c = v[i].y - mean;
+            sq += a * a + c * c;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+    bf16* out = p.out + (size_t)r * p.ldo;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int idx = lane * 2 + i * 128;
+        if (idx < p.D) {
+            const float2 g = *reinterpret_cast<const float2*>(p.gamma + idx);
+            const float2 be = *reinterpret_cast<const float2*>(p.beta + idx);
+            const float y0 = (v[i].x - mean) * rstd * g.x + be.x;
+            const float y1 = (v[i].y - mean) * rstd * g.y + be.y;
+            bf16 h0, l0, h1, l1;
+            split_bf16(y0, h0, l0);
+            split_bf16(y1, h1, l1);
+            bf16x2 hv = {h0, h1};
+            *reinterpret_cast<bf16x2*>(out + idx) = hv;
+            if constexpr (PLANES == 2) {
+                bf16x2 lv = {l0, l1};
+                *reinterpret_cast<bf16x2*>(out + p.out_plane + idx) = lv;
+            }
+            if (p.out_f32) *reinterpret_cast<float2*>(p.out_f32 + (size_t)r * p.D + idx) = make_float2(y0, y1);
+        }
+    }
+}
+
+int launch_layernorm(const LayerNormParams& p, int planes, hipStream_t stream) {
+    CWM_REQUIRE(p.D % 2 == 0 && p.D <= 1024, "layernorm: D=%d must be even and <= 1024", p.D);
+    CWM_REQUIRE(p.ldx % 2 == 0 && p.ldo % 2 == 0, "layernorm: row strides must be even");
+    const int blocks = (p.rows + 3) / 4;
+    if (planes == 1)
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, stream, p);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mask -> permutation.  Reference: `x[~mask].reshape(B,-1,C)` (vmae.py:167) and the decoder order
+// `cat([vis, masked])` (vmae.py:555-557): visible tokens in ascending token index, then masked
+// tokens in ascending token index.  Integer-exact; one workgroup per sample, block-wide scan.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_to_perm_kernel(const uint8_t* mask, int Nt, int n_vis, int* perm, int* err) {
+    __shared__ int counts[256];
+    __shared__ int total_vis;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const uint8_t* m = mask + (size_t)b * Nt;
+    const int per = (Nt + 255) / 256;
+    const int lo = min(t * per, Nt), hi = min(lo + per, Nt);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += (m[i] == 0);
+    counts[t] = c;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int v = counts[i];
+            counts[i] = run;
+            run += v;
+        }
+        total_vis = run;
+        if (run != n_vis) atomicExch(err, 1);
+    }
+    __syncthreads();
+    int vis_before = counts[t];
+    const int tv = total_vis;
+    int* pr = perm + (size_t)b * Nt;
+    for (int i = lo; i < hi; ++i) {
+        if (m[i] == 0) {
+            pr[vis_before] = i;
+            ++vis_before;
+        } else {
+            pr[tv + (i - vis_before)] = i;
+        }
+    }
+}
+
+int launch_mask_to_perm(const uint8_t* mask, int B, int Nt, int n_vis, int* perm, int* err, hipStream_t stream) {
+    hipLaunchKernelGGL(mask_to_perm_kernel, dim3(B), dim3(256), 0, stream, mask, Nt, n_vis, perm, err);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void perm_to_rank_kernel(const int* perm, int* rank, int Nt, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / Nt;
+    rank[(size_t)b * Nt + perm[i]] = i - b * Nt;
+}
+
+int launch_perm_to_rank(const int* perm, int* rank, int B, int Nt, hipStream_t stream) {
+    const int total = B * Nt;
+    hipLaunchKernelGGL(perm_to_rank_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, perm, rank, Nt, total);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Frame load + imagenet normalise + tubelet patch gather (im2col of the visible tokens only).
+// Reference: `_preprocess` + `imagenet_normalize` (prediction.py:304-312, utils.py:15-21) and the
+// Conv3d patch embed (VideoMAE/utils.py:174-197), whose GEMM is done by gemm.hip on this matrix.
+// The reference embeds all Nt tokens and gathers afterwards (vmae.py:155-167); the embed is
+// per-token, so gathering first is identical and skips the masked half of frame 2.
+// One thread per (row, c, ph): reads P contiguous pixels, writes P contiguous bf16.
+// ---------------------------------------------------------------------------------------------
+template <int PLANES>
+__global__ __launch_bounds__(256) void patch_gather_kernel(const PatchGatherParams p) {
+    const int per_row = p.C * p.P;
+    const int64_t total = (int64_t)p.B * p.n_rows * per_row;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int row = (int)(gid / per_row);
+    const int rem = (int)(gid - (int64_t)row * per_row);
+    const int c = rem / p.P, ph = rem - c * p.P;
+    const int b = row / p.n_rows, i = row - b * p.n_rows;
+    const int tau = p.perm[(size_t)b * p.Nt + i];
+    const int gw = p.W / p.P;
+    const int n = (p.H / p.P) * gw;
+    const int t = tau / n, hw = tau - t * n;
+    const int hy = hw / gw, wx = hw - hy * gw;
+    const float* src = p.x + b * p.sb + c * p.sc + t * p.st + (int64_t)(hy * p.P + ph) * p.W + wx * p.P;
+    const float mean = (c == 0) ? 0.485f : (c == 1) ? 0.456f : 0.406f;
+    const float stdv = (c == 0) ? 0.229f : (c == 1) ? 0.224f : 0.225f;
+    bf16* dst = p.out + (size_t)row * p.ld + c * p.P * p.P + ph * p.P;
+    for (int pw = 0; pw < p.P; pw += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src + pw);
+        float f[4] = {v.x, v.y, v.z, v.w};
+        bf16x4 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = f[e];
+            if (p.normalize) a = (a - mean) / stdv;
+            bf16 hi, lo;
+            split_bf16(a, hi, lo);
+            hv[e] = hi;
+            lv[e] = lo;
+        }
+        *reinterpret_cast<bf16x4*>(dst + pw) = hv;
+        if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + p.out_plane + pw) = lv;
+    }
+    // zero the K padding (K = C*P*P rounded up to ld) once per row
+    if (rem == 0) {
+        const int K = p.C * p.P * p.P;
+        bf16* rowp = p.out + (size_t)row * p.ld;
+        for (int k = K; k < p.ld; ++k) {
+            rowp[k] = (bf16)0.f;
+            if constexpr (PLANES == 2) rowp[p.out_plane + k] = (bf16)0.f;
+        }
+    }
+}
+
+int launch_patch_gather(const PatchGatherParams& p, int planes, hipStream_t stream) {
+    CWM_REQUIRE(p.P % 4 == 0 && p.W % 4 == 0, "patch_gather: patch size and width must be multiples of 4");
+    CWM_REQUIRE(p.C == 3 || !p.normalize, "patch_gather: imagenet normalisation needs 3 channels");
+    CWM_REQUIRE(p.ld >= p.C * p.P * p.P && p.ld % 4 == 0, "patch_gather: bad ld");
+    const int64_t total = (int64_t)p.B * p.n_rows * p.C * p.P;
+    const int blocks = (int)((total + 255) / 256);
+    if (planes == 1)
+        hipLaunchKernelGGL(patch_gather_kernel<1>, dim3(blocks), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(patch_gather_kernel<2>, dim3(blocks), dim3(256), 0, stream, p);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// decoder input, masked half: x_full[b][n_vis + j] = mask_token + pos[perm[b][n_vis + j]]
+// (vmae.py:556-557).  The visible half is written by the encoder_to_decoder GEMM epilogue.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_mask_tokens_kernel(float* x_full, const float* mask_token, const float* pos,
+                                                                const int* perm, int Nt, int n_vis, int D, int64_t total4) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total4) return;
+    const int d4 = D / 4;
+    const int64_t row = gid / d4;
+    const int c4 = (int)(gid - row * d4);
+    const int nm = Nt - n_vis;
+    const int b = (int)(row / nm), j = (int)(row - (int64_t)b * nm);
+    const int tau = perm[(size_t)b * Nt + n_vis + j];
+    const float4 mt = *reinterpret_cast<const float4*>(mask_token + c4 * 4);
+    const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)tau * D + c4 * 4);
+    float4 o = make_float4(mt.x + pe.x, mt.y + pe.y, mt.z + pe.z, mt.w + pe.w);
+    *reinterpret_cast<float4*>(x_full + ((size_t)b * Nt + n_vis + j) * D + c4 * 4) = o;
+}
+
+int launch_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt,
+                            int n_vis, int D, hipStream_t stream) {
+    CWM_REQUIRE(D % 4 == 0, "fill_mask_tokens: D must be a multiple of 4");
+    const int64_t total4 = (int64_t)B * (Nt - n_vis) * (D / 4);
+    if (total4 == 0) return 0;
+    hipLaunchKernelGGL(fill_mask_tokens_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, x_full,
+                       mask_token, pos, perm, Nt, n_vis, D, total4);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Patch un-embed scatter.  Reference: `pred_patches_to_video` (prediction.py:245-259) with
+// `Patchify` (patches.py:74,98-102): feature index f = (ph*P + pw)*C + c; visible patches take the
+// RAW (un-normalised) wrapper input.  One thread per 4 horizontally adjacent output pixels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unembed_kernel(const UnembedParams p) {
+    const int w4 = p.W / 4;
+    const int64_t total = (int64_t)p.B * p.T * p.C * p.H * w4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    int64_t r = gid;
+    const int x4 = (int)(r % w4); r /= w4;
+    const int y = (int)(r % p.H); r /= p.H;
+    const int c = (int)(r % p.C); r /= p.C;
+    const int t = (int)(r % p.T);
+    const int b = (int)(r / p.T);
+    const int x0 = x4 * 4;
+    const int gw = p.W / p.P;
+    const int n = (p.H / p.P) * gw;
+    const int Nt = p.T * n;
+    const int tau = t * n + (y / p.P) * gw + (x0 / p.P);
+    float4 o;
+    if (p.mask[(size_t)b * Nt + tau]) {
+        const int j = p.rank[(size_t)b * Nt + tau] - p.n_vis;
+        const float* yp = p.y + ((size_t)b * p.Nm + j) * (p.P * p.P * p.C) + ((y % p.P) * p.P + (x0 % p.P)) * p.C + c;
+        o = make_float4(yp[0], yp[p.C], yp[2 * p.C], yp[3 * p.C]);
+    } else {
+        o = *reinterpret_cast<const float4*>(p.x + b * p.sb + t * p.st + c * p.sc + (int64_t)y * p.W + x0);
+    }
+    *reinterpret_cast<float4*>(p.out + ((((size_t)b * p.T + t) * p.C + c) * p.H + y) * p.W + x0) = o;
+}
+
+int launch_unembed(const UnembedParams& p, hipStream_t stream) {
+    CWM_REQUIRE(p.P % 4 == 0 && p.W % 4 == 0, "unembed: patch size and width must be multiples of 4");
+    const int64_t total = (int64_t)p.B * p.T * p.C * p.H * (p.W / 4);
+    hipLaunchKernelGGL(unembed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void split_bf16_kernel(const float* x, int64_t n, bf16* hi, bf16* lo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bf16 h, l;
+    split_bf16(x[i], h, l);
+    hi[i] = h;
+    if (lo) lo[i] = l;
+}
+
+int launch_split_bf16(const float* x, int64_t n, bf16* hi, bf16* lo, hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, n, hi, lo);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace cwm

@@ -1,0 +1,277 @@
+// bf16 / split-bf16 ("bf16x3") MFMA GEMM for CDNA4 (gfx950):  C[M,N] = A[M,K] * W[N,K]^T  (+ epilogue)
+//
+// Replaces every `F.linear` on the predictor path (reference call sites: VideoMAE/utils.py:48-53
+// fc1/fc2, :93 qkv, :119 proj; vmae.py:547 encoder_to_decoder, :251 head; the Conv3d patch embed of
+// VideoMAE/utils.py:174-197 expressed as an im2col GEMM).
+//
+// * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 4x4 MFMA 16x16x32 tiles)
+// * A and W are both K-contiguous, so one lane's MFMA fragment is one 16-byte LDS read
+// * LDS tiles are XOR-swizzled so the ds_read_b128 fragment reads are bank-conflict free
+// * double-buffered LDS, global loads of tile t+1 issued before the MFMAs of tile t (register staging)
+// * PLANES==2 ("parity" mode): operands are (hi, lo) bf16 planes and each product is
+//   hi*hi + hi*lo + lo*hi, fp32-accumulated -> ~2^-16 relative operand error instead of 2^-9
+// * XCD-aware, grouped tile order so that co-resident tiles of one XCD share A panels / W tiles in L2
+// * fused epilogues: bias, residual(+row map), exact-erf GELU, bf16 hi/lo split, QKV head scatter
+#include "common.h"
+#include "kernels.h"
+
+namespace cwm {
+
+template <int BK>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    if constexpr (BK == 64) {
+        return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    } else {
+        // 64-byte rows: 4 rows share one 256-byte bank row; permute so each ds_read_b128 lane group
+        // (rows {0-3,12-15} at chunk c, rows {4-11} at chunk c^1) covers 16 distinct 16-byte slots.
+        const int x = (row >> 2) & 3;
+        const int t = (0x78 >> (2 * x)) & 3;  // {0,2,3,1}
+        return row * 64 + ((chunk ^ t) << 4);
+    }
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int PLANES>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+    constexpr int BM = 128, BN = 128;
+    constexpr int BK = (PLANES == 1) ? 64 : 32;
+    constexpr int CPR = BK / 8;               // 16-byte chunks per tile row
+    constexpr int NLD = (BM * CPR) / 256;     // staging loads per thread per operand plane
+    constexpr int TILE_BYTES = BM * BK * 2;
+    constexpr int STAGE_BYTES = TILE_BYTES * 2 * PLANES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // ---- tile selection: XCD chunking + GROUP_M-grouped order --------------------------------
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    int id = xcd_remap(blockIdx.x, ntiles);
+    constexpr int GROUP_M = 8;
+    const int group_sz = GROUP_M * tiles_n;
+    const int g = id / group_sz;
+    const int first_m = g * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    const int in_g = id - g * group_sz;
+    const int tile_m = first_m + (in_g % gm);
+    const int tile_n = in_g / gm;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- staging addresses --------------------------------------------------------------------
+    const bf16* a_src[NLD];
+    const bf16* w_src[NLD];
+    int st_off[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / CPR, chunk = idx % CPR;
+        const int ra = min(m0 + row, p.M - 1);
+        a_src[i] = p.A + (size_t)ra * p.lda + chunk * 8;
+        w_src[i] = p.W + (size_t)(n0 + row) * p.K + chunk * 8;
+        st_off[i] = lds_off<BK>(row, chunk);
+    }
+
+    uint4 ra_[PLANES][NLD], rb_[PLANES][NLD];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                ra_[pl][i] = *reinterpret_cast<const uint4*>(a_src[i] + (size_t)pl * p.a_plane + k0);
+                rb_[pl][i] = *reinterpret_cast<const uint4*>(w_src[i] + (size_t)pl * p.w_plane + k0);
+            }
+    };
+    auto store_tile = [&](int stage) {
+        char* base = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                *reinterpret_cast<uint4*>(base + pl * TILE_BYTES + st_off[i]) = ra_[pl][i];
+                *reinterpret_cast<uint4*>(base + (PLANES + pl) * TILE_BYTES + st_off[i]) = rb_[pl][i];
+            }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (row within tile, k-chunk within a 32-wide k-step)
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_off[4][BK / 32], b_off[4][BK / 32];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            a_off[i][kk] = lds_off<BK>(wr * 64 + i * 16 + frow, kk * 4 + fq);
+            b_off[i][kk] = lds_off<BK>(wc * 64 + i * 16 + frow, kk * 4 + fq);
+        }
+
+    const int nk = p.K / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) load_tile((t + 1) * BK);
+        const char* base = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 af[PLANES][4], bfr[PLANES][4];
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * TILE_BYTES + a_off[i][kk]);
+                    bfr[pl][i] = *reinterpret_cast<const bf16x8*>(base + (PLANES + pl) * TILE_BYTES + b_off[i][kk]);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (PLANES == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[1][j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (t + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    // C/D layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const int col_l = lane & 15;
+    const int row_l = (lane >> 4) * 4;
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int mbase = m0 + wr * 64 + i * 16 + row_l;
+        if (mbase >= p.M) continue;
+        // per-row bookkeeping shared by the 4 column fragments
+        int out_row[4], res_row[4], bidx[4], tok[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mbase + r;
+            if (p.rows_in > 0) {
+                const int b = m / p.rows_in, ii = m - b * p.rows_in;
+                out_row[r] = b * p.rows_out + ii;
+                res_row[r] = p.resid_rowmap ? p.resid_rowmap[b * p.map_stride + ii] : out_row[r];
+                bidx[r] = b;
+                tok[r] = ii;
+            } else {
+                out_row[r] = m;
+                res_row[r] = m;
+                bidx[r] = 0;
+                tok[r] = m;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wc * 64 + j * 16;  // fragment's first column (wave-uniform)
+            if (nb >= p.N) continue;
+            const int n = nb + col_l;
+            const float bias = p.bias ? p.bias[n] : 0.f;
+            if (p.epi == EPI_F32) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (mbase + r < p.M) {
+                        float v = acc[i][j][r] + bias;
+                        if (p.resid) v += p.resid[(size_t)res_row[r] * p.ldr + n];
+                        p.C[(size_t)out_row[r] * p.ldc + n] = v;
+                    }
+                }
+            } else if (p.epi == EPI_BF16_GELU || p.epi == EPI_BF16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (mbase + r < p.M) {
+                        float v = acc[i][j][r] + bias;
+                        if (p.epi == EPI_BF16_GELU) v = gelu_erf(v);
+                        bf16 hi, lo;
+                        split_bf16(v, hi, lo);
+                        const size_t o = (size_t)out_row[r] * p.ldo + n;
+                        p.out_hi[o] = hi;
+                        if constexpr (PLANES == 2) p.out_hi[o + p.out_plane] = lo;
+                    }
+                }
+            } else {  // EPI_QKV: scatter to per-head Q, K ([B*H, Ntok, hd]) and V^T ([B*H, hd, Npad])
+                const int D = p.qkv_dim;
+                const int which = nb / D;           // 0 q, 1 k, 2 v (uniform per 16-col fragment)
+                const int c = n - which * D;
+                const int h = c / p.head_dim, d = c - h * p.head_dim;
+                float vals[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bias;
+                    vals[r] = (which == 0) ? v * p.q_scale : v;
+                }
+                if (which < 2) {
+                    bf16* dst = (which == 0) ? p.q_out : p.k_out;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (mbase + r < p.M) {
+                            bf16 hi, lo;
+                            split_bf16(vals[r], hi, lo);
+                            const size_t o = ((size_t)(bidx[r] * p.heads + h) * p.n_tok + tok[r]) * p.head_dim + d;
+                            dst[o] = hi;
+                            if constexpr (PLANES == 2) dst[o + p.qk_plane] = lo;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (mbase + r < p.M) {
+                            bf16 hi, lo;
+                            split_bf16(vals[r], hi, lo);
+                            const size_t o = ((size_t)(bidx[r] * p.heads + h) * p.head_dim + d) * p.n_pad + tok[r];
+                            p.vt_out[o] = hi;
+                            if constexpr (PLANES == 2) p.vt_out[o + p.vt_plane] = lo;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+int launch_gemm(const GemmParams& p, int planes, hipStream_t stream) {
+    CWM_REQUIRE(planes == 1 || planes == 2, "gemm: planes must be 1 or 2");
+    const int BK = planes == 1 ? 64 : 32;
+    CWM_REQUIRE(p.K % 64 == 0, "gemm: K=%d must be a multiple of 64", p.K);
+    CWM_REQUIRE(p.lda % 8 == 0, "gemm: lda=%d must be a multiple of 8", p.lda);
+    CWM_REQUIRE(p.M > 0 && p.N > 0, "gemm: empty problem M=%d N=%d", p.M, p.N);
+    if (p.epi == EPI_QKV) {
+        CWM_REQUIRE(p.rows_in == p.n_tok && p.qkv_dim % 16 == 0 && p.N == 3 * p.qkv_dim, "gemm: bad QKV epilogue setup");
+    }
+    (void)BK;
+    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const size_t smem = 65536;
+    if (planes == 1) {
+        static bool attr1 = false;
+        if (!attr1) {
+            CWM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr1 = true;
+        }
+        hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(tiles), dim3(256), smem, stream, p);
+    } else {
+        static bool attr2 = false;
+        if (!attr2) {
+            CWM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(gemm_bf16_kernel<2>, dim3(tiles), dim3(256), smem, stream, p);
+    }
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace cwm

@@ -1,0 +1,118 @@
+// Internal launch interfaces of the HIP kernels (not part of the C ABI; see include/cwm_hip.h).
+#pragma once
+#include "common.h"
+
+namespace cwm {
+
+enum GemmEpilogue : int {
+    EPI_F32 = 0,        // C = acc + bias (+ resid[rowmap])            fp32 out
+    EPI_BF16_GELU = 1,  // out = split_bf16(gelu_erf(acc + bias))      bf16 plane(s) out
+    EPI_BF16 = 2,       // out = split_bf16(acc + bias)                bf16 plane(s) out
+    EPI_QKV = 3,        // per-head scatter: Q (scaled), K -> [B*H,N,hd]; V -> V^T [B*H,hd,Npad]
+};
+
+struct GemmParams {
+    // operands: A[planes][M][lda], W[planes][Npad][K]  (bf16, K-contiguous)
+    const bf16* A;
+    const bf16* W;
+    int64_t a_plane, w_plane;
+    int lda;
+    int M, N, K;
+    const float* bias;  // [N] or nullptr
+    int epi;
+    // row mapping (rows_in == 0: identity).  m = b*rows_in + i  ->  out row b*rows_out + i,
+    // residual row = resid_rowmap ? resid_rowmap[b*map_stride + i] : out row
+    int rows_in, rows_out, map_stride;
+    const int* resid_rowmap;
+    // EPI_F32
+    float* C;
+    int ldc;
+    const float* resid;
+    int ldr;
+    // EPI_BF16*
+    bf16* out_hi;
+    int64_t out_plane;
+    int ldo;
+    // EPI_QKV
+    bf16* q_out;
+    bf16* k_out;
+    bf16* vt_out;
+    int64_t qk_plane, vt_plane;
+    int qkv_dim, heads, head_dim, n_tok, n_pad;
+    float q_scale;
+};
+
+int launch_gemm(const GemmParams& p, int planes, hipStream_t stream);
+
+struct AttnParams {
+    const bf16* q;   // [planes][B*H][N][64]   (q pre-scaled by hd^-0.5)
+    const bf16* k;   // [planes][B*H][N][64]
+    const bf16* vt;  // [planes][B*H][64][n_pad]
+    int64_t qk_plane, vt_plane;
+    bf16* o;         // [planes][B*N][ldo]  (head h at columns h*64..)
+    int64_t o_plane;
+    int ldo;
+    int n_tok, n_pad, heads, batch;
+};
+
+int launch_attention(const AttnParams& p, int planes, hipStream_t stream);
+
+struct LayerNormParams {
+    const float* x;  // rows of length D, row stride ldx
+    int ldx;
+    const float* gamma;
+    const float* beta;
+    float eps;
+    int D;
+    int rows;        // number of output rows
+    // input row for output row r: (r / rows_out_per_b) * rows_in_per_b + in_offset + (r % rows_out_per_b)
+    // (rows_out_per_b == 0: identity)
+    int rows_out_per_b, rows_in_per_b, in_offset;
+    bf16* out;       // [planes][rows][ldo]
+    int64_t out_plane;
+    int ldo;
+    float* out_f32;  // optional fp32 copy of the normalised rows ([rows][D]); may be nullptr
+};
+
+int launch_layernorm(const LayerNormParams& p, int planes, hipStream_t stream);
+
+// mask[B,Nt] (1 = masked) -> perm[B,Nt] = [visible tokens ascending | masked tokens ascending];
+// err[0] is set to 1 if any row's visible count != n_vis.
+int launch_mask_to_perm(const uint8_t* mask, int B, int Nt, int n_vis, int* perm, int* err, hipStream_t stream);
+
+struct PatchGatherParams {
+    const float* x;  // frames; element (b,c,t,y,x) at b*sb + c*sc + t*st + y*W + x
+    int64_t sb, sc, st;
+    int normalize;   // apply (x - mean_c)/std_c in-kernel (prediction.py:309-310)
+    int C, H, W, P;
+    const int* perm; // [B][Nt]
+    int Nt, n_rows;  // rows per sample to gather (= n_vis)
+    int B;
+    bf16* out;       // [planes][B*n_rows][ld]  patch vector order (c, ph, pw), zero-padded to ld
+    int64_t out_plane;
+    int ld;
+};
+
+int launch_patch_gather(const PatchGatherParams& p, int planes, hipStream_t stream);
+
+// x_full[b][n_vis + j][:] = mask_token + pos[perm[b][n_vis + j]]   (vmae.py:556-557)
+int launch_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt,
+                            int n_vis, int D, hipStream_t stream);
+
+struct UnembedParams {
+    const float* y;  // [B][Nm][P*P*C], feature order (ph, pw, c)
+    const float* x;  // raw frames, element (b,t,c,y,x) at b*sb + t*st + c*sc + y*W + x
+    int64_t sb, sc, st;
+    const uint8_t* mask;  // [B][Nt]
+    const int* rank;      // [B][Nt]: position of token tau in perm (>= n_vis for masked tokens)
+    int B, T, C, H, W, P, n_vis, Nm;
+    float* out;           // [B][T][C][H][W] contiguous
+};
+
+int launch_unembed(const UnembedParams& p, hipStream_t stream);
+
+int launch_perm_to_rank(const int* perm, int* rank, int B, int Nt, hipStream_t stream);
+
+int launch_split_bf16(const float* x, int64_t n, bf16* hi, bf16* lo, hipStream_t stream);
+
+}  // namespace cwm

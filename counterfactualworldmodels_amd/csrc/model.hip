@@ -1,0 +1,777 @@
+// Model handle, weight packing, workspace and forward orchestration behind the C ABI (include/cwm_hip.h).
+// Restates the control flow of `PretrainVisionTransformer.forward` (cwm/models/VideoMAE/vmae.py:539-560),
+// `PretrainVisionTransformerEncoder.forward_features` (:152-173), `...Decoder.forward` (:246-255) and
+// `Block.forward` (cwm/models/VideoMAE/utils.py:146-153) as a fixed sequence of HIP kernel launches
+// on the caller's stream.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cwm_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace cwm;
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void cwm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* cwm_last_error(void) { return g_err; }
+extern "C" const char* cwm_version(void) { return "cwm_hip 0.1.0 gfx950"; }
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct LinearW {
+    bf16* w = nullptr;  // [2][Npad][Kpad]
+    int64_t plane = 0;
+    int N = 0, K = 0, Npad = 0, Kpad = 0;
+    float* bias = nullptr;  // [Npad] (zero-filled) or nullptr when the layer has no bias
+};
+
+struct BlockW {
+    float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+    LinearW qkv, proj, fc1, fc2;
+};
+
+enum SlotKind { SLOT_MATRIX, SLOT_VECTOR };
+
+struct Slot {
+    SlotKind kind;
+    std::vector<int64_t> shape;
+    LinearW* lin = nullptr;  // SLOT_MATRIX
+    float* dst = nullptr;    // SLOT_VECTOR (device)
+    int64_t numel = 0;
+    bool loaded = false;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    double flops;
+};
+
+struct KernelTimer {
+    bool enabled = false;
+    std::vector<EventPair> pool;
+    size_t used = 0;
+    cwm_kernel_stats acc = {0, 0.0, 0.0};
+};
+
+}  // namespace
+
+struct cwm_model {
+    cwm_config cfg;
+    int device = 0;
+    int Nt = 0, n_per_frame = 0, patch_k = 0, patch_kpad = 0, out_dim = 0;
+    std::vector<BlockW> enc, dec;
+    LinearW patch, e2d, head;
+    float *enc_norm_g = nullptr, *enc_norm_b = nullptr, *dec_norm_g = nullptr, *dec_norm_b = nullptr;
+    float* mask_token = nullptr;
+    float *pos_enc = nullptr, *pos_dec = nullptr;  // [Nt][De], [Nt][Dd] sinusoid tables
+    std::map<std::string, Slot> slots;
+    std::vector<void*> allocs;  // everything to hipFree on destroy (weights)
+    // workspace (grown on demand)
+    int ws_batch = 0, ws_nvis = 0;
+    std::vector<void*> ws_allocs;
+    int *perm = nullptr, *rank = nullptr, *err = nullptr;
+    bf16 *patches = nullptr, *hbuf = nullptr, *gbuf = nullptr, *qbuf = nullptr, *kbuf = nullptr, *vtbuf = nullptr;
+    float *x_enc = nullptr, *x_dec = nullptr;
+    size_t hbuf_plane = 0, gbuf_plane = 0, qk_plane_cap = 0, vt_plane_cap = 0, patches_plane = 0;
+    KernelTimer timers[CWM_KCLASS_COUNT];
+};
+
+namespace {
+
+__global__ void pack_weight_kernel(const float* src, int N, int K, bf16* hi, bf16* lo, int Npad, int Kpad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Npad * Kpad) return;
+    const int n = (int)(i / Kpad), k = (int)(i - (int64_t)n * Kpad);
+    float v = (n < N && k < K) ? src[(size_t)n * K + k] : 0.f;
+    bf16 h, l;
+    split_bf16(v, h, l);
+    hi[i] = h;
+    lo[i] = l;
+}
+
+int dev_alloc(cwm_model* m, void** p, size_t bytes, bool zero, std::vector<void*>& list) {
+    CWM_HIP_CHECK(hipMalloc(p, bytes ? bytes : 16));
+    list.push_back(*p);
+    if (zero) CWM_HIP_CHECK(hipMemset(*p, 0, bytes ? bytes : 16));
+    (void)m;
+    return 0;
+}
+
+int make_linear(cwm_model* m, LinearW& L, int N, int K, bool bias) {
+    L.N = N;
+    L.K = K;
+    L.Npad = round_up(N, 128);
+    L.Kpad = round_up(K, 64);
+    L.plane = (int64_t)L.Npad * L.Kpad;
+    void* p;
+    if (int rc = dev_alloc(m, &p, (size_t)2 * L.plane * sizeof(bf16), true, m->allocs)) return rc;
+    L.w = (bf16*)p;
+    if (bias) {
+        if (int rc = dev_alloc(m, &p, (size_t)L.Npad * sizeof(float), true, m->allocs)) return rc;
+        L.bias = (float*)p;
+    }
+    return 0;
+}
+
+int make_vec(cwm_model* m, float** v, int n) {
+    void* p;
+    if (int rc = dev_alloc(m, &p, (size_t)n * sizeof(float), true, m->allocs)) return rc;
+    *v = (float*)p;
+    return 0;
+}
+
+void add_matrix_slot(cwm_model* m, const std::string& key, LinearW* L, std::vector<int64_t> shape) {
+    Slot s;
+    s.kind = SLOT_MATRIX;
+    s.shape = shape;
+    s.lin = L;
+    s.numel = (int64_t)L->N * L->K;
+    m->slots[key] = s;
+}
+
+void add_vec_slot(cwm_model* m, const std::string& key, float* dst, std::vector<int64_t> shape) {
+    Slot s;
+    s.kind = SLOT_VECTOR;
+    s.shape = shape;
+    s.dst = dst;
+    s.numel = 1;
+    for (auto d : shape) s.numel *= d;
+    m->slots[key] = s;
+}
+
+int make_block(cwm_model* m, BlockW& b, const std::string& pre, int D, int hidden) {
+    int rc;
+    if ((rc = make_vec(m, &b.ln1_g, D)) || (rc = make_vec(m, &b.ln1_b, D)) || (rc = make_vec(m, &b.ln2_g, D)) ||
+        (rc = make_vec(m, &b.ln2_b, D)))
+        return rc;
+    if ((rc = make_linear(m, b.qkv, 3 * D, D, true)) || (rc = make_linear(m, b.proj, D, D, true)) ||
+        (rc = make_linear(m, b.fc1, hidden, D, true)) || (rc = make_linear(m, b.fc2, D, hidden, true)))
+        return rc;
+    add_vec_slot(m, pre + "norm1.weight", b.ln1_g, {D});
+    add_vec_slot(m, pre + "norm1.bias", b.ln1_b, {D});
+    add_vec_slot(m, pre + "norm2.weight", b.ln2_g, {D});
+    add_vec_slot(m, pre + "norm2.bias", b.ln2_b, {D});
+    // qkv bias = [q_bias | 0 | v_bias]  (VideoMAE/utils.py:89-93: there is no k bias)
+    add_vec_slot(m, pre + "attn.q_bias", b.qkv.bias, {D});
+    add_vec_slot(m, pre + "attn.v_bias", b.qkv.bias + 2 * D, {D});
+    add_matrix_slot(m, pre + "attn.qkv.weight", &b.qkv, {3 * D, D});
+    add_matrix_slot(m, pre + "attn.proj.weight", &b.proj, {D, D});
+    add_vec_slot(m, pre + "attn.proj.bias", b.proj.bias, {D});
+    add_matrix_slot(m, pre + "mlp.fc1.weight", &b.fc1, {hidden, D});
+    add_vec_slot(m, pre + "mlp.fc1.bias", b.fc1.bias, {hidden});
+    add_matrix_slot(m, pre + "mlp.fc2.weight", &b.fc2, {D, hidden});
+    add_vec_slot(m, pre + "mlp.fc2.bias", b.fc2.bias, {D});
+    return 0;
+}
+
+// `get_sinusoid_encoding_table` (VideoMAE/utils.py:251-268): float64 on the host, cast to fp32.
+int make_sinusoid(cwm_model* m, float** dst, int n_pos, int d) {
+    std::vector<float> tab((size_t)n_pos * d);
+    for (int pos = 0; pos < n_pos; ++pos)
+        for (int j = 0; j < d; ++j) {
+            const double ang = (double)pos / pow(10000.0, 2.0 * (double)(j / 2) / (double)d);
+            tab[(size_t)pos * d + j] = (float)((j & 1) ? cos(ang) : sin(ang));
+        }
+    if (int rc = make_vec(m, dst, n_pos * d)) return rc;
+    CWM_HIP_CHECK(hipMemcpy(*dst, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ensure_workspace(cwm_model* m, int B, int n_vis) {
+    if (B <= m->ws_batch && n_vis <= m->ws_nvis && m->ws_batch > 0) return 0;
+    CWM_HIP_CHECK(hipDeviceSynchronize());
+    for (void* p : m->ws_allocs) (void)hipFree(p);
+    m->ws_allocs.clear();
+    const cwm_config& c = m->cfg;
+    const int Bc = B > m->ws_batch ? B : m->ws_batch;
+    const int Nv = n_vis > m->ws_nvis ? n_vis : m->ws_nvis;
+    const int Nt = m->Nt;
+    const size_t rows_e = (size_t)Bc * Nv, rows_d = (size_t)Bc * Nt;
+    void* p;
+    int rc;
+#define WS(ptr, type, count)                                                                  \
+    if ((rc = dev_alloc(m, &p, (size_t)(count) * sizeof(type), true, m->ws_allocs))) return rc; \
+    ptr = (type*)p;
+    WS(m->perm, int, rows_d);
+    WS(m->rank, int, rows_d);
+    WS(m->err, int, 4);
+    m->patches_plane = rows_e * m->patch_kpad;
+    WS(m->patches, bf16, 2 * m->patches_plane);
+    WS(m->x_enc, float, rows_e * c.enc_dim);
+    WS(m->x_dec, float, rows_d * c.dec_dim);
+    const size_t act = std::max(rows_e * c.enc_dim, rows_d * c.dec_dim);
+    m->hbuf_plane = act;
+    WS(m->hbuf, bf16, 2 * act);
+    m->gbuf_plane = act * c.mlp_ratio;
+    WS(m->gbuf, bf16, 2 * m->gbuf_plane);
+    m->qk_plane_cap = act;
+    WS(m->qbuf, bf16, 2 * act);
+    WS(m->kbuf, bf16, 2 * act);
+    const size_t vt_e = (size_t)Bc * c.enc_dim * round_up(Nv, 64);
+    const size_t vt_d = (size_t)Bc * c.dec_dim * round_up(Nt, 64);
+    m->vt_plane_cap = std::max(vt_e, vt_d);
+    WS(m->vtbuf, bf16, 2 * m->vt_plane_cap);
+#undef WS
+    m->ws_batch = Bc;
+    m->ws_nvis = Nv;
+    return 0;
+}
+
+// ---- timed launches ---------------------------------------------------------------------------
+int timer_begin(cwm_model* m, int kclass, double flops, hipStream_t s, EventPair** out) {
+    *out = nullptr;
+    KernelTimer& t = m->timers[kclass];
+    if (!t.enabled) return 0;
+    if (t.used == t.pool.size()) {
+        EventPair e;
+        CWM_HIP_CHECK(hipEventCreate(&e.a));
+        CWM_HIP_CHECK(hipEventCreate(&e.b));
+        t.pool.push_back(e);
+    }
+    EventPair& e = t.pool[t.used++];
+    e.flops = flops;
+    CWM_HIP_CHECK(hipEventRecord(e.a, s));
+    *out = &e;
+    return 0;
+}
+
+int timer_end(EventPair* e, hipStream_t s) {
+    if (e) CWM_HIP_CHECK(hipEventRecord(e->b, s));
+    return 0;
+}
+
+int run_gemm(cwm_model* m, const GemmParams& p, int planes, hipStream_t s) {
+    EventPair* e;
+    if (int rc = timer_begin(m, CWM_KCLASS_GEMM, 2.0 * p.M * (double)p.N * p.K, s, &e)) return rc;
+    if (int rc = launch_gemm(p, planes, s)) return rc;
+    return timer_end(e, s);
+}
+
+int run_attention(cwm_model* m, const AttnParams& p, int planes, hipStream_t s) {
+    EventPair* e;
+    const double fl = 4.0 * (double)p.n_tok * p.n_tok * 64.0 * p.heads * p.batch;
+    if (int rc = timer_begin(m, CWM_KCLASS_ATTENTION, fl, s, &e)) return rc;
+    if (int rc = launch_attention(p, planes, s)) return rc;
+    return timer_end(e, s);
+}
+
+GemmParams gemm_base(const bf16* A, int64_t a_plane, int lda, const LinearW& L, int M) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A;
+    p.a_plane = a_plane;
+    p.lda = lda;
+    p.W = L.w;
+    p.w_plane = L.plane;
+    p.M = M;
+    p.N = L.N;
+    p.K = L.Kpad;
+    p.bias = L.bias;
+    return p;
+}
+
+// Block.forward (VideoMAE/utils.py:146-153): x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x)))
+int run_block(cwm_model* m, const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, hipStream_t s) {
+    const int M = B * n_tok;
+    const int64_t hplane = (int64_t)M * D;
+    const int hidden = w.fc1.N;
+    const int n_pad = round_up(n_tok, 64);
+    int rc;
+    LayerNormParams ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = x; ln.ldx = D; ln.gamma = w.ln1_g; ln.beta = w.ln1_b; ln.eps = m->cfg.ln_eps; ln.D = D; ln.rows = M;
+    ln.out = m->hbuf; ln.out_plane = hplane; ln.ldo = D;
+    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+
+    GemmParams g = gemm_base(m->hbuf, hplane, D, w.qkv, M);
+    g.epi = EPI_QKV;
+    g.rows_in = n_tok; g.rows_out = n_tok; g.map_stride = n_tok;
+    g.q_out = m->qbuf; g.k_out = m->kbuf; g.vt_out = m->vtbuf;
+    g.qk_plane = hplane; g.vt_plane = (int64_t)B * D * n_pad;
+    g.qkv_dim = D; g.heads = H; g.head_dim = D / H; g.n_tok = n_tok; g.n_pad = n_pad;
+    g.q_scale = 1.0f / sqrtf((float)(D / H));
+    if ((rc = run_gemm(m, g, planes, s))) return rc;
+
+    AttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = m->qbuf; a.k = m->kbuf; a.vt = m->vtbuf; a.qk_plane = hplane; a.vt_plane = (int64_t)B * D * n_pad;
+    a.o = m->hbuf; a.o_plane = hplane; a.ldo = D; a.n_tok = n_tok; a.n_pad = n_pad; a.heads = H; a.batch = B;
+    if ((rc = run_attention(m, a, planes, s))) return rc;
+
+    g = gemm_base(m->hbuf, hplane, D, w.proj, M);
+    g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
+    if ((rc = run_gemm(m, g, planes, s))) return rc;
+
+    ln.gamma = w.ln2_g; ln.beta = w.ln2_b;
+    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+
+    g = gemm_base(m->hbuf, hplane, D, w.fc1, M);
+    g.epi = EPI_BF16_GELU; g.out_hi = m->gbuf; g.out_plane = (int64_t)M * hidden; g.ldo = hidden;
+    if ((rc = run_gemm(m, g, planes, s))) return rc;
+
+    g = gemm_base(m->gbuf, (int64_t)M * hidden, hidden, w.fc2, M);
+    g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
+    return run_gemm(m, g, planes, s);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
+    CWM_REQUIRE(cfg && out, "cwm_model_create: null argument");
+    const cwm_config& c = *cfg;
+    CWM_REQUIRE(c.patch > 0 && c.img_h % c.patch == 0 && c.img_w % c.patch == 0, "image size (%d,%d) must be divisible by patch size %d",
+                c.img_h, c.img_w, c.patch);
+    CWM_REQUIRE(c.patch % 4 == 0 && c.img_w % 4 == 0, "patch size must be a multiple of 4");
+    CWM_REQUIRE(c.enc_heads > 0 && c.dec_heads > 0 && c.enc_dim == 64 * c.enc_heads && c.dec_dim == 64 * c.dec_heads,
+                "this build supports head_dim 64 only (enc %d/%d, dec %d/%d)", c.enc_dim, c.enc_heads, c.dec_dim, c.dec_heads);
+    CWM_REQUIRE(c.enc_dim <= 1024 && c.dec_dim <= 1024 && c.enc_dim % 64 == 0 && c.dec_dim % 64 == 0, "embed dims must be multiples of 64, <= 1024");
+    CWM_REQUIRE(c.in_chans == 3 && c.num_frames >= 1 && c.mlp_ratio >= 1 && c.enc_depth >= 1 && c.dec_depth >= 1, "unsupported config");
+    cwm_model* m = new cwm_model();
+    m->cfg = c;
+    CWM_HIP_CHECK(hipGetDevice(&m->device));
+    m->n_per_frame = (c.img_h / c.patch) * (c.img_w / c.patch);
+    m->Nt = m->n_per_frame * c.num_frames;
+    m->patch_k = c.in_chans * c.patch * c.patch;
+    m->patch_kpad = round_up(m->patch_k, 64);
+    m->out_dim = c.in_chans * c.patch * c.patch;
+    int rc = 0;
+    m->enc.resize(c.enc_depth);
+    m->dec.resize(c.dec_depth);
+    do {
+        if ((rc = make_linear(m, m->patch, c.enc_dim, m->patch_k, true))) break;
+        add_matrix_slot(m, "encoder.patch_embed.proj.weight", &m->patch, {c.enc_dim, c.in_chans, 1, c.patch, c.patch});
+        add_vec_slot(m, "encoder.patch_embed.proj.bias", m->patch.bias, {c.enc_dim});
+        for (int i = 0; i < c.enc_depth && !rc; ++i)
+            rc = make_block(m, m->enc[i], "encoder.blocks." + std::to_string(i) + ".", c.enc_dim, c.mlp_ratio * c.enc_dim);
+        if (rc) break;
+        if ((rc = make_vec(m, &m->enc_norm_g, c.enc_dim)) || (rc = make_vec(m, &m->enc_norm_b, c.enc_dim))) break;
+        add_vec_slot(m, "encoder.norm.weight", m->enc_norm_g, {c.enc_dim});
+        add_vec_slot(m, "encoder.norm.bias", m->enc_norm_b, {c.enc_dim});
+        if ((rc = make_linear(m, m->e2d, c.dec_dim, c.enc_dim, false))) break;
+        add_matrix_slot(m, "encoder_to_decoder.weight", &m->e2d, {c.dec_dim, c.enc_dim});
+        if ((rc = make_vec(m, &m->mask_token, c.dec_dim))) break;
+        add_vec_slot(m, "mask_token", m->mask_token, {1, 1, c.dec_dim});
+        for (int i = 0; i < c.dec_depth && !rc; ++i)
+            rc = make_block(m, m->dec[i], "decoder.blocks." + std::to_string(i) + ".", c.dec_dim, c.mlp_ratio * c.dec_dim);
+        if (rc) break;
+        if ((rc = make_vec(m, &m->dec_norm_g, c.dec_dim)) || (rc = make_vec(m, &m->dec_norm_b, c.dec_dim))) break;
+        add_vec_slot(m, "decoder.norm.weight", m->dec_norm_g, {c.dec_dim});
+        add_vec_slot(m, "decoder.norm.bias", m->dec_norm_b, {c.dec_dim});
+        if ((rc = make_linear(m, m->head, m->out_dim, c.dec_dim, true))) break;
+        add_matrix_slot(m, "decoder.head.weight", &m->head, {m->out_dim, c.dec_dim});
+        add_vec_slot(m, "decoder.head.bias", m->head.bias, {m->out_dim});
+        if ((rc = make_sinusoid(m, &m->pos_enc, m->Nt, c.enc_dim))) break;  // vmae.py:75
+        if ((rc = make_sinusoid(m, &m->pos_dec, m->Nt, c.dec_dim))) break;  // vmae.py:366
+    } while (0);
+    if (rc) {
+        cwm_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return CWM_OK;
+}
+
+extern "C" void cwm_model_destroy(cwm_model* m) {
+    if (!m) return;
+    (void)hipDeviceSynchronize();
+    for (void* p : m->allocs) (void)hipFree(p);
+    for (void* p : m->ws_allocs) (void)hipFree(p);
+    for (auto& t : m->timers)
+        for (auto& e : t.pool) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+    delete m;
+}
+
+extern "C" int cwm_model_load_weight(cwm_model* m, const char* key, const float* data, int on_device, const int64_t* shape, int ndim) {
+    CWM_REQUIRE(m && key && data && shape, "cwm_model_load_weight: null argument");
+    auto it = m->slots.find(key);
+    CWM_REQUIRE(it != m->slots.end(), "unexpected key in state_dict: %s", key);
+    Slot& s = it->second;
+    bool same = (int)s.shape.size() == ndim;
+    for (int i = 0; same && i < ndim; ++i) same = s.shape[i] == shape[i];
+    CWM_REQUIRE(same, "size mismatch for %s", key);
+    if (s.kind == SLOT_VECTOR) {
+        CWM_HIP_CHECK(hipMemcpy(s.dst, data, (size_t)s.numel * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    } else {
+        LinearW& L = *s.lin;
+        const float* src = data;
+        float* tmp = nullptr;
+        if (!on_device) {
+            CWM_HIP_CHECK(hipMalloc((void**)&tmp, (size_t)s.numel * sizeof(float)));
+            hipError_t e = hipMemcpy(tmp, data, (size_t)s.numel * sizeof(float), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(tmp);
+                cwm_set_error("hipMemcpy failed: %s", hipGetErrorString(e));
+                return CWM_ERR_HIP;
+            }
+            src = tmp;
+        }
+        const int64_t total = (int64_t)L.Npad * L.Kpad;
+        hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, src, L.N, L.K, L.w,
+                           L.w + L.plane, L.Npad, L.Kpad);
+        hipError_t e = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (e != hipSuccess) {
+            cwm_set_error("pack_weight failed: %s", hipGetErrorString(e));
+            return CWM_ERR_HIP;
+        }
+    }
+    s.loaded = true;
+    return CWM_OK;
+}
+
+extern "C" int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen) {
+    int missing = 0;
+    if (buf && buflen > 0) buf[0] = 0;
+    for (auto& kv : m->slots)
+        if (!kv.second.loaded) {
+            if (!missing && buf && buflen > 0) snprintf(buf, buflen, "%s", kv.first.c_str());
+            ++missing;
+        }
+    return missing;
+}
+
+extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
+    CWM_REQUIRE(m && a, "cwm_forward: null argument");
+    CWM_REQUIRE(a->x_dev && a->mask_dev && a->y_tokens_dev, "cwm_forward: x_dev, mask_dev and y_tokens_dev are required");
+    CWM_REQUIRE(a->mode == CWM_MODE_FAST || a->mode == CWM_MODE_PARITY, "cwm_forward: bad mode %d", a->mode);
+    const cwm_config& c = m->cfg;
+    const int B = a->batch, Nt = m->Nt, Nv = a->n_vis, Nm = Nt - Nv;
+    CWM_REQUIRE(B > 0, "cwm_forward: batch must be positive");
+    CWM_REQUIRE(Nv > 0 && Nm > 0, "cwm_forward: need 0 < n_vis (%d) < num tokens (%d)", Nv, Nt);
+    {
+        char miss[256];
+        const int nmiss = cwm_model_missing_weights(m, miss, sizeof(miss));
+        CWM_REQUIRE(nmiss == 0, "cwm_forward: %d state-dict tensors not loaded (first: %s)", nmiss, miss);
+    }
+    if (int rc = ensure_workspace(m, B, Nv)) return rc;
+    hipStream_t s = (hipStream_t)a->stream;
+    const int planes = a->mode == CWM_MODE_PARITY ? 2 : 1;
+    int rc;
+
+    CWM_HIP_CHECK(hipMemsetAsync(m->err, 0, sizeof(int), s));
+    if ((rc = launch_mask_to_perm(a->mask_dev, B, Nt, Nv, m->perm, m->err, s))) return rc;
+
+    // a1-a3: frame load (+normalise) + tubelet patch gather of the visible tokens, patch-embed GEMM
+    // with bias and positional-table add in the epilogue
+    PatchGatherParams pg;
+    memset(&pg, 0, sizeof(pg));
+    pg.x = a->x_dev; pg.sb = a->x_stride_b; pg.sc = a->x_stride_c; pg.st = a->x_stride_t; pg.normalize = a->normalize;
+    pg.C = c.in_chans; pg.H = c.img_h; pg.W = c.img_w; pg.P = c.patch; pg.perm = m->perm; pg.Nt = Nt; pg.n_rows = Nv; pg.B = B;
+    pg.out = m->patches; pg.out_plane = (int64_t)B * Nv * m->patch_kpad; pg.ld = m->patch_kpad;
+    if ((rc = launch_patch_gather(pg, planes, s))) return rc;
+
+    GemmParams g = gemm_base(m->patches, pg.out_plane, m->patch_kpad, m->patch, B * Nv);
+    g.epi = EPI_F32; g.C = m->x_enc; g.ldc = c.enc_dim;
+    g.resid = m->pos_enc; g.ldr = c.enc_dim; g.resid_rowmap = m->perm; g.rows_in = Nv; g.rows_out = Nv; g.map_stride = Nt;
+    if ((rc = run_gemm(m, g, planes, s))) return rc;
+
+    // a4-a6: encoder blocks over the visible tokens
+    for (int i = 0; i < c.enc_depth; ++i)
+        if ((rc = run_block(m, m->enc[i], m->x_enc, B, Nv, c.enc_dim, c.enc_heads, planes, s))) return rc;
+
+    // a7: encoder.norm, encoder_to_decoder (no bias); a8: + pos[vis] written straight into x_full rows [0,Nv)
+    LayerNormParams ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = m->x_enc; ln.ldx = c.enc_dim; ln.gamma = m->enc_norm_g; ln.beta = m->enc_norm_b; ln.eps = c.ln_eps; ln.D = c.enc_dim;
+    ln.rows = B * Nv; ln.out = m->hbuf; ln.out_plane = (int64_t)B * Nv * c.enc_dim; ln.ldo = c.enc_dim;
+    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+    g = gemm_base(m->hbuf, ln.out_plane, c.enc_dim, m->e2d, B * Nv);
+    g.epi = EPI_F32; g.C = m->x_dec; g.ldc = c.dec_dim;
+    g.resid = m->pos_dec; g.ldr = c.dec_dim; g.resid_rowmap = m->perm; g.rows_in = Nv; g.rows_out = Nt; g.map_stride = Nt;
+    if ((rc = run_gemm(m, g, planes, s))) return rc;
+    if ((rc = launch_fill_mask_tokens(m->x_dec, m->mask_token, m->pos_dec, m->perm, B, Nt, Nv, c.dec_dim, s))) return rc;
+
+    // a9: decoder blocks over the full token set, norm + head on the last Nm tokens
+    for (int i = 0; i < c.dec_depth; ++i)
+        if ((rc = run_block(m, m->dec[i], m->x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, s))) return rc;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = m->x_dec; ln.ldx = c.dec_dim; ln.gamma = m->dec_norm_g; ln.beta = m->dec_norm_b; ln.eps = c.ln_eps; ln.D = c.dec_dim;
+    ln.rows = B * Nm; ln.rows_out_per_b = Nm; ln.rows_in_per_b = Nt; ln.in_offset = Nv;
+    ln.out = m->hbuf; ln.out_plane = (int64_t)B * Nm * c.dec_dim; ln.ldo = c.dec_dim;
+    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+    g = gemm_base(m->hbuf, ln.out_plane, c.dec_dim, m->head, B * Nm);
+    g.epi = EPI_F32; g.C = a->y_tokens_dev; g.ldc = m->out_dim;
+    if ((rc = run_gemm(m, g, planes, s))) return rc;
+
+    // a11: patch un-embed scatter
+    if (a->y_video_dev) {
+        const float* xr = a->xraw_dev ? a->xraw_dev : a->x_dev;
+        CWM_REQUIRE(a->xraw_dev || a->normalize, "cwm_forward: y_video_dev needs the raw frames (xraw_dev) when normalize=0");
+        if ((rc = launch_perm_to_rank(m->perm, m->rank, B, Nt, s))) return rc;
+        UnembedParams u;
+        memset(&u, 0, sizeof(u));
+        u.y = a->y_tokens_dev; u.x = xr; u.sb = a->x_stride_b; u.sc = a->x_stride_c; u.st = a->x_stride_t;
+        u.mask = a->mask_dev; u.rank = m->rank; u.B = B; u.T = c.num_frames; u.C = c.in_chans; u.H = c.img_h; u.W = c.img_w;
+        u.P = c.patch; u.n_vis = Nv; u.Nm = Nm; u.out = a->y_video_dev;
+        if ((rc = launch_unembed(u, s))) return rc;
+    }
+
+    if (a->check) {
+        int herr = 0;
+        CWM_HIP_CHECK(hipMemcpyAsync(&herr, m->err, sizeof(int), hipMemcpyDeviceToHost, s));
+        CWM_HIP_CHECK(hipStreamSynchronize(s));
+        if (herr) {
+            cwm_set_error("mask rows do not all have n_vis=%d visible tokens (shape '[%d, -1, %d]' is invalid for the gathered input)", Nv, B,
+                          c.enc_dim);
+            return CWM_ERR_MASK;
+        }
+    }
+    return CWM_OK;
+}
+
+extern "C" int cwm_timing_enable(cwm_model* m, int kclass, int enable) {
+    CWM_REQUIRE(m && kclass >= 0 && kclass < CWM_KCLASS_COUNT, "cwm_timing_enable: bad argument");
+    KernelTimer& t = m->timers[kclass];
+    t.enabled = enable != 0;
+    if (enable && t.pool.size() < 512) {
+        while (t.pool.size() < 512) {
+            EventPair e;
+            CWM_HIP_CHECK(hipEventCreate(&e.a));
+            CWM_HIP_CHECK(hipEventCreate(&e.b));
+            e.flops = 0;
+            t.pool.push_back(e);
+        }
+    }
+    return CWM_OK;
+}
+
+extern "C" int cwm_timing_collect(cwm_model* m, int kclass, cwm_kernel_stats* out) {
+    CWM_REQUIRE(m && out && kclass >= 0 && kclass < CWM_KCLASS_COUNT, "cwm_timing_collect: bad argument");
+    KernelTimer& t = m->timers[kclass];
+    for (size_t i = 0; i < t.used; ++i) {
+        CWM_HIP_CHECK(hipEventSynchronize(t.pool[i].b));
+        float ms = 0.f;
+        CWM_HIP_CHECK(hipEventElapsedTime(&ms, t.pool[i].a, t.pool[i].b));
+        t.acc.launches += 1;
+        t.acc.total_ms += ms;
+        t.acc.total_flops += t.pool[i].flops;
+    }
+    t.used = 0;
+    *out = t.acc;
+    t.acc = {0, 0.0, 0.0};
+    return CWM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone kernel entry points (tests).  They allocate scratch per call: not for hot loops.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    T* get(size_t count, bool zero = false) {
+        void* p = nullptr;
+        if (hipMalloc(&p, count * sizeof(T) + 16) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        if (zero) (void)hipMemset(p, 0, count * sizeof(T));
+        return (T*)p;
+    }
+};
+
+__global__ void pad_split_rows_kernel(const float* src, int rows, int K, bf16* hi, bf16* lo, int Kpad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * Kpad) return;
+    const int r = (int)(i / Kpad), k = (int)(i - (int64_t)r * Kpad);
+    const float v = k < K ? src[(size_t)r * K + k] : 0.f;
+    bf16 h, l;
+    split_bf16(v, h, l);
+    hi[i] = h;
+    lo[i] = l;
+}
+
+// qkv [B,N,3,H,64] fp32 -> Q (scaled), K [B*H,N,64], V^T [B*H,64,n_pad]
+__global__ void qkv_scatter_kernel(const float* qkv, int B, int N, int H, int n_pad, float scale, bf16* q, bf16* k, bf16* vt,
+                                   int64_t qk_plane, int64_t vt_plane) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = H * 64;
+    if (i >= (int64_t)B * N * 3 * D) return;
+    const int c = (int)(i % (3 * D));
+    const int64_t row = i / (3 * D);
+    const int b = (int)(row / N), n = (int)(row - (int64_t)b * N);
+    const int which = c / D, cc = c - which * D, h = cc / 64, d = cc - h * 64;
+    float v = qkv[i];
+    if (which == 0) v *= scale;
+    bf16 hi, lo;
+    split_bf16(v, hi, lo);
+    if (which < 2) {
+        bf16* dst = which == 0 ? q : k;
+        const size_t o = ((size_t)(b * H + h) * N + n) * 64 + d;
+        dst[o] = hi;
+        dst[o + qk_plane] = lo;
+    } else {
+        const size_t o = ((size_t)(b * H + h) * 64 + d) * n_pad + n;
+        vt[o] = hi;
+        vt[o + vt_plane] = lo;
+    }
+}
+
+__global__ void merge_planes_kernel(const bf16* hi, const bf16* lo, float* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (float)hi[i] + (lo ? (float)lo[i] : 0.f);
+}
+}  // namespace
+
+extern "C" int cwm_split_bf16(const float* x_dev, int64_t n, void* hi_dev, void* lo_dev, void* stream) {
+    CWM_REQUIRE(x_dev && hi_dev && n >= 0, "cwm_split_bf16: bad argument");
+    return launch_split_bf16(x_dev, n, (bf16*)hi_dev, (bf16*)lo_dev, (hipStream_t)stream);
+}
+
+extern "C" int cwm_linear(const float* a_dev, const float* w_dev, const float* bias_dev, const float* resid_dev, float* c_dev, int M,
+                          int N, int K, int gelu, int mode, void* stream) {
+    CWM_REQUIRE(a_dev && w_dev && c_dev && M > 0 && N > 0 && K > 0, "cwm_linear: bad argument");
+    CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_linear: bad mode");
+    hipStream_t s = (hipStream_t)stream;
+    const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
+    const int Kp = round_up(K, 64), Np = round_up(N, 128);
+    Scratch sc;
+    bf16* A = sc.get<bf16>((size_t)2 * M * Kp);
+    bf16* W = sc.get<bf16>((size_t)2 * Np * Kp);
+    float* bias = sc.get<float>(Np, true);
+    bf16* G = gelu ? sc.get<bf16>((size_t)2 * M * N) : nullptr;
+    CWM_REQUIRE(A && W && bias && (!gelu || G), "cwm_linear: out of device memory");
+    hipLaunchKernelGGL(pad_split_rows_kernel, dim3((unsigned)(((int64_t)M * Kp + 255) / 256)), dim3(256), 0, s, a_dev, M, K, A,
+                       A + (size_t)M * Kp, Kp);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)(((int64_t)Np * Kp + 255) / 256)), dim3(256), 0, s, w_dev, N, K, W,
+                       W + (size_t)Np * Kp, Np, Kp);
+    if (bias_dev) CWM_HIP_CHECK(hipMemcpyAsync(bias, bias_dev, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.a_plane = (int64_t)M * Kp; p.lda = Kp; p.W = W; p.w_plane = (int64_t)Np * Kp;
+    p.M = M; p.N = N; p.K = Kp; p.bias = bias;
+    if (gelu) {
+        p.epi = EPI_BF16_GELU; p.out_hi = G; p.out_plane = (int64_t)M * N; p.ldo = N;
+    } else {
+        p.epi = EPI_F32; p.C = c_dev; p.ldc = N; p.resid = resid_dev; p.ldr = N;
+    }
+    if (int rc = launch_gemm(p, planes, s)) return rc;
+    if (gelu) {
+        const int64_t n = (int64_t)M * N;
+        hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, G, planes == 2 ? G + n : nullptr, c_dev, n);
+    }
+    CWM_HIP_CHECK(hipStreamSynchronize(s));
+    return CWM_OK;
+}
+
+extern "C" int cwm_attention(const float* qkv_dev, float* o_dev, int B, int N, int H, int mode, void* stream) {
+    CWM_REQUIRE(qkv_dev && o_dev && B > 0 && N > 0 && H > 0, "cwm_attention: bad argument");
+    CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_attention: bad mode");
+    hipStream_t s = (hipStream_t)stream;
+    const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
+    const int D = H * 64, n_pad = round_up(N, 64);
+    const int64_t qk_plane = (int64_t)B * N * D, vt_plane = (int64_t)B * D * n_pad;
+    Scratch sc;
+    bf16* q = sc.get<bf16>(2 * qk_plane);
+    bf16* k = sc.get<bf16>(2 * qk_plane);
+    bf16* vt = sc.get<bf16>(2 * vt_plane);
+    bf16* o = sc.get<bf16>(2 * qk_plane);
+    CWM_REQUIRE(q && k && vt && o, "cwm_attention: out of device memory");
+    // poison V^T padding with NaN bit patterns: the kernel must not let it leak
+    CWM_HIP_CHECK(hipMemsetAsync(vt, 0xFF, (size_t)2 * vt_plane * sizeof(bf16), s));
+    const int64_t total = (int64_t)B * N * 3 * D;
+    hipLaunchKernelGGL(qkv_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv_dev, B, N, H, n_pad, 0.125f, q, k,
+                       vt, qk_plane, vt_plane);
+    AttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = q; a.k = k; a.vt = vt; a.qk_plane = qk_plane; a.vt_plane = vt_plane; a.o = o; a.o_plane = qk_plane; a.ldo = D;
+    a.n_tok = N; a.n_pad = n_pad; a.heads = H; a.batch = B;
+    if (int rc = launch_attention(a, planes, s)) return rc;
+    hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)((qk_plane + 255) / 256)), dim3(256), 0, s, o, planes == 2 ? o + qk_plane : nullptr,
+                       o_dev, qk_plane);
+    CWM_HIP_CHECK(hipStreamSynchronize(s));
+    return CWM_OK;
+}
+
+extern "C" int cwm_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev, int rows, int D, float eps,
+                             void* stream) {
+    CWM_REQUIRE(x_dev && gamma_dev && beta_dev && y_dev && rows > 0, "cwm_layernorm: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    Scratch sc;
+    bf16* tmp = sc.get<bf16>((size_t)2 * rows * D);
+    CWM_REQUIRE(tmp, "cwm_layernorm: out of device memory");
+    LayerNormParams ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = x_dev; ln.ldx = D; ln.gamma = gamma_dev; ln.beta = beta_dev; ln.eps = eps; ln.D = D; ln.rows = rows;
+    ln.out = tmp; ln.out_plane = (int64_t)rows * D; ln.ldo = D; ln.out_f32 = y_dev;
+    if (int rc = launch_layernorm(ln, 2, s)) return rc;
+    CWM_HIP_CHECK(hipStreamSynchronize(s));
+    return CWM_OK;
+}
+
+extern "C" int cwm_mask_to_perm(const uint8_t* mask_dev, int B, int Nt, int n_vis, int32_t* perm_dev, void* stream) {
+    CWM_REQUIRE(mask_dev && perm_dev && B > 0 && Nt > 0, "cwm_mask_to_perm: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    Scratch sc;
+    int* err = sc.get<int>(4, true);
+    CWM_REQUIRE(err, "cwm_mask_to_perm: out of device memory");
+    if (int rc = launch_mask_to_perm(mask_dev, B, Nt, n_vis, perm_dev, err, s)) return rc;
+    int herr = 0;
+    CWM_HIP_CHECK(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
+    CWM_HIP_CHECK(hipStreamSynchronize(s));
+    if (herr) {
+        cwm_set_error("mask rows do not all have n_vis=%d visible tokens", n_vis);
+        return CWM_ERR_MASK;
+    }
+    return CWM_OK;
+}
+
+extern "C" int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const uint8_t* mask_dev, int B, int T, int C, int H, int W, int P,
+                           int n_vis, float* out_dev, void* stream) {
+    CWM_REQUIRE(y_tokens_dev && x_dev && mask_dev && out_dev, "cwm_unembed: null argument");
+    CWM_REQUIRE(P > 0 && H % P == 0 && W % P == 0, "cwm_unembed: image size must be divisible by the patch size");
+    hipStream_t s = (hipStream_t)stream;
+    const int Nt = T * (H / P) * (W / P);
+    Scratch sc;
+    int* perm = sc.get<int>((size_t)B * Nt);
+    int* rank = sc.get<int>((size_t)B * Nt);
+    int* err = sc.get<int>(4, true);
+    CWM_REQUIRE(perm && rank && err, "cwm_unembed: out of device memory");
+    int rc;
+    if ((rc = launch_mask_to_perm(mask_dev, B, Nt, n_vis, perm, err, s))) return rc;
+    if ((rc = launch_perm_to_rank(perm, rank, B, Nt, s))) return rc;
+    UnembedParams u;
+    memset(&u, 0, sizeof(u));
+    u.y = y_tokens_dev; u.x = x_dev; u.sb = (int64_t)T * C * H * W; u.st = (int64_t)C * H * W; u.sc = (int64_t)H * W;
+    u.mask = mask_dev; u.rank = rank; u.B = B; u.T = T; u.C = C; u.H = H; u.W = W; u.P = P; u.n_vis = n_vis; u.Nm = Nt - n_vis; u.out = out_dev;
+    if ((rc = launch_unembed(u, s))) return rc;
+    int herr = 0;
+    CWM_HIP_CHECK(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
+    CWM_HIP_CHECK(hipStreamSynchronize(s));
+    if (herr) {
+        cwm_set_error("mask rows do not all have n_vis=%d visible tokens", n_vis);
+        return CWM_ERR_MASK;
+    }
+    return CWM_OK;
+}

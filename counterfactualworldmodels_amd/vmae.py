@@ -1,0 +1,289 @@
+"""Host-side mirror of the reference VMAE predictor classes, backed by libcwm_hip.so.
+
+`PretrainVisionTransformer` keeps the reference's class surface -- constructor semantics of the
+factories (`cwm/models/VideoMAE/vmae.py:563-619`), parameter names/shapes (state-dict compatible with
+the published checkpoints), attributes read by the wrapper/UI (`patch_size`, `image_size`,
+`num_frames`, `mask_size`, `encoder.patch_embed.proj.kernel_size`, ...) and
+`forward(x[B,C,T,H,W], mask[B,Nt]) -> [B,Nm,C*P*P]` (`vmae.py:539-560`) -- but holds no compute:
+the forward pass is one call into the C ABI (`include/cwm_hip.h: cwm_forward`), which runs the
+hand-written HIP kernels.  There is no PyTorch fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import CONFIGS, LN_EPS, VmaeConfig
+
+
+def trunc_normal_(tensor, mean=0.0, std=1.0):
+    # vmae.py:25-26 (timm's trunc_normal_ == torch.nn.init.trunc_normal_)
+    return nn.init.trunc_normal_(tensor, mean=mean, std=std, a=-std, b=std)
+
+
+def _init_weights(m):
+    # vmae.py:100-107 / :212-219
+    if isinstance(m, nn.Linear):
+        nn.init.xavier_uniform_(m.weight)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.constant_(m.bias, 0)
+        nn.init.constant_(m.weight, 1.0)
+
+
+class _NoForward(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(
+            "%s is a parameter container: the computation runs inside libcwm_hip.so via "
+            "PretrainVisionTransformer.forward" % type(self).__name__
+        )
+
+
+class Attention(_NoForward):
+    """Parameter layout of VideoMAE/utils.py:57-85 (fused qkv without bias, separate q/v bias)."""
+
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.q_bias = nn.Parameter(torch.zeros(dim))
+        self.v_bias = nn.Parameter(torch.zeros(dim))
+        self.proj = nn.Linear(dim, dim)
+
+
+class Mlp(_NoForward):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class Block(_NoForward):
+    def __init__(self, dim, num_heads, mlp_ratio):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=LN_EPS)
+        self.attn = Attention(dim, num_heads)
+        self.norm2 = nn.LayerNorm(dim, eps=LN_EPS)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+
+class PatchEmbed(_NoForward):
+    def __init__(self, cfg: VmaeConfig):
+        super().__init__()
+        self.patch_size = (cfg.patch, cfg.patch)
+        self.tubelet_size = 1
+        self.num_frames = cfg.num_frames
+        self.num_patches = cfg.num_tokens
+        self.embed_dim = cfg.enc_dim
+        self.proj = nn.Conv3d(cfg.in_chans, cfg.enc_dim, kernel_size=(1, cfg.patch, cfg.patch), stride=(1, cfg.patch, cfg.patch))
+
+
+class PretrainVisionTransformerEncoder(_NoForward):
+    def __init__(self, cfg: VmaeConfig):
+        super().__init__()
+        self.embed_dim = self.num_features = cfg.enc_dim
+        self.patch_size = (1, cfg.patch, cfg.patch)
+        self.pt, self.ph, self.pw = self.patch_size
+        self.patch_embed = PatchEmbed(cfg)
+        self.image_size = cfg.img_size[0]
+        self.num_patches = cfg.num_tokens
+        self.num_frames = cfg.num_frames
+        self.blocks = nn.ModuleList([Block(cfg.enc_dim, cfg.enc_heads, cfg.mlp_ratio) for _ in range(cfg.enc_depth)])
+        self.norm = nn.LayerNorm(cfg.enc_dim, eps=LN_EPS)
+        self.head = nn.Identity()
+        self.timestamps = None
+        self.apply(_init_weights)
+
+
+class PretrainVisionTransformerDecoder(_NoForward):
+    def __init__(self, cfg: VmaeConfig):
+        super().__init__()
+        self.embed_dim = self.num_features = cfg.dec_dim
+        self.num_classes = cfg.out_dim
+        self.patch_size = (cfg.patch, cfg.patch)
+        self.blocks = nn.ModuleList([Block(cfg.dec_dim, cfg.dec_heads, cfg.mlp_ratio) for _ in range(cfg.dec_depth)])
+        self.norm = nn.LayerNorm(cfg.dec_dim, eps=LN_EPS)
+        self.head = nn.Linear(cfg.dec_dim, cfg.out_dim)
+        self.apply(_init_weights)
+
+
+class PretrainVisionTransformer(nn.Module):
+    """Drop-in for `cwm.models.VideoMAE.vmae.PretrainVisionTransformer` (main_input=None models)."""
+
+    def __init__(self, cfg: VmaeConfig, mode: str = "parity", use_flash_attention: bool = True, **unused):
+        super().__init__()
+        self.cfg = cfg
+        self.mode = mode
+        _lib.mode_id(mode)
+        self.get_main_input = None
+        self.encoder = PretrainVisionTransformerEncoder(cfg)
+        self.decoder = PretrainVisionTransformerDecoder(cfg)
+        self.encoder_to_decoder = nn.Linear(cfg.enc_dim, cfg.dec_dim, bias=False)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, cfg.dec_dim))
+        trunc_normal_(self.mask_token, std=0.02)
+        self.timestamps = None
+        self.num_frames = cfg.num_frames
+        self.num_patches = cfg.num_tokens
+        self.num_patches_per_frame = cfg.tokens_per_frame
+        self.patch_size = self.encoder.patch_size
+        self.image_size = tuple(cfg.img_size)
+        self.default_cfg = {}
+        self._handle: Optional[int] = None
+        self._handle_device: Optional[torch.device] = None
+        self._loaded: Dict[str, Tuple[int, int]] = {}
+
+    # ---- reference attribute surface -------------------------------------------------------------
+    @property
+    def mask_size(self):  # vmae.py:386-390
+        return (
+            self.num_frames // self.patch_size[0],
+            self.image_size[-2] // self.patch_size[-2],
+            self.image_size[-1] // self.patch_size[-1],
+        )
+
+    def get_num_layers(self):
+        return len(self.encoder.blocks)
+
+    # ---- C-ABI plumbing --------------------------------------------------------------------------
+    def _ensure_handle(self, device: torch.device) -> int:
+        lib = _lib.get_lib()
+        if self._handle is not None and self._handle_device == device:
+            return self._handle
+        self._release()
+        c = self.cfg
+        ccfg = _lib.CwmConfig(
+            c.img_size[0], c.img_size[1], c.patch, c.num_frames, c.in_chans, c.enc_dim, c.enc_depth, c.enc_heads,
+            c.dec_dim, c.dec_depth, c.dec_heads, c.mlp_ratio, LN_EPS,
+        )
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.cwm_model_create(C.byref(ccfg), C.byref(h)))
+        self._handle = h.value
+        self._handle_device = device
+        self._loaded = {}
+        return self._handle
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            try:
+                _lib.get_lib().cwm_model_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+            self._loaded = {}
+
+    def __del__(self):
+        self._release()
+
+    def sync_weights(self, device: Optional[torch.device] = None) -> int:
+        """Push every parameter that changed since the last call into the library (packs to bf16
+        hi/lo planes).  Counterpart of `load_state_dict` at the boundary (prediction.py:81-107)."""
+        device = device or next(self.parameters()).device
+        h = self._ensure_handle(device)
+        lib = _lib.get_lib()
+        n = 0
+        with torch.cuda.device(device):
+            for name, p in self.state_dict(keep_vars=True).items():
+                tag = (p.data_ptr(), p._version)
+                if self._loaded.get(name) == tag:
+                    continue
+                t = p.detach()
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    t = t.float().contiguous()
+                on_dev = 1 if t.is_cuda else 0
+                if t.is_cuda and t.device != device:
+                    t = t.to(device)
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                _lib.check(lib.cwm_model_load_weight(h, name.encode(), t.data_ptr(), on_dev, shape, t.dim()))
+                self._loaded[name] = tag
+                n += 1
+        return n
+
+    def _run(self, x, strides, normalize, mask, n_vis, want_video, xraw=None, check=True):
+        _lib.require_gpu()
+        if not x.is_cuda:
+            raise RuntimeError("PretrainVisionTransformer.forward needs a CUDA/HIP tensor (no CPU fallback); got %s" % x.device)
+        lib = _lib.get_lib()
+        dev = x.device
+        self.sync_weights(dev)
+        c = self.cfg
+        B = x.shape[0]
+        Nt = c.num_tokens
+        mask = mask.to(device=dev, dtype=torch.bool).reshape(B, -1).contiguous()
+        if mask.shape[1] != Nt:
+            raise RuntimeError("mask has %d tokens per row, model expects %d" % (mask.shape[1], Nt))
+        if n_vis is None:
+            n_vis = Nt - int(mask[0].sum().item())
+        Nm = Nt - n_vis
+        y = torch.empty((B, Nm, c.out_dim), device=dev, dtype=torch.float32)
+        video = torch.empty((B, c.num_frames, c.in_chans, c.img_size[0], c.img_size[1]), device=dev, dtype=torch.float32) if want_video else None
+        args = _lib.CwmForwardArgs(
+            x.data_ptr(), strides[0], strides[1], strides[2], int(normalize), mask.data_ptr(), B, n_vis, y.data_ptr(),
+            _lib.ptr(video), _lib.ptr(xraw), _lib.mode_id(self.mode), int(check), _lib.current_stream_handle(dev),
+        )
+        with torch.cuda.device(dev):
+            _lib.check(lib.cwm_forward(self._handle, C.byref(args)))
+        return y, video
+
+    @staticmethod
+    def _frame_strides(x: torch.Tensor, c_dim: int, t_dim: int):
+        """(tensor, (stride_b, stride_c, stride_t)) with H,W contiguous; copies only if needed."""
+        if x.dtype != torch.float32:
+            x = x.float()
+        H, W = x.shape[-2:]
+        if x.stride(-1) != 1 or x.stride(-2) != W:
+            x = x.contiguous()
+        return x, (x.stride(0), x.stride(c_dim), x.stride(t_dim))
+
+    # ---- reference forward: vmae.py:539-560 ------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x, mask, timestamps=None, *args, n_vis: Optional[int] = None, check: bool = True, **kwargs):
+        """x: float[B,C,T,H,W] (already pre-processed by the caller, any strides), mask: bool[B,Nt]
+        with equal visible counts per row.  Returns float[B,Nm,C*P*P]."""
+        if x.dim() != 5 or x.shape[1] != self.cfg.in_chans or x.shape[2] != self.cfg.num_frames:
+            raise RuntimeError("expected x of shape [B,%d,%d,H,W], got %s" % (self.cfg.in_chans, self.cfg.num_frames, tuple(x.shape)))
+        if tuple(x.shape[-2:]) != tuple(self.cfg.img_size):
+            raise RuntimeError("input image size %s does not match the model's %s" % (tuple(x.shape[-2:]), self.cfg.img_size))
+        x, strides = self._frame_strides(x, 1, 2)
+        y, _ = self._run(x, strides, False, mask, n_vis, False, check=check)
+        return y
+
+    @torch.no_grad()
+    def predict_video(self, x_btchw, mask, normalize: bool = True, n_vis: Optional[int] = None, check: bool = True):
+        """Fused wrapper path: raw [B,T,C,H,W] frames in [0,1] -> (tokens [B,Nm,C*P*P], video
+        [B,T,C,H,W]) = `_preprocess` + forward + `pred_patches_to_video`
+        (prediction.py:304-312, :419-422, :245-259) in one library call."""
+        if x_btchw.dim() != 5 or x_btchw.shape[2] != self.cfg.in_chans or x_btchw.shape[1] != self.cfg.num_frames:
+            raise RuntimeError("expected x of shape [B,%d,%d,H,W], got %s" % (self.cfg.num_frames, self.cfg.in_chans, tuple(x_btchw.shape)))
+        x, strides = self._frame_strides(x_btchw, 2, 1)
+        return self._run(x, strides, normalize, mask, n_vis, True, xraw=x, check=check)
+
+    # ---- kernel timing (bench.py roofline) ------------------------------------------------------------
+    def timing_enable(self, kclass: int, enable: bool = True):
+        if self._handle is None:
+            raise RuntimeError("run a forward pass (or sync_weights) before enabling timing")
+        _lib.check(_lib.get_lib().cwm_timing_enable(self._handle, kclass, int(enable)))
+
+    def timing_collect(self, kclass: int):
+        st = _lib.CwmKernelStats()
+        _lib.check(_lib.get_lib().cwm_timing_collect(self._handle, kclass, C.byref(st)))
+        return {"launches": st.launches, "total_ms": st.total_ms, "total_flops": st.total_flops}
+
+
+# ---- factories (same names / defaults as vmae.py:597-619) -------------------------------------------
+def base_16x16patch_2frames_1tube(**kwargs):
+    return PretrainVisionTransformer(CONFIGS["base_16x16patch_2frames_1tube"], **kwargs)
+
+
+def base_8x8patch_2frames_1tube(**kwargs):
+    return PretrainVisionTransformer(CONFIGS["base_8x8patch_2frames_1tube"], **kwargs)
+
+
+def large_4x4patch_2frames_1tube(**kwargs):
+    return PretrainVisionTransformer(CONFIGS["large_4x4patch_2frames_1tube"], **kwargs)

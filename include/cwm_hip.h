@@ -1,0 +1,131 @@
+/*
+ * cwm_hip.h -- C ABI of libcwm_hip.so: the MI355X (gfx950) VMAE predictor forward pass.
+ *
+ * This is the drop-in boundary for ONE path of neuroailab/CounterfactualWorldModels: everything
+ * executed inside `self.predictor(x, mask)` at cwm/models/prediction.py:419-422, i.e.
+ * `PretrainVisionTransformer.forward` (cwm/models/VideoMAE/vmae.py:539-560) with the primitives of
+ * cwm/models/VideoMAE/utils.py (PatchEmbed :156-198, Attention :57-121, Mlp :37-54, Block :124-153),
+ * plus the two thin wrapper steps either side of it: `_preprocess` / `imagenet_normalize`
+ * (prediction.py:304-312, utils.py:15-21) and `pred_patches_to_video` (prediction.py:245-259).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer named *_dev is a HIP device pointer owned by the
+ *     caller; `stream` is a hipStream_t passed as void* (NULL = default stream)
+ *   - functions return 0 on success, a negative code on failure, never throw; the message is
+ *     available from cwm_last_error() (thread-local)
+ *   - the library owns packed (bf16 hi/lo) weights and a workspace per model handle; no caller
+ *     tensor is retained past a call
+ *   - one process per GPU; a model handle lives on the device that was current at create time
+ */
+#ifndef CWM_HIP_H
+#define CWM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CWM_OK 0
+#define CWM_ERR_INVALID (-1) /* bad argument / precondition (mirrors the reference's shape errors) */
+#define CWM_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define CWM_ERR_MASK (-3)    /* rows of `mask` do not all have n_vis visible tokens (vmae.py:167 reshape) */
+
+/* Arithmetic mode of the GEMM / attention kernels. */
+#define CWM_MODE_FAST 1   /* bf16 MFMA operands, fp32 accumulate                         */
+#define CWM_MODE_PARITY 2 /* split-bf16 (hi+lo, 3 MFMAs per product): <=1e-3 vs fp32 CPU */
+
+/* Mirrors the constructor arguments of PretrainVisionTransformer (vmae.py:261-297) that the
+ * factories vmae.py:563-619 set; tubelet_size is 1 on this path. */
+typedef struct cwm_config {
+    int32_t img_h, img_w;   /* 224, 224 */
+    int32_t patch;          /* 8 (base_8x8), 4 (large_4x4), 16 */
+    int32_t num_frames;     /* 2 */
+    int32_t in_chans;       /* 3 */
+    int32_t enc_dim, enc_depth, enc_heads;
+    int32_t dec_dim, dec_depth, dec_heads;
+    int32_t mlp_ratio;      /* 4 */
+    float ln_eps;           /* 1e-6 */
+} cwm_config;
+
+typedef struct cwm_model cwm_model;
+
+/* replaces: model construction via the factories, vmae.py:597-619 */
+int cwm_model_create(const cwm_config* cfg, cwm_model** out);
+void cwm_model_destroy(cwm_model* m);
+
+/* replaces: `model.load_state_dict(...)` (prediction.py:81-107).  `key` is the reference state-dict
+ * name, `data` fp32 in PyTorch layout, on the host (on_device=0) or on the
+ * model's device (on_device=1).  The tensor is copied and packed; the caller's buffer is not kept.
+ * Re-loading a key overwrites it.  Unknown key or wrong shape -> CWM_ERR_INVALID. */
+int cwm_model_load_weight(cwm_model* m, const char* key, const float* data, int on_device, const int64_t* shape, int ndim);
+/* Number of state-dict tensors not loaded yet (0 = ready); fills `buf` with the first missing key. */
+int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen);
+
+typedef struct cwm_forward_args {
+    /* frames: element (b, c, t, y, x) at x_dev[b*x_stride_b + c*x_stride_c + t*x_stride_t + y*W + x]
+     * (so both [B,C,T,H,W] and the wrapper's [B,T,C,H,W] layouts are accepted without a copy) */
+    const float* x_dev;
+    int64_t x_stride_b, x_stride_c, x_stride_t;
+    /* 1: x_dev is the raw [0,1] wrapper input and (x-mean)/std is fused into the frame load
+     * (prediction.py:309-310); 0: x_dev is already what the model should see (vmae.py:539 seam) */
+    int32_t normalize;
+    const uint8_t* mask_dev; /* bool [B, Nt], 1 = masked (torch.bool storage) */
+    int32_t batch;
+    int32_t n_vis;           /* visible tokens per row; every row must have exactly this many */
+    float* y_tokens_dev;     /* out [B, Nt - n_vis, in_chans*patch*patch] fp32, feature order (ph pw c) */
+    /* optional fused `pred_patches_to_video`: out [B, T, C, H, W]; visible patches are copied from
+     * xraw_dev (same strides as x_dev; NULL = use x_dev, valid when normalize=1) */
+    float* y_video_dev;
+    const float* xraw_dev;
+    int32_t mode;            /* CWM_MODE_FAST or CWM_MODE_PARITY */
+    int32_t check;           /* 1: synchronise the stream and verify the mask precondition */
+    void* stream;
+} cwm_forward_args;
+
+/* replaces: `self.predictor(self._preprocess(x), mask)` prediction.py:419-422
+ *           = PretrainVisionTransformer.forward vmae.py:539-560,
+ * and optionally `pred_patches_to_video` prediction.py:245-259. */
+int cwm_forward(cwm_model* m, const cwm_forward_args* args);
+
+/* ---- timing hooks (bench.py roofline): HIP events around every launch of one kernel class ------ */
+#define CWM_KCLASS_GEMM 0
+#define CWM_KCLASS_ATTENTION 1
+#define CWM_KCLASS_COUNT 2
+typedef struct cwm_kernel_stats {
+    int64_t launches;
+    double total_ms;    /* sum of launch durations (HIP events on the launch stream) */
+    double total_flops; /* algorithmic FLOPs (2*M*N*K; attention 4*N*N*hd per head) of those launches */
+} cwm_kernel_stats;
+int cwm_timing_enable(cwm_model* m, int kclass, int enable);
+/* Synchronises the recorded events, accumulates, and resets the event pool. */
+int cwm_timing_collect(cwm_model* m, int kclass, cwm_kernel_stats* out);
+
+/* ---- stand-alone kernel entry points (kernel-level parity tests; same kernels the model uses) -- */
+/* fp32 -> bf16 hi (and lo if lo_dev != NULL) */
+int cwm_split_bf16(const float* x_dev, int64_t n, void* hi_dev, void* lo_dev, void* stream);
+/* C[M,N] (fp32, ldc=N) = A[M,K] * W[N,K]^T + bias (+ resid), all fp32 device inputs; the library
+ * splits/pads the operands exactly as the model path does.  replaces: F.linear (VideoMAE/utils.py:48-53) */
+int cwm_linear(const float* a_dev, const float* w_dev, const float* bias_dev, const float* resid_dev, float* c_dev,
+               int M, int N, int K, int gelu, int mode, void* stream);
+/* O[B,N,H*64] = softmax(q k^T) v per head from a packed qkv activation [B,N,3*H*64] (fp32 device),
+ * q scaled by 64^-0.5 after bias as in VideoMAE/utils.py:94-113. */
+int cwm_attention(const float* qkv_dev, float* o_dev, int B, int N, int H, int mode, void* stream);
+/* y = LayerNorm(x) (fp32 in/out, eps, affine).  replaces nn.LayerNorm at VideoMAE/utils.py:148-149 */
+int cwm_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev, int rows, int D,
+                  float eps, void* stream);
+/* perm[B,Nt] = [visible ascending | masked ascending]; returns CWM_ERR_MASK if a row's visible
+ * count != n_vis (synchronises).  replaces the boolean gathers vmae.py:167,555-556 */
+int cwm_mask_to_perm(const uint8_t* mask_dev, int B, int Nt, int n_vis, int32_t* perm_dev, void* stream);
+/* replaces pred_patches_to_video (prediction.py:245-259); x is [B,T,C,H,W] contiguous raw frames */
+int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const uint8_t* mask_dev, int B, int T, int C, int H, int W,
+                int P, int n_vis, float* out_dev, void* stream);
+
+const char* cwm_last_error(void);
+/* "cwm_hip <version> gfx950" */
+const char* cwm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CWM_HIP_H */

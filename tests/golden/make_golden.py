@@ -1,0 +1,211 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE (this container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--skip-large]
+
+The reference's own tests pin nothing for the predictor path (there are none), so
+the oracle (`oracle/vmae_oracle.py`) and the HIP path are pinned against these
+captured reference outputs.  Weights/inputs come from the package's deterministic
+generator (`counterfactualworldmodels_amd/synthetic.py`), loaded into the *reference*
+modules; only inputs that are cheap to store, and the reference outputs, are saved.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_import  # noqa: E402
+from counterfactualworldmodels_amd import config as C  # noqa: E402
+from counterfactualworldmodels_amd import synthetic as S  # noqa: E402
+
+TINY = C.VmaeConfig(
+    name="tiny_8x8", img_size=(32, 32), patch=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=1, dec_heads=2
+)
+
+
+def build_ref_model(ns, cfg: C.VmaeConfig, seed: int):
+    from functools import partial
+
+    if cfg.name in ("base_8x8patch_2frames_1tube", "large_4x4patch_2frames_1tube", "base_16x16patch_2frames_1tube"):
+        m = getattr(ns.vmae, cfg.name)()
+    else:
+        m = ns.vmae.PretrainVisionTransformer(
+            img_size=cfg.img_size[0],
+            patch_size=(cfg.patch, cfg.patch),
+            encoder_embed_dim=cfg.enc_dim,
+            encoder_depth=cfg.enc_depth,
+            encoder_num_heads=cfg.enc_heads,
+            encoder_num_classes=0,
+            decoder_embed_dim=cfg.dec_dim,
+            decoder_depth=cfg.dec_depth,
+            decoder_num_heads=cfg.dec_heads,
+            mlp_ratio=cfg.mlp_ratio,
+            qkv_bias=True,
+            num_frames=cfg.num_frames,
+            tubelet_size=1,
+            norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+        )
+    sd = {k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, seed).items()}
+    res = m.load_state_dict(sd)
+    assert not res.missing_keys and not res.unexpected_keys, res
+    return m.eval().requires_grad_(False)
+
+
+def run_model_case(ns, cfg, *, batch, k_vis, clump, seed, out_name, through_wrapper=True):
+    t0 = time.time()
+    m = build_ref_model(ns, cfg, seed)
+    x = torch.from_numpy(S.synthetic_frames(batch, cfg, seed))
+    mask = torch.from_numpy(S.synthetic_masks(batch, cfg, k_vis, seed, clump))
+    out = {
+        "cfg_name": np.array(cfg.name),
+        "seed": np.array(seed),
+        "batch": np.array(batch),
+        "k_vis": np.array(k_vis),
+        "clump": np.array(clump),
+        "mask": mask.numpy(),
+    }
+    with torch.no_grad():
+        if through_wrapper:
+            # the reference "Predictor class surface": prediction.py:17, predict :406
+            G = ns.prediction.PredictorBasedGenerator(
+                predictor=m, imagenet_normalize_inputs=True, temporal_dim=2, seed=0
+            )
+            y_model = m(G._preprocess(x), mask.clone())
+            video = G.predict(x, mask.clone(), frame=None)
+            out["video_digest"] = np.array(
+                [video.double().sum().item(), video.double().abs().sum().item(), (video.double() ** 2).sum().item()]
+            )
+            out["video_frame1_rows"] = video[:, 1, :, :: max(1, cfg.img_size[0] // 8)].numpy().copy()
+        else:
+            mean = torch.tensor(C.IMAGENET_MEAN).view(1, 3, 1, 1, 1)
+            std = torch.tensor(C.IMAGENET_STD).view(1, 3, 1, 1, 1)
+            y_model = m((x.transpose(1, 2) - mean) / std, mask.clone())
+    out["y_tokens"] = y_model.numpy()
+    if cfg.name == "tiny_8x8":
+        out["x"] = x.numpy()
+    np.savez_compressed(os.path.join(HERE, out_name), **out)
+    print(f"[golden] {out_name}: y {tuple(y_model.shape)} std {y_model.std():.4f} ({time.time() - t0:.1f}s)")
+
+
+def run_block_case(ns):
+    """Per-op tiles at real width, short N."""
+    from functools import partial
+
+    D, H, N, B = 768, 12, 40, 2
+    blk = ns.vutils.Block(dim=D, num_heads=H, mlp_ratio=4, qkv_bias=True, init_values=0.0,
+                          norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    schema = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    sd = {k: torch.from_numpy(S.synthetic_tensor("golden_block." + k, shp, 7)) for k, shp in schema.items()}
+    blk.load_state_dict(sd)
+    blk.eval()
+    g = np.random.Generator(np.random.PCG64(11))
+    x = torch.from_numpy(g.standard_normal((B, N, D), dtype=np.float32))
+    with torch.no_grad():
+        h1 = blk.norm1(x)
+        a = blk.attn(h1)
+        y = blk(x)
+        mlp = blk.mlp(blk.norm2(x + a))
+    np.savez_compressed(
+        os.path.join(HERE, "block_768.npz"),
+        x=x.numpy(), norm1=h1.numpy(), attn=a.numpy(), mlp=mlp.numpy(), y=y.numpy(),
+        heads=np.array(H), seed=np.array(7),
+    )
+    print("[golden] block_768.npz")
+
+
+def run_index_cases(ns):
+    """Bit-exact mask / index fixtures (part)."""
+    out = {}
+    # RectangularizeMasks('min') with torch's global RNG (masking.py:90-132)
+    rect = ns.masking.RectangularizeMasks("min")
+    g = np.random.Generator(np.random.PCG64(5))
+    masks = g.random((6, 2 * 14 * 14)) < 0.9
+    masks[:, :196] = False
+    torch.manual_seed(1234)
+    m_in = torch.from_numpy(masks.copy())
+    m_out = rect(m_in.clone())
+    out["rect_in"] = masks
+    out["rect_out"] = m_out.numpy()
+    out["rect_seed"] = np.array(1234)
+    # sinusoid tables (VideoMAE/utils.py:251-268) and torch-fp32 pos_embedding (transformer.py:37-52)
+    for (n, d) in [(1568, 768), (1568, 384), (6272, 1024), (6272, 512), (32, 128)]:
+        t = ns.vutils.get_sinusoid_encoding_table(n, d)[0].double()
+        out[f"sinusoid_{n}_{d}"] = np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item(),
+                                             t[n - 1, d - 1].item(), t[n // 2, d // 3].item()])
+    for (n, d) in [(25, 384), (25, 192), (6272, 512)]:
+        t = ns.transformer.pos_embedding(n, d, "cpu")[0].double()
+        out[f"posemb_{n}_{d}"] = np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item(),
+                                           t[n - 1, d - 1].item(), t[n // 2, d // 3].item()])
+    # Patchify round trip / pred_patches_to_video (prediction.py:245-259)
+    cfg = TINY
+    m = build_ref_model(ns, cfg, 3)
+    G = ns.prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2, seed=0)
+    x = torch.from_numpy(S.synthetic_frames(3, cfg, 3))
+    mask = torch.from_numpy(S.synthetic_masks(3, cfg, 4, 3))
+    G.set_image_size(x.shape[-2:])
+    G.inp_shape = x.shape
+    y = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).standard_normal(
+        (3, int(mask[0].sum()), cfg.out_dim), dtype=np.float32))
+    vid = G.pred_patches_to_video(y, x, mask)
+    out["unembed_x"] = x.numpy()
+    out["unembed_mask"] = mask.numpy()
+    out["unembed_y"] = y.numpy()
+    out["unembed_video"] = vid.numpy()
+    np.savez_compressed(os.path.join(HERE, "index_ops.npz"), **out)
+    print("[golden] index_ops.npz")
+
+
+def run_init_case(ns):
+    """Reference constructor RNG parity: seed -> freshly initialised parameters (vmae.py:90,209,371)."""
+    out = {}
+    for seed in (0, 5):
+        from functools import partial
+
+        torch.manual_seed(seed)
+        m = ns.vmae.PretrainVisionTransformer(
+            img_size=32, patch_size=(8, 8), encoder_embed_dim=128, encoder_depth=2, encoder_num_heads=2,
+            encoder_num_classes=0, decoder_embed_dim=128, decoder_depth=1, decoder_num_heads=2, mlp_ratio=4,
+            qkv_bias=True, num_frames=2, tubelet_size=1, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+        sd = m.state_dict()
+        out[f"keys_{seed}"] = np.array(list(sd.keys()))
+        out[f"sums_{seed}"] = np.array([v.double().sum().item() for v in sd.values()])
+        out[f"abs_{seed}"] = np.array([v.double().abs().sum().item() for v in sd.values()])
+    np.savez_compressed(os.path.join(HERE, "init_tiny.npz"), **out)
+    print("[golden] init_tiny.npz")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-large", action="store_true")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    torch.set_num_threads(os.cpu_count() or 1)
+    ns = ref_import.import_reference()
+    if args.only == "init":
+        run_init_case(ns)
+        return
+    run_init_case(ns)
+    run_index_cases(ns)
+    run_block_case(ns)
+    run_model_case(ns, TINY, batch=3, k_vis=4, clump=1, seed=3, out_name="tiny_8x8_k4.npz")
+    run_model_case(ns, TINY, batch=2, k_vis=1, clump=1, seed=4, out_name="tiny_8x8_k1.npz")
+    base = C.CONFIGS["base_8x8patch_2frames_1tube"]
+    run_model_case(ns, base, batch=2, k_vis=8, clump=1, seed=0, out_name="base8_k8_b2.npz")
+    run_model_case(ns, base, batch=1, k_vis=1, clump=1, seed=1, out_name="base8_k1_b1.npz")
+    if not args.skip_large:
+        large = C.CONFIGS["large_4x4patch_2frames_1tube"]
+        run_model_case(ns, large, batch=1, k_vis=32, clump=2, seed=0, out_name="large4_k32_b1.npz",
+                       through_wrapper=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+"""Host-side logic of the package that needs no GPU: schema, factories/initialisation parity,
+mask helpers, synthetic generators, error behaviour without a device."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from counterfactualworldmodels_amd import config as C
+from counterfactualworldmodels_amd import masking, synthetic as S, vmae
+from oracle import vmae_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TINY = C.VmaeConfig(name="tiny_8x8", img_size=(32, 32), patch=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128,
+                    dec_depth=1, dec_heads=2)
+
+
+def test_parameter_counts():
+    # known-answer parameter counts (ipynb:244 for L/4)
+    assert C.num_parameters(C.CONFIGS["base_8x8patch_2frames_1tube"]) == 92_661_312
+    assert C.num_parameters(C.CONFIGS["large_4x4patch_2frames_1tube"]) == 340_709_936
+    assert len(C.state_dict_schema(C.CONFIGS["base_8x8patch_2frames_1tube"])) == 218
+    assert C.CONFIGS["base_8x8patch_2frames_1tube"].num_tokens == 1568
+    assert C.CONFIGS["large_4x4patch_2frames_1tube"].num_tokens == 6272
+
+
+def test_module_state_dict_matches_schema():
+    m = vmae.PretrainVisionTransformer(TINY)
+    sd = m.state_dict()
+    schema = C.state_dict_schema(TINY)
+    assert list(sd.keys()) == list(schema.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == schema[k], k
+    assert m.patch_size == (1, 8, 8) and m.mask_size == (2, 4, 4) and m.num_frames == 2
+    assert m.encoder.patch_embed.proj.kernel_size == (1, 8, 8)
+
+
+@pytest.mark.parametrize("seed", [0, 5])
+def test_constructor_rng_parity_with_reference(seed):
+    """Same seed -> same freshly initialised parameters as the reference constructor (fixture
+    captured from the reference by make_golden.py)."""
+    g = np.load(os.path.join(GOLDEN, "init_tiny.npz"))
+    torch.manual_seed(seed)
+    m = vmae.PretrainVisionTransformer(TINY)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g[f"keys_{seed}"]]
+    sums = np.array([v.double().sum().item() for v in sd.values()])
+    abss = np.array([v.double().abs().sum().item() for v in sd.values()])
+    assert np.allclose(sums, g[f"sums_{seed}"], rtol=0, atol=1e-9)
+    assert np.allclose(abss, g[f"abs_{seed}"], rtol=0, atol=1e-9)
+
+
+def test_factories_exist():
+    for name in ("base_8x8patch_2frames_1tube", "base_16x16patch_2frames_1tube", "large_4x4patch_2frames_1tube"):
+        assert callable(getattr(vmae, name))
+
+
+def test_rectangularize_matches_oracle_and_mutates_in_place():
+    g = np.load(os.path.join(GOLDEN, "index_ops.npz"))
+    a = torch.from_numpy(g["rect_in"].copy())
+    torch.manual_seed(int(g["rect_seed"]))
+    out = masking.RectangularizeMasks("min")(a)
+    assert np.array_equal(out.numpy(), g["rect_out"])
+    assert np.array_equal(a.numpy(), g["rect_out"])  # in place, like the reference
+    same = torch.from_numpy(g["rect_out"].copy())
+    assert torch.equal(masking.RectangularizeMasks("min")(same.clone()), same)  # idempotent on rectangular input
+    assert masking.RectangularizeMasks("full")(same).all()
+    assert masking.RectangularizeMasks(None)(same) is same
+
+
+def test_rectangularize_empty_and_ragged():
+    r = masking.RectangularizeMasks("min")
+    z = torch.zeros(3, 10, dtype=torch.bool)
+    assert not r(z.clone()).any()
+    ragged = torch.zeros(3, 10, dtype=torch.bool)
+    ragged[0, :7] = True
+    ragged[1, :2] = True
+    ragged[2, :] = True
+    out = r(ragged.clone())
+    assert out.sum(-1).tolist() == [2, 2, 2]
+    assert (out & ~ragged).sum() == 0  # only ever un-masks
+
+
+def test_upsample_masks():
+    m = torch.tensor([[True, False], [False, True]])[None]
+    up = masking.upsample_masks(m, (4, 4))
+    assert up.shape == (1, 4, 4) and up[0, 0, 1] and not up[0, 0, 2] and up[0, 3, 3]
+    assert masking.upsample_masks(up, (2, 2)).equal(m)
+
+
+def test_synthetic_generators_are_stable():
+    cfg = C.CONFIGS["base_8x8patch_2frames_1tube"]
+    w = S.synthetic_tensor("encoder.blocks.0.attn.qkv.weight", (2304, 768), 0)
+    assert w.dtype == np.float32 and abs(float(w.std()) - float(np.sqrt(2.0 / (2304 + 768))) ) < 1e-3
+    x = S.synthetic_frames(1, cfg, 0)
+    assert x.shape == (1, 2, 3, 224, 224) and 0 <= x.min() and x.max() < 1
+    mk = S.synthetic_masks(4, cfg, 8, 0)
+    assert mk.shape == (4, 1568) and not mk[:, :784].any() and ((~mk).sum(-1) == 792).all()
+    mk = S.synthetic_masks(2, C.CONFIGS["large_4x4patch_2frames_1tube"], 32, 0, clump=2)
+    assert ((~mk).sum(-1) == 3168).all()
+    p = S.synthetic_prompts(256, cfg, 0)
+    assert p.shape == (256, 4) and (np.abs(p[:, 2:]).max() <= 3) and (np.abs(p[:, 2:]).sum(-1) > 0).all()
+
+
+def test_forward_without_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = vmae.PretrainVisionTransformer(TINY)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 2, 32, 32), torch.zeros(1, 32, dtype=torch.bool))
+    with pytest.raises(RuntimeError):
+        m.decoder(torch.zeros(1))
+
+
+def test_oracle_spec_matches_config():
+    for name, cfg in C.CONFIGS.items():
+        s = O.SPECS[name]
+        for f in ("patch", "enc_dim", "enc_depth", "enc_heads", "dec_dim", "dec_depth", "dec_heads", "mlp_ratio"):
+            assert getattr(s, f) == getattr(cfg, f)
