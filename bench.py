@@ -1,0 +1,174 @@
+"""bench.py -- predicted frames/s of the VMAE predictor path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic frame pairs already resident in HBM:
+raw [B,2,3,224,224] frames + masks -> normalise, tubelet patch embed + mask gather, ViT encoder over
+visible tokens, ViT decoder over the full token set, pixel head, patch un-embed -> predicted frames.
+N=1 workload = BASELINE.json configs[1]: ViT-B/8, batch 32.  With N>1 every rank runs the same
+per-GPU batch on its own shard of frame pairs (independent units, no data-path collective): weak
+scaling, value = all ranks' frame pairs / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from counterfactualworldmodels_amd import _lib, config as C, synthetic as S, vmae  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    "base8": dict(cfg="base_8x8patch_2frames_1tube", batch=32, k_vis=8, clump=1,
+                  name="ViT-base VMAE 8x8, batch=32 synthetic frame pairs (BASELINE configs[1])"),
+    "large4": dict(cfg="large_4x4patch_2frames_1tube", batch=8, k_vis=32, clump=2,
+                   name="ViT-large VMAE 4x4, batch=8 (BASELINE configs[2])"),
+}
+
+
+def timed_steps(model, x, mask, n_vis, steps, distributed):
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.predict_video(x, mask, normalize=True, n_vis=n_vis, check=False)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_baseline(cfg, k_vis, clump, seed, budget_s=20.0):
+    """The oracle (CPU restatement of the reference, torch fp32 eager) on this box's host cores."""
+    from oracle import vmae_oracle as O
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    W = {k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, seed).items()}
+    B = 2
+    x = torch.from_numpy(S.synthetic_frames(B, cfg, seed))
+    mask = torch.from_numpy(S.synthetic_masks(B, cfg, k_vis, seed, clump))
+    spec = O.SPECS[cfg.name]
+    with torch.no_grad():
+        O.predict(W, spec, x, mask, frame=None)  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            O.predict(W, spec, x, mask, frame=None)
+            n += 1
+            if time.perf_counter() - t0 > budget_s or n >= 8:
+                break
+        dt = time.perf_counter() - t0
+    return {
+        "value": B * n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": "%d forward passes of batch %d (%s, k_vis=%d) through oracle/vmae_oracle.py, torch CPU fp32 eager" % (n, B, cfg.name, k_vis),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="base8", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="parity", choices=["parity", "fast"])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra fast-mode measurement")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    n_gpus = world if distributed else 1
+
+    wl = WORKLOADS[args.workload]
+    cfg = C.CONFIGS[wl["cfg"]]
+    B = args.batch or wl["batch"]
+    n_vis = cfg.tokens_per_frame + wl["k_vis"]
+    dev = torch.device("cuda", local_rank)
+
+    model = vmae.PretrainVisionTransformer(cfg, mode=args.mode)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, 0).items()})
+    model = model.to(dev).eval()
+    # every rank owns a different shard of synthetic frame pairs (seed = rank)
+    x = torch.from_numpy(S.synthetic_frames(B, cfg, rank)).to(dev)
+    mask = torch.from_numpy(S.synthetic_masks(B, cfg, wl["k_vis"], rank, wl["clump"])).to(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        model.predict_video(x, mask, normalize=True, n_vis=n_vis, check=True)
+    torch.cuda.synchronize()
+
+    model.timing_enable(_lib.KCLASS_GEMM, True)
+    dt = timed_steps(model, x, mask, n_vis, args.steps, distributed)
+    gemm = model.timing_collect(_lib.KCLASS_GEMM)
+    model.timing_enable(_lib.KCLASS_GEMM, False)
+
+    value = B * n_gpus * args.steps / dt
+    flops_pair = C.algorithmic_flops(cfg, n_vis)
+    out = {
+        "metric": "predicted frames/sec (2x224x224, ViT-B/8)" if args.workload == "base8" else "predicted frames/sec (2x224x224, ViT-L/4)",
+        "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {
+            "workload": wl["name"], "predictor": cfg.name, "per_gpu_batch": B, "global_batch": B * n_gpus, "n_vis": n_vis,
+            "tokens_decoder": cfg.num_tokens, "mode": args.mode,
+            "arithmetic": "split-bf16 (hi+lo) MFMA operands, 3 MFMAs/product, fp32 accumulate" if args.mode == "parity"
+            else "bf16 MFMA operands, fp32 accumulate",
+            "parallelism": "dp%d (independent frame pairs per rank, no collective)" % n_gpus,
+            "weights": "random-init (deterministic synthetic generator)",
+        },
+        "model_tflops": flops_pair * value / 1e12,
+        "model_frac_of_bf16_peak": flops_pair * value / 1e12 / (PEAK_BF16_TFLOPS * n_gpus),
+    }
+    ach = gemm["total_flops"] / (gemm["total_ms"] * 1e-3) / 1e12 if gemm["total_ms"] > 0 else 0.0
+    out["roofline"] = {
+        "bound": "mfma", "kernel": "cwm::gemm_bf16_kernel<%d>" % (2 if args.mode == "parity" else 1),
+        "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+        "launches": gemm["launches"], "avg_launch_us": 1e3 * gemm["total_ms"] / max(gemm["launches"], 1),
+        "note": "algorithmic 2*M*N*K of all GEMM launches in the timed region / summed HIP-event durations (rank 0)"
+                + ("; parity mode executes 3x these FLOPs on the MFMA pipe" if args.mode == "parity" else ""),
+    }
+
+    if not args.no_secondary:
+        other = "fast" if args.mode == "parity" else "parity"
+        model.mode = other
+        for _ in range(2):
+            model.predict_video(x, mask, normalize=True, n_vis=n_vis, check=False)
+        dt2 = timed_steps(model, x, mask, n_vis, args.steps, distributed)
+        out["secondary"] = {"mode": other, "value": B * n_gpus * args.steps / dt2, "unit": "frames/s",
+                            "ms_per_step": 1e3 * dt2 / args.steps,
+                            "note": "plain-bf16 fast mode does NOT meet the 1e-3 parity tolerance (see tests/test_model_gpu.py)"
+                            if other == "fast" else "split-bf16 parity mode"}
+        model.mode = args.mode
+
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, wl["k_vis"], wl["clump"], 0)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

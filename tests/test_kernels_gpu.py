@@ -1,0 +1,166 @@
+"""Kernel-level parity on a real MI355X, through the C ABI, against the CPU oracle / torch fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from counterfactualworldmodels_amd import _lib
+from oracle import vmae_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# tolerances (max-abs, on O(1) outputs): split-bf16 "parity" mode carries ~2^-16 relative operand
+# error; plain bf16 "fast" mode 2^-9 per operand.
+TOL = {"parity": 2e-4, "fast": 6e-2}
+
+
+@pytest.fixture(scope="module")
+def gu():
+    import gpu_utils
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    _lib.get_lib()
+    return gpu_utils
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("mode", ["parity", "fast"])
+@pytest.mark.parametrize(
+    "M,N,K",
+    [(128, 128, 64), (256, 384, 768), (200, 192, 384), (77, 48, 512), (1000, 1152, 384), (300, 768, 192), (130, 1024, 48), (5, 16, 64)],
+)
+def test_linear_matches_torch(gu, mode, M, N, K):
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ref = F.linear(a, w, b)
+    out = gu.linear(a, w, b, mode=mode)
+    err = (out - ref).abs().max().item()
+    assert err <= TOL[mode] * max(1.0, ref.abs().max().item() / 4), (err, mode, M, N, K)
+
+
+@pytest.mark.parametrize("mode", ["parity", "fast"])
+def test_linear_residual_and_gelu(gu, mode):
+    M, N, K = 333, 256, 1024
+    a, w, b, r = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=K ** -0.5), rnd(N, seed=6), rnd(M, N, seed=7)
+    out = gu.linear(a, w, b, resid=r, mode=mode)
+    assert (out - (F.linear(a, w, b) + r)).abs().max().item() <= TOL[mode]
+    out = gu.linear(a, w, b, gelu=True, mode=mode)
+    assert (out - F.gelu(F.linear(a, w, b))).abs().max().item() <= TOL[mode]
+    out = gu.linear(a, w, None, mode=mode)
+    assert (out - F.linear(a, w)).abs().max().item() <= TOL[mode]
+
+
+def test_linear_is_exact_on_small_integers(gu):
+    """A = I-like / small-integer operands are exactly representable in bf16: the MFMA fragment
+    layout (row/col maps, asymmetric B) must then reproduce the product bit-for-bit."""
+    M, N, K = 192, 160, 128
+    g = torch.Generator().manual_seed(9)
+    a = torch.randint(-4, 5, (M, K), generator=g).float()
+    w = torch.randint(-4, 5, (N, K), generator=g).float()
+    for mode in ("fast", "parity"):
+        out = gu.linear(a, w, None, mode=mode)
+        assert torch.equal(out, a @ w.t()), mode
+    eye = torch.eye(128)
+    wasym = torch.arange(128 * 128, dtype=torch.float32).reshape(128, 128) % 251
+    assert torch.equal(gu.linear(eye, wasym, None, mode="fast"), wasym.t())
+
+
+def ref_attention(qkv, H):
+    B, N, _ = qkv.shape
+    q, k, v = qkv.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    a = ((q * 0.125) @ k.transpose(-2, -1)).softmax(-1)
+    return (a @ v).transpose(1, 2).reshape(B, N, H * 64)
+
+
+@pytest.mark.parametrize("mode", ["parity", "fast"])
+@pytest.mark.parametrize("B,N,H", [(1, 64, 1), (2, 40, 2), (1, 128, 2), (2, 200, 3), (1, 792, 2), (1, 785, 1), (1, 1568, 1), (1, 3168, 1)])
+def test_attention_matches_dense_softmax(gu, mode, B, N, H):
+    qkv = rnd(B, N, 3 * H * 64, seed=N)
+    ref = ref_attention(qkv, H)
+    out = gu.attention(qkv, H, mode=mode)
+    assert torch.isfinite(out).all()
+    err = (out - ref).abs().max().item()
+    assert err <= (3e-4 if mode == "parity" else 3e-2), (err, mode, B, N, H)
+
+
+def test_attention_online_softmax_rescale_branch(gu):
+    """Force the running max to jump late (guide §5.4 rule 26): one key far above the rest in the
+    LAST tile, and one in the first tile, for a subset of queries."""
+    B, N, H = 1, 300, 1
+    qkv = rnd(B, N, 192, seed=5)
+    q = qkv[0, :, :64]
+    k = qkv[0, :, 64:128]
+    k[290] = q[7] * 6.0   # spike for query 7 in the last tile
+    k[3] = q[100] * 6.0   # spike for query 100 in the first tile
+    ref = ref_attention(qkv, H)
+    for mode in ("parity", "fast"):
+        out = gu.attention(qkv, H, mode=mode)
+        err = (out - ref).abs().max().item()
+        assert err <= (5e-4 if mode == "parity" else 5e-2), (mode, err)
+
+
+def test_attention_golden_block(gu):
+    """Reference `Attention`/`Block` tile at real width (tests/golden/block_768.npz)."""
+    from collections import OrderedDict
+
+    from counterfactualworldmodels_amd import config as C, synthetic as S
+
+    g = np.load(os.path.join(GOLDEN, "block_768.npz"))
+    shapes = OrderedDict()
+    C._block_schema("", 768, 3072, shapes)
+    W = {k: torch.from_numpy(S.synthetic_tensor("golden_block." + k, shp, int(g["seed"]))) for k, shp in shapes.items()}
+    x = torch.from_numpy(g["x"])
+    B, N, D = x.shape
+    h1 = gu.layernorm(x.reshape(-1, D), W["norm1.weight"], W["norm1.bias"]).reshape(B, N, D)
+    assert (h1 - torch.from_numpy(g["norm1"])).abs().max().item() <= 2e-6
+    bias = torch.cat([W["attn.q_bias"], torch.zeros(D), W["attn.v_bias"]])
+    qkv = gu.linear(h1.reshape(-1, D), W["attn.qkv.weight"], bias).reshape(B, N, 3 * D)
+    o = gu.attention(qkv, 12)
+    a = gu.linear(o.reshape(-1, D), W["attn.proj.weight"], W["attn.proj.bias"]).reshape(B, N, D)
+    assert (a - torch.from_numpy(g["attn"])).abs().max().item() <= 2e-4
+
+
+@pytest.mark.parametrize("D", [128, 192, 384, 512, 768, 1024])
+def test_layernorm(gu, D):
+    x = rnd(37, D, seed=D) * 3 + 1
+    g_, b_ = 1 + 0.1 * rnd(D, seed=1), 0.1 * rnd(D, seed=2)
+    ref = F.layer_norm(x, (D,), g_, b_, 1e-6)
+    out = gu.layernorm(x, g_, b_)
+    assert (out - ref).abs().max().item() <= 5e-6
+
+
+def test_mask_to_perm_bit_exact_and_errors(gu):
+    g = torch.Generator().manual_seed(0)
+    for (B, Nt, nv) in [(3, 32, 20), (2, 1568, 792), (4, 6272, 3168), (1, 300, 1), (2, 257, 256)]:
+        mask = torch.ones(B, Nt, dtype=torch.bool)
+        for b in range(B):
+            mask[b, torch.randperm(Nt, generator=g)[:nv]] = False
+        perm = gu.mask_to_perm(mask, nv)
+        for b in range(B):
+            vis = torch.where(~mask[b])[0]
+            msk = torch.where(mask[b])[0]
+            assert torch.equal(perm[b].long(), torch.cat([vis, msk]))
+    ragged = torch.ones(2, 64, dtype=torch.bool)
+    ragged[0, :10] = False
+    ragged[1, :11] = False
+    with pytest.raises(_lib.CwmHipError) as e:
+        gu.mask_to_perm(ragged, 10)
+    assert e.value.code == _lib.ERR_MASK
+
+
+def test_unembed_bit_exact_golden(gu):
+    g = np.load(os.path.join(GOLDEN, "index_ops.npz"))
+    lib = _lib.get_lib()
+    d = gu.dev()
+    y, x, m = (torch.from_numpy(g[k]).to(d) for k in ("unembed_y", "unembed_x", "unembed_mask"))
+    out = torch.empty_like(x)
+    B, T, Cc, H, W = x.shape
+    n_vis = m.shape[1] - int(m[0].sum())
+    _lib.check(lib.cwm_unembed(y.data_ptr(), x.data_ptr(), m.data_ptr(), B, T, Cc, H, W, 8, n_vis, out.data_ptr(), gu.stream()))
+    assert np.array_equal(out.cpu().numpy(), g["unembed_video"])

@@ -1,0 +1,155 @@
+"""End-to-end parity of the HIP predictor (through the host mirror + C ABI) against the golden
+reference outputs and the CPU oracle, plus size-independent properties at bench batch sizes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from counterfactualworldmodels_amd import _lib, config as C, prediction, synthetic as S, vmae
+from oracle import vmae_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TINY = C.VmaeConfig(name="tiny_8x8", img_size=(32, 32), patch=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128,
+                    dec_depth=1, dec_heads=2)
+TINY_SPEC = O.VmaeSpec(img_size=(32, 32), patch=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=1, dec_heads=2)
+PARITY_TOL = 1e-3  # BASELINE.json north_star: outputs within 1e-3 max-abs of the CPU reference
+
+
+def build(cfg, seed, mode="parity"):
+    m = vmae.PretrainVisionTransformer(cfg, mode=mode)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, seed).items()})
+    return m.to("cuda:0").eval()
+
+
+def case_inputs(g, cfg):
+    seed, batch, k_vis, clump = int(g["seed"]), int(g["batch"]), int(g["k_vis"]), int(g["clump"])
+    x = torch.from_numpy(S.synthetic_frames(batch, cfg, seed))
+    mask = torch.from_numpy(S.synthetic_masks(batch, cfg, k_vis, seed, clump))
+    return seed, x, mask
+
+
+@pytest.mark.parametrize("name", ["tiny_8x8_k4.npz", "tiny_8x8_k1.npz"])
+def test_tiny_golden(name):
+    g = np.load(os.path.join(GOLDEN, name))
+    seed, x, mask = case_inputs(g, TINY)
+    m = build(TINY, seed)
+    G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+    xd, md = x.cuda(), mask.cuda()
+    y = m(G._preprocess(xd), md).cpu()           # the reference seam (vmae.py:539)
+    assert y.shape == g["y_tokens"].shape
+    assert np.abs(y.numpy() - g["y_tokens"]).max() <= 2e-4
+    video = G.predict(xd, md.clone(), frame=None).cpu()   # fused path
+    rows = video[:, 1, :, :: max(1, TINY.img_size[0] // 8)].numpy()
+    assert np.abs(rows - g["video_frame1_rows"]).max() <= 2e-4
+    v = video.double()
+    dig = np.array([v.sum().item(), v.abs().sum().item(), (v ** 2).sum().item()])
+    assert np.allclose(dig, g["video_digest"], rtol=1e-5)
+    # visible patches are bit-exact copies of the raw input
+    with torch.no_grad():
+        ref_video = O.predict({k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(TINY, seed).items()}, TINY_SPEC, x, mask,
+                              frame=None)
+    vis_pix = O.patches_to_video((~mask)[..., None].expand(-1, -1, 192).float(), 2, 3, 32, 32, 8).bool()
+    assert torch.equal(video[vis_pix], x[vis_pix])
+    assert (video - ref_video).abs().max().item() <= 2e-4
+    # frame=-1 returns the last frame only (prediction.py:447-449)
+    last = G.predict(xd, md.clone()).cpu()
+    assert last.shape == (x.shape[0], 1, 3, 32, 32) and torch.equal(last[:, 0], video[:, 1])
+
+
+@pytest.mark.parametrize("name", ["base8_k8_b2.npz", "base8_k1_b1.npz"])
+def test_base8_golden_parity_and_fast(name):
+    g = np.load(os.path.join(GOLDEN, name))
+    cfg = C.CONFIGS["base_8x8patch_2frames_1tube"]
+    seed, x, mask = case_inputs(g, cfg)
+    m = build(cfg, seed, "parity")
+    G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+    y = G.predict_tokens(x.cuda(), mask.cuda()).cpu().numpy()
+    err = np.abs(y - g["y_tokens"]).max()
+    print(f"[{name}] parity-mode max-abs vs reference: {err:.3e}")
+    assert err <= PARITY_TOL, err
+    video = G.predict(x.cuda(), mask.cuda(), frame=None).cpu()
+    rows = video[:, 1, :, :: cfg.img_size[0] // 8].numpy()
+    assert np.abs(rows - g["video_frame1_rows"]).max() <= PARITY_TOL
+    m.mode = "fast"
+    yf = G.predict_tokens(x.cuda(), mask.cuda()).cpu().numpy()
+    errf = np.abs(yf - g["y_tokens"]).max()
+    print(f"[{name}] fast-mode (plain bf16) max-abs vs reference: {errf:.3e}")
+    assert errf <= 1.5e-1 and np.abs(yf - g["y_tokens"]).mean() <= 1.5e-2
+
+
+def test_large4_golden_parity():
+    g = np.load(os.path.join(GOLDEN, "large4_k32_b1.npz"))
+    cfg = C.CONFIGS["large_4x4patch_2frames_1tube"]
+    seed = int(g["seed"])
+    x = torch.from_numpy(S.synthetic_frames(1, cfg, seed))
+    mask = torch.from_numpy(S.synthetic_masks(1, cfg, 32, seed, 2))
+    m = build(cfg, seed, "parity")
+    G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+    y = G.predict_tokens(x.cuda(), mask.cuda()).cpu().numpy()
+    err = np.abs(y - g["y_tokens"]).max()
+    print(f"[large4] parity-mode max-abs vs reference: {err:.3e}")
+    assert err <= PARITY_TOL, err
+    m.mode = "fast"
+    yf = G.predict_tokens(x.cuda(), mask.cuda()).cpu().numpy()
+    print(f"[large4] fast-mode max-abs vs reference: {np.abs(yf - g['y_tokens']).max():.3e}")
+    assert np.abs(yf - g["y_tokens"]).max() <= 2.5e-1
+
+
+def test_bench_batch_properties():
+    """At BASELINE.json's full size (B/8, batch 32) the oracle takes minutes, so check
+    size-independent properties: per-sample independence (a row's output does not depend on its
+    batch-mates or its position), determinism, and agreement of rows 0-1 with the golden B=2 case."""
+    g = np.load(os.path.join(GOLDEN, "base8_k8_b2.npz"))
+    cfg = C.CONFIGS["base_8x8patch_2frames_1tube"]
+    m = build(cfg, 0, "parity")
+    B = 32
+    x = torch.from_numpy(S.synthetic_frames(B, cfg, 0)).cuda()
+    mask = torch.from_numpy(S.synthetic_masks(B, cfg, 8, 0)).cuda()
+    xp = O.preprocess(x.cpu()).cuda()
+    y = m(xp, mask, n_vis=792)
+    assert torch.isfinite(y).all()
+    # the first two rows of the B=32 synthetic batch are exactly the golden B=2 inputs
+    assert np.array_equal(mask[:2].cpu().numpy(), g["mask"])
+    assert np.abs(y[:2].cpu().numpy() - g["y_tokens"]).max() <= PARITY_TOL
+    y2 = m(xp, mask, n_vis=792)
+    assert torch.equal(y, y2)  # deterministic
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
+    yp = m(xp[perm], mask[perm], n_vis=792)
+    assert (yp - y[perm]).abs().max().item() <= 1e-5  # batch-permutation equivariance
+    ys = m(xp[5:6], mask[5:6], n_vis=792)
+    assert (ys - y[5:6]).abs().max().item() <= 1e-5   # batch-size invariance
+
+
+def test_error_behaviour():
+    m = build(TINY, 3)
+    x = torch.zeros(2, 3, 2, 32, 32, device="cuda")
+    ragged = torch.zeros(2, 32, dtype=torch.bool, device="cuda")
+    ragged[0, 16:] = True
+    ragged[1, 17:] = True
+    with pytest.raises(RuntimeError):  # the reference's reshape fails on unequal visible counts (vmae.py:167)
+        m(x, ragged)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 3, 2, 40, 40, device="cuda"), ragged)
+    with pytest.raises(RuntimeError):
+        m(x.cpu(), ragged.cpu())
+    sd = m.state_dict()
+    sd["bogus.weight"] = torch.zeros(3)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(sd)
+
+
+def test_weight_reload_is_picked_up():
+    m = build(TINY, 3)
+    x = torch.from_numpy(S.synthetic_frames(2, TINY, 3)).cuda()
+    mask = torch.from_numpy(S.synthetic_masks(2, TINY, 4, 3)).cuda()
+    xp = O.preprocess(x.cpu()).cuda()
+    y1 = m(xp, mask)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(TINY, 4).items()})
+    y2 = m(xp, mask)
+    W = {k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(TINY, 4).items()}
+    with torch.no_grad():
+        ref = O.vmae_forward(W, TINY_SPEC, xp.cpu(), mask.cpu())
+    assert (y2.cpu() - ref).abs().max().item() <= 2e-4
+    assert (y1 - y2).abs().max().item() > 1e-2
