@@ -57,7 +57,9 @@ def cpu_baseline(cfg, k_vis, clump, seed, budget_s=20.0):
     """The oracle (CPU restatement of the reference, torch fp32 eager) on this box's host cores."""
     from oracle import vmae_oracle as O
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    # thread count: best of a scan on the MI355X host (2x EPYC 9575F, 256 hw threads): 16 threads
+    # 0.78 s/forward vs 0.90 (8), 0.93 (32), 1.6 (64), 3.2 (128), 45 (256, oversubscribed)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     W = {k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, seed).items()}
     B = 2
     x = torch.from_numpy(S.synthetic_frames(B, cfg, seed))

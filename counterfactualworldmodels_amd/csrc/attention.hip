@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
         st_koff[i] = lds_off128(st_row[i], st_chunk[i]);
         st_voff[i] = lds_off128(st_row[i], st_chunk[i]);
     }
-    uint4 rk[PLANES][2], rv[PLANES][2];
+    u32x4 rk[PLANES][2], rv[PLANES][2];
     auto load_tiles = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -68,14 +68,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
             const int key0 = kt * 64 + st_chunk[i] * 8;
 #pragma unroll
             for (int pl = 0; pl < PLANES; ++pl) {
-                rk[pl][i] = *reinterpret_cast<const uint4*>(Kb + (size_t)pl * p.qk_plane + (size_t)krow * 64 + st_chunk[i] * 8);
-                uint4 v = *reinterpret_cast<const uint4*>(Vb + (size_t)pl * p.vt_plane + (size_t)st_row[i] * p.n_pad + key0);
+                rk[pl][i] = *reinterpret_cast<const u32x4*>(Kb + (size_t)pl * p.qk_plane + (size_t)krow * 64 + st_chunk[i] * 8);
+                u32x4 v = *reinterpret_cast<const u32x4*>(Vb + (size_t)pl * p.vt_plane + (size_t)st_row[i] * p.n_pad + key0);
                 if (key0 + 8 > N) {  // zero the keys past the sequence end (P is 0 there, 0 * garbage must stay 0)
-                    unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        if (key0 + e >= N) w[e >> 1] &= (e & 1) ? 0x0000FFFFu : 0xFFFF0000u;
-                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                        if (key0 + e >= N) v[e >> 1] &= (e & 1) ? 0x0000FFFFu : 0xFFFF0000u;
                 }
                 rv[pl][i] = v;
             }
@@ -87,10 +85,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < PLANES; ++pl) {
-                *reinterpret_cast<uint4*>(base + pl * TILE_BYTES + st_koff[i]) = rk[pl][i];
-                uint4 v = rv[pl][i];
-                if (st_row[i] & 16) v = make_uint4(v.z, v.w, v.x, v.y);  // swap the 8-byte halves (bank spread)
-                *reinterpret_cast<uint4*>(base + (PLANES + pl) * TILE_BYTES + st_voff[i]) = v;
+                *reinterpret_cast<u32x4*>(base + pl * TILE_BYTES + st_koff[i]) = rk[pl][i];
+                u32x4 v = rv[pl][i];
+                if (st_row[i] & 16) v = __builtin_shufflevector(v, v, 2, 3, 0, 1);  // swap the 8-byte halves (bank spread)
+                *reinterpret_cast<u32x4*>(base + (PLANES + pl) * TILE_BYTES + st_voff[i]) = v;
             }
     };
 

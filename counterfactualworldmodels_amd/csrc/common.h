@@ -11,6 +11,9 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+// NB: use this native vector (not HIP's struct uint4) for register-staged tiles: arrays of the HIP
+// struct types are not promoted to registers by hipcc and end up in scratch.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int kWave = 64;
 

@@ -76,26 +76,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         st_off[i] = lds_off<BK>(row, chunk);
     }
 
-    uint4 ra_[PLANES][NLD], rb_[PLANES][NLD];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int pl = 0; pl < PLANES; ++pl)
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                ra_[pl][i] = *reinterpret_cast<const uint4*>(a_src[i] + (size_t)pl * p.a_plane + k0);
-                rb_[pl][i] = *reinterpret_cast<const uint4*>(w_src[i] + (size_t)pl * p.w_plane + k0);
-            }
-    };
-    auto store_tile = [&](int stage) {
-        char* base = smem + stage * STAGE_BYTES;
-#pragma unroll
-        for (int pl = 0; pl < PLANES; ++pl)
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                *reinterpret_cast<uint4*>(base + pl * TILE_BYTES + st_off[i]) = ra_[pl][i];
-                *reinterpret_cast<uint4*>(base + (PLANES + pl) * TILE_BYTES + st_off[i]) = rb_[pl][i];
-            }
-    };
+    // staging registers (kept as plain unrolled code: native vector type: arrays of HIP's struct uint4 are
+    // left in scratch by hipcc, which serialises the prefetch behind the MFMAs)
+    u32x4 ra_[PLANES * NLD], rb_[PLANES * NLD];
+#define CWM_LOAD_TILE(k0)                                                                                          \
+    _Pragma("unroll") for (int pl = 0; pl < PLANES; ++pl) _Pragma("unroll") for (int i = 0; i < NLD; ++i) {        \
+        ra_[pl * NLD + i] = *reinterpret_cast<const u32x4*>(a_src[i] + (size_t)pl * p.a_plane + (k0));            \
+        rb_[pl * NLD + i] = *reinterpret_cast<const u32x4*>(w_src[i] + (size_t)pl * p.w_plane + (k0));            \
+    }
+#define CWM_STORE_TILE(stage)                                                                                      \
+    _Pragma("unroll") for (int pl = 0; pl < PLANES; ++pl) _Pragma("unroll") for (int i = 0; i < NLD; ++i) {        \
+        *reinterpret_cast<u32x4*>(smem + (stage) * STAGE_BYTES + pl * TILE_BYTES + st_off[i]) = ra_[pl * NLD + i]; \
+        *reinterpret_cast<u32x4*>(smem + (stage) * STAGE_BYTES + (PLANES + pl) * TILE_BYTES + st_off[i]) =         \
+            rb_[pl * NLD + i];                                                                                     \
+    }
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -115,13 +109,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         }
 
     const int nk = p.K / BK;
-    load_tile(0);
-    store_tile(0);
+    CWM_LOAD_TILE(0)
+    CWM_STORE_TILE(0)
     __syncthreads();
 
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nk) load_tile((t + 1) * BK);
+        if (t + 1 < nk) {
+            CWM_LOAD_TILE((t + 1) * BK)
+        }
         const char* base = smem + cur * STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
@@ -144,7 +140,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (t + 1 < nk) store_tile(cur ^ 1);
+        if (t + 1 < nk) {
+            CWM_STORE_TILE(cur ^ 1)
+        }
         __syncthreads();
     }
 
