@@ -95,6 +95,9 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     ),
+    "cwm_bench_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "cwm_bench_attention": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "cwm_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
     "cwm_last_error": (C.c_char_p, []),
     "cwm_version": (C.c_char_p, []),
 }

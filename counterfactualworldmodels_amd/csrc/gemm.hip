@@ -4,54 +4,186 @@
 // fc1/fc2, :93 qkv, :119 proj; vmae.py:547 encoder_to_decoder, :251 head; the Conv3d patch embed of
 // VideoMAE/utils.py:174-197 expressed as an im2col GEMM).
 //
-// * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 4x4 MFMA 16x16x32 tiles)
+// * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 4x4 MFMA 16x16x32 tiles),
+//   two workgroups per CU
 // * A and W are both K-contiguous, so one lane's MFMA fragment is one 16-byte LDS read
-// * LDS tiles are XOR-swizzled so the ds_read_b128 fragment reads are bank-conflict free
-// * double-buffered LDS, global loads of tile t+1 issued before the MFMAs of tile t (register staging)
+// * K tiles are staged by LDS-DMA (`global_load_lds_dwordx4`, 1 KiB per wave-instruction, no staging
+//   VGPRs, no ds_write pass) into a 2-stage LDS ring; tile t+1 is in flight while tile t is multiplied.
+//   An LDS-DMA piece lands linearly (lane l -> base + 16 l), so the bank-conflict XOR swizzle is applied
+//   to the per-lane SOURCE address and again on the fragment reads (measured SQ_LDS_BANK_CONFLICT = 0)
 // * PLANES==2 ("parity" mode): operands are (hi, lo) bf16 planes and each product is
 //   hi*hi + hi*lo + lo*hi, fp32-accumulated -> ~2^-16 relative operand error instead of 2^-9
 // * XCD-aware, grouped tile order so that co-resident tiles of one XCD share A panels / W tiles in L2
+// * accumulators are kept TRANSPOSED (D^T = W_frag . A_frag^T): a lane then owns 4 consecutive output
+//   columns of one row, so every epilogue access is a 16-byte (fp32) / 8-byte (bf16) vector; the V third
+//   of the QKV projection uses the plain orientation instead (4 consecutive tokens per lane) because it
+//   is stored transposed ([head][d][token]) for the attention kernel
 // * fused epilogues: bias, residual(+row map), exact-erf GELU, bf16 hi/lo split, QKV head scatter
 #include "common.h"
 #include "kernels.h"
 
 namespace cwm {
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
 template <int BK>
-__device__ __forceinline__ int lds_off(int row, int chunk) {
+__device__ __forceinline__ int lds_swizzle(int row) {
     if constexpr (BK == 64) {
-        return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+        return (row >> 1) & 7;
     } else {
         // 64-byte rows: 4 rows share one 256-byte bank row; permute so each ds_read_b128 lane group
         // (rows {0-3,12-15} at chunk c, rows {4-11} at chunk c^1) covers 16 distinct 16-byte slots.
-        const int x = (row >> 2) & 3;
-        const int t = (0x78 >> (2 * x)) & 3;  // {0,2,3,1}
-        return row * 64 + ((chunk ^ t) << 4);
+        return (0x78 >> (2 * ((row >> 2) & 3))) & 3;  // {0,2,3,1}
     }
 }
 
+template <int BK>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * (BK * 2) + ((chunk ^ lds_swizzle<BK>(row)) << 4);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+struct RowMap {
+    int out_row, res_row, b, tok;
+};
+
+__device__ __forceinline__ RowMap map_row(const GemmParams& p, int m) {
+    RowMap r;
+    if (p.rows_in > 0) {
+        r.b = m / p.rows_in;
+        r.tok = m - r.b * p.rows_in;
+        r.out_row = r.b * p.rows_out + r.tok;
+        r.res_row = p.resid_rowmap ? p.resid_rowmap[r.b * p.map_stride + r.tok] : r.out_row;
+    } else {
+        r.b = 0;
+        r.tok = m;
+        r.out_row = m;
+        r.res_row = m;
+    }
+    return r;
+}
+
+// Transposed accumulators: acc[i][j][r] = C[m0 + wr*64 + i*16 + (lane&15)][n0 + wc*64 + j*16 + (lane>>4)*4 + r]
+template <int PLANES>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int wr, int wc, int lane) {
+    const int ncol = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const RowMap rm = map_row(p, m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wc * 64 + j * 16;  // fragment's first column (wave-uniform)
+            if (nb >= p.N) continue;
+            const int n = nb + ncol;
+            f32x4 v = acc[i][j];
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.epi == EPI_F32) {
+                if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)rm.res_row * p.ldr + n);
+                *reinterpret_cast<f32x4*>(p.C + (size_t)rm.out_row * p.ldc + n) = v;
+            } else {
+                bf16* dst;
+                int64_t plane;
+                if (p.epi == EPI_QKV) {
+                    const int D = p.qkv_dim;
+                    const int which = nb / D;  // 0 q, 1 k (v tiles take epilogue_cols)
+                    const int c = n - which * D;
+                    const int h = c / p.head_dim, d = c - h * p.head_dim;
+                    if (which == 0) v *= p.q_scale;
+                    dst = (which == 0 ? p.q_out : p.k_out) + ((size_t)(rm.b * p.heads + h) * p.n_tok + rm.tok) * p.head_dim + d;
+                    plane = p.qk_plane;
+                } else {
+                    if (p.epi == EPI_BF16_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    }
+                    dst = p.out_hi + (size_t)rm.out_row * p.ldo + n;
+                    plane = p.out_plane;
+                }
+                bf16x4 hv, lv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bf16 hi = (bf16)v[r];
+                    hv[r] = hi;
+                    lv[r] = (bf16)(v[r] - (float)hi);
+                }
+                *reinterpret_cast<bf16x4*>(dst) = hv;
+                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + plane) = lv;
+            }
+        }
+    }
+}
+
+// Plain accumulators (V tiles of the QKV projection):
+// acc[i][j][r] = C[m0 + wr*64 + i*16 + (lane>>4)*4 + r][n0 + wc*64 + j*16 + (lane&15)]  -> V^T[(b,h)][d][token]
+template <int PLANES>
+__device__ __forceinline__ void epilogue_cols_vt(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int wr, int wc, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int mbase = m0 + wr * 64 + i * 16 + (lane >> 4) * 4;
+        if (mbase >= p.M) continue;
+        const int b0 = mbase / p.n_tok, tok0 = mbase - b0 * p.n_tok;
+        const bool vec = (mbase + 3 < p.M) && (tok0 + 3 < p.n_tok) && ((tok0 & 3) == 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wc * 64 + j * 16;
+            if (nb >= p.N) continue;
+            const int n = nb + (lane & 15);
+            const float bias = p.bias ? p.bias[n] : 0.f;
+            const int c = n - 2 * p.qkv_dim;
+            const int h = c / p.head_dim, d = c - h * p.head_dim;
+            bf16x4 hv, lv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[i][j][r] + bias;
+                const bf16 hi = (bf16)v;
+                hv[r] = hi;
+                lv[r] = (bf16)(v - (float)hi);
+            }
+            if (vec) {
+                bf16* dst = p.vt_out + ((size_t)(b0 * p.heads + h) * p.head_dim + d) * p.n_pad + tok0;
+                *reinterpret_cast<bf16x4*>(dst) = hv;
+                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + p.vt_plane) = lv;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mbase + r;
+                    if (m < p.M) {
+                        const int b = m / p.n_tok, tok = m - b * p.n_tok;
+                        bf16* dst = p.vt_out + ((size_t)(b * p.heads + h) * p.head_dim + d) * p.n_pad + tok;
+                        *dst = hv[r];
+                        if constexpr (PLANES == 2) dst[p.vt_plane] = lv[r];
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <int PLANES>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     constexpr int BM = 128, BN = 128;
     constexpr int BK = (PLANES == 1) ? 64 : 32;
-    constexpr int CPR = BK / 8;               // 16-byte chunks per tile row
-    constexpr int NLD = (BM * CPR) / 256;     // staging loads per thread per operand plane
+    constexpr int CPR = BK / 8;        // 16-byte chunks per tile row
+    constexpr int RPI = 64 / CPR;      // tile rows covered by one 1-KiB DMA piece
+    constexpr int NI = BM / RPI / 4;   // DMA pieces per wave per operand plane
     constexpr int TILE_BYTES = BM * BK * 2;
     constexpr int STAGE_BYTES = TILE_BYTES * 2 * PLANES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
     // ---- tile selection: XCD chunking + GROUP_M-grouped order --------------------------------
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;
-    int id = xcd_remap(blockIdx.x, ntiles);
+    const int id = xcd_remap(blockIdx.x, ntiles);
     constexpr int GROUP_M = 8;
     const int group_sz = GROUP_M * tiles_n;
     const int g = id / group_sz;
@@ -62,34 +194,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     const int tile_n = in_g / gm;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- staging addresses --------------------------------------------------------------------
-    const bf16* a_src[NLD];
-    const bf16* w_src[NLD];
-    int st_off[NLD];
+    // ---- per-lane source pointers of this wave's DMA pieces (piece j covers tile rows RPI*j ...) ----
+    const bf16* a_src[NI];
+    const bf16* w_src[NI];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int idx = tid + i * 256;
-        const int row = idx / CPR, chunk = idx % CPR;
-        const int ra = min(m0 + row, p.M - 1);
-        a_src[i] = p.A + (size_t)ra * p.lda + chunk * 8;
-        w_src[i] = p.W + (size_t)(n0 + row) * p.K + chunk * 8;
-        st_off[i] = lds_off<BK>(row, chunk);
+    for (int jj = 0; jj < NI; ++jj) {
+        const int row = (wave * NI + jj) * RPI + lane / CPR;
+        const int logical = (lane % CPR) ^ lds_swizzle<BK>(row);
+        a_src[jj] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + logical * 8;
+        w_src[jj] = p.W + (size_t)(n0 + row) * p.K + logical * 8;
     }
+    auto issue_tile = [&](int stage, int k0) {
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+            for (int jj = 0; jj < NI; ++jj) {
+                const int j = wave * NI + jj;
+                char* da = smem + stage * STAGE_BYTES + pl * TILE_BYTES + j * 1024;
+                char* dw = smem + stage * STAGE_BYTES + (PLANES + pl) * TILE_BYTES + j * 1024;
+                __builtin_amdgcn_global_load_lds((gbl_void*)(a_src[jj] + (size_t)pl * p.a_plane + k0), (lds_void*)da, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void*)(w_src[jj] + (size_t)pl * p.w_plane + k0), (lds_void*)dw, 16, 0, 0);
+            }
+    };
 
-    // staging registers (kept as plain unrolled code: native vector type: arrays of HIP's struct uint4 are
-    // left in scratch by hipcc, which serialises the prefetch behind the MFMAs)
-    u32x4 ra_[PLANES * NLD], rb_[PLANES * NLD];
-#define CWM_LOAD_TILE(k0)                                                                                          \
-    _Pragma("unroll") for (int pl = 0; pl < PLANES; ++pl) _Pragma("unroll") for (int i = 0; i < NLD; ++i) {        \
-        ra_[pl * NLD + i] = *reinterpret_cast<const u32x4*>(a_src[i] + (size_t)pl * p.a_plane + (k0));            \
-        rb_[pl * NLD + i] = *reinterpret_cast<const u32x4*>(w_src[i] + (size_t)pl * p.w_plane + (k0));            \
-    }
-#define CWM_STORE_TILE(stage)                                                                                      \
-    _Pragma("unroll") for (int pl = 0; pl < PLANES; ++pl) _Pragma("unroll") for (int i = 0; i < NLD; ++i) {        \
-        *reinterpret_cast<u32x4*>(smem + (stage) * STAGE_BYTES + pl * TILE_BYTES + st_off[i]) = ra_[pl * NLD + i]; \
-        *reinterpret_cast<u32x4*>(smem + (stage) * STAGE_BYTES + (PLANES + pl) * TILE_BYTES + st_off[i]) =         \
-            rb_[pl * NLD + i];                                                                                     \
-    }
+    // the V third of a QKV projection is accumulated in the plain orientation (block-uniform choice)
+    const bool plain = (p.epi == EPI_QKV) && (n0 >= 2 * p.qkv_dim);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -109,16 +238,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         }
 
     const int nk = p.K / BK;
-    CWM_LOAD_TILE(0)
-    CWM_STORE_TILE(0)
-    __syncthreads();
-
+    issue_tile(0, 0);
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nk) {
-            CWM_LOAD_TILE((t + 1) * BK)
-        }
+        __syncthreads();  // hipcc drains vmcnt before the barrier: tile t has landed; stage cur^1 is free
+        if (t + 1 < nk && !(p.ablate & 1)) issue_tile(cur ^ 1, (t + 1) * BK);
         const char* base = smem + cur * STAGE_BYTES;
+        if (p.ablate & 4) continue;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 af[PLANES][4], bfr[PLANES][4];
@@ -129,145 +255,74 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
                     af[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * TILE_BYTES + a_off[i][kk]);
                     bfr[pl][i] = *reinterpret_cast<const bf16x8*>(base + (PLANES + pl) * TILE_BYTES + b_off[i][kk]);
                 }
+            if (p.ablate & 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (PLANES == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[1][j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[pl][i]), "v"(bfr[pl][i]));
+                continue;
+            }
+            if (!plain) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (PLANES == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], af[1][i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], af[0][i], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], af[0][i], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (t + 1 < nk) {
-            CWM_STORE_TILE(cur ^ 1)
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue -------------------------------------------------------------------------------
-    // C/D layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
-    const int col_l = lane & 15;
-    const int row_l = (lane >> 4) * 4;
-
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int mbase = m0 + wr * 64 + i * 16 + row_l;
-        if (mbase >= p.M) continue;
-        // per-row bookkeeping shared by the 4 column fragments
-        int out_row[4], res_row[4], bidx[4], tok[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = mbase + r;
-            if (p.rows_in > 0) {
-                const int b = m / p.rows_in, ii = m - b * p.rows_in;
-                out_row[r] = b * p.rows_out + ii;
-                res_row[r] = p.resid_rowmap ? p.resid_rowmap[b * p.map_stride + ii] : out_row[r];
-                bidx[r] = b;
-                tok[r] = ii;
             } else {
-                out_row[r] = m;
-                res_row[r] = m;
-                bidx[r] = 0;
-                tok[r] = m;
-            }
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nb = n0 + wc * 64 + j * 16;  // fragment's first column (wave-uniform)
-            if (nb >= p.N) continue;
-            const int n = nb + col_l;
-            const float bias = p.bias ? p.bias[n] : 0.f;
-            if (p.epi == EPI_F32) {
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (mbase + r < p.M) {
-                        float v = acc[i][j][r] + bias;
-                        if (p.resid) v += p.resid[(size_t)res_row[r] * p.ldr + n];
-                        p.C[(size_t)out_row[r] * p.ldc + n] = v;
-                    }
-                }
-            } else if (p.epi == EPI_BF16_GELU || p.epi == EPI_BF16) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (mbase + r < p.M) {
-                        float v = acc[i][j][r] + bias;
-                        if (p.epi == EPI_BF16_GELU) v = gelu_erf(v);
-                        bf16 hi, lo;
-                        split_bf16(v, hi, lo);
-                        const size_t o = (size_t)out_row[r] * p.ldo + n;
-                        p.out_hi[o] = hi;
-                        if constexpr (PLANES == 2) p.out_hi[o + p.out_plane] = lo;
-                    }
-                }
-            } else {  // EPI_QKV: scatter to per-head Q, K ([B*H, Ntok, hd]) and V^T ([B*H, hd, Npad])
-                const int D = p.qkv_dim;
-                const int which = nb / D;           // 0 q, 1 k, 2 v (uniform per 16-col fragment)
-                const int c = n - which * D;
-                const int h = c / p.head_dim, d = c - h * p.head_dim;
-                float vals[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + bias;
-                    vals[r] = (which == 0) ? v * p.q_scale : v;
-                }
-                if (which < 2) {
-                    bf16* dst = (which == 0) ? p.q_out : p.k_out;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (mbase + r < p.M) {
-                            bf16 hi, lo;
-                            split_bf16(vals[r], hi, lo);
-                            const size_t o = ((size_t)(bidx[r] * p.heads + h) * p.n_tok + tok[r]) * p.head_dim + d;
-                            dst[o] = hi;
-                            if constexpr (PLANES == 2) dst[o + p.qk_plane] = lo;
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (PLANES == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[1][j], acc[i][j], 0, 0, 0);
                         }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
                     }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (mbase + r < p.M) {
-                            bf16 hi, lo;
-                            split_bf16(vals[r], hi, lo);
-                            const size_t o = ((size_t)(bidx[r] * p.heads + h) * p.head_dim + d) * p.n_pad + tok[r];
-                            p.vt_out[o] = hi;
-                            if constexpr (PLANES == 2) p.vt_out[o + p.vt_plane] = lo;
-                        }
-                    }
-                }
             }
         }
     }
+    if (!plain)
+        epilogue_rows<PLANES>(p, acc, m0, n0, wr, wc, lane);
+    else
+        epilogue_cols_vt<PLANES>(p, acc, m0, n0, wr, wc, lane);
 }
+
+int g_gemm_ablate = 0;
 
 int launch_gemm(const GemmParams& p, int planes, hipStream_t stream) {
     CWM_REQUIRE(planes == 1 || planes == 2, "gemm: planes must be 1 or 2");
-    const int BK = planes == 1 ? 64 : 32;
     CWM_REQUIRE(p.K % 64 == 0, "gemm: K=%d must be a multiple of 64", p.K);
     CWM_REQUIRE(p.lda % 8 == 0, "gemm: lda=%d must be a multiple of 8", p.lda);
     CWM_REQUIRE(p.M > 0 && p.N > 0, "gemm: empty problem M=%d N=%d", p.M, p.N);
-    if (p.epi == EPI_QKV) {
-        CWM_REQUIRE(p.rows_in == p.n_tok && p.qkv_dim % 16 == 0 && p.N == 3 * p.qkv_dim, "gemm: bad QKV epilogue setup");
+    CWM_REQUIRE(p.N % 16 == 0, "gemm: N=%d must be a multiple of 16", p.N);
+    if (p.epi == EPI_F32) {
+        CWM_REQUIRE(p.ldc % 4 == 0 && (!p.resid || p.ldr % 4 == 0), "gemm: ldc/ldr must be multiples of 4");
+    } else if (p.epi == EPI_QKV) {
+        CWM_REQUIRE(p.rows_in == p.n_tok && p.N == 3 * p.qkv_dim && p.head_dim % 4 == 0, "gemm: bad QKV epilogue setup");
+        CWM_REQUIRE(p.qkv_dim % 128 == 0, "gemm: QKV epilogue needs the model width (%d) to be a multiple of the 128-column tile", p.qkv_dim);
+        CWM_REQUIRE(p.n_pad % 4 == 0, "gemm: n_pad must be a multiple of 4");
+    } else {
+        CWM_REQUIRE(p.ldo % 4 == 0, "gemm: ldo must be a multiple of 4");
     }
-    (void)BK;
     const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
     const size_t smem = 65536;
-    if (planes == 1) {
-        static bool attr1 = false;
-        if (!attr1) {
-            CWM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr1 = true;
-        }
-        hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(tiles), dim3(256), smem, stream, p);
-    } else {
-        static bool attr2 = false;
-        if (!attr2) {
-            CWM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr2 = true;
-        }
-        hipLaunchKernelGGL(gemm_bf16_kernel<2>, dim3(tiles), dim3(256), smem, stream, p);
+    typedef void (*kern_t)(const GemmParams);
+    static const kern_t kerns[2] = {gemm_bf16_kernel<1>, gemm_bf16_kernel<2>};
+    static bool attr_done[2] = {false, false};
+    kern_t k = kerns[planes - 1];
+    if (!attr_done[planes - 1]) {
+        CWM_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done[planes - 1] = true;
     }
+    GemmParams pp = p;
+    pp.ablate = g_gemm_ablate;
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, pp);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }

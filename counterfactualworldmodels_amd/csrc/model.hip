@@ -775,3 +775,129 @@ extern "C" int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const 
     }
     return CWM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// diagnostics
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void fill_random_bf16_kernel(bf16* dst, int64_t n, unsigned seed, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)i * 2654435761u + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    dst[i] = (bf16)(((float)(x & 0xFFFF) / 32768.0f - 1.0f) * scale);
+}
+__global__ void fill_random_f32_kernel(float* dst, int64_t n, unsigned seed, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)i * 2654435761u + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    dst[i] = ((float)(x & 0xFFFF) / 32768.0f - 1.0f) * scale;
+}
+void fill_bf16(bf16* d, int64_t n, unsigned seed, float scale) {
+    hipLaunchKernelGGL(fill_random_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, n, seed, scale);
+}
+void fill_f32(float* d, int64_t n, unsigned seed, float scale) {
+    hipLaunchKernelGGL(fill_random_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, n, seed, scale);
+}
+}  // namespace
+
+extern "C" int cwm_debug_set(const char* key, int value) {
+    CWM_REQUIRE(key, "cwm_debug_set: null key");
+    if (!strcmp(key, "gemm_ablate")) {
+        g_gemm_ablate = value;
+        return CWM_OK;
+    }
+    cwm_set_error("cwm_debug_set: unknown key %s", key);
+    return CWM_ERR_INVALID;
+}
+
+extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters, double* avg_us) {
+    CWM_REQUIRE(avg_us && M > 0 && N > 0 && K > 0 && iters > 0, "cwm_bench_gemm: bad argument");
+    CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_bench_gemm: bad mode");
+    const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
+    const int Kp = round_up(K, 64), Np = round_up(N, 128);
+    Scratch sc;
+    bf16* A = sc.get<bf16>((size_t)2 * M * Kp);
+    bf16* W = sc.get<bf16>((size_t)2 * Np * Kp);
+    float* bias = sc.get<float>(Np);
+    float* Cm = sc.get<float>((size_t)M * N);
+    bf16* G = sc.get<bf16>((size_t)2 * M * N + 64 * 1024);
+    bf16* G2 = sc.get<bf16>((size_t)2 * M * N + 64 * 1024);
+    bf16* G3 = sc.get<bf16>((size_t)2 * M * N + 64 * 1024 * 64);
+    CWM_REQUIRE(A && W && bias && Cm && G && G2 && G3, "cwm_bench_gemm: out of device memory");
+    fill_bf16(A, (int64_t)2 * M * Kp, 1, 1.0f);
+    fill_bf16(W, (int64_t)2 * Np * Kp, 2, 0.05f);
+    fill_f32(bias, Np, 3, 0.1f);
+    fill_f32(Cm, (int64_t)M * N, 4, 1.0f);
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.a_plane = (int64_t)M * Kp; p.lda = Kp; p.W = W; p.w_plane = (int64_t)Np * Kp;
+    p.M = M; p.N = N; p.K = Kp; p.bias = bias;
+    if (epi == 1) {
+        p.epi = EPI_BF16_GELU; p.out_hi = G; p.out_plane = (int64_t)M * N; p.ldo = N;
+    } else if (epi == 3) {
+        CWM_REQUIRE(N % 192 == 0, "cwm_bench_gemm: QKV epilogue needs N = 3*64*heads");
+        const int D = N / 3, H = D / 64, n_tok = 792 <= M && M % 792 == 0 ? 792 : M, B = M / n_tok;
+        const int n_pad = round_up(n_tok, 64);
+        p.epi = EPI_QKV; p.rows_in = n_tok; p.rows_out = n_tok; p.map_stride = n_tok;
+        p.q_out = G; p.k_out = G2; p.vt_out = G3; p.qk_plane = (int64_t)M * D; p.vt_plane = (int64_t)B * D * n_pad;
+        CWM_REQUIRE(p.vt_plane * 2 <= (int64_t)2 * M * N + 64 * 1024 * 64, "cwm_bench_gemm: V^T scratch too small");
+        p.qkv_dim = D; p.heads = H; p.head_dim = 64; p.n_tok = n_tok; p.n_pad = n_pad; p.q_scale = 0.125f;
+    } else {
+        p.epi = EPI_F32; p.C = Cm; p.ldc = N; p.resid = Cm; p.ldr = N;
+    }
+    hipEvent_t e0, e1;
+    CWM_HIP_CHECK(hipEventCreate(&e0));
+    CWM_HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i)
+        if (int rc = launch_gemm(p, planes, 0)) return rc;
+    CWM_HIP_CHECK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i)
+        if (int rc = launch_gemm(p, planes, 0)) return rc;
+    CWM_HIP_CHECK(hipEventRecord(e1, 0));
+    CWM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CWM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = 1e3 * ms / iters;
+    return CWM_OK;
+}
+
+extern "C" int cwm_bench_attention(int B, int H, int N, int mode, int iters, double* avg_us) {
+    CWM_REQUIRE(avg_us && B > 0 && H > 0 && N > 0 && iters > 0, "cwm_bench_attention: bad argument");
+    CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_bench_attention: bad mode");
+    const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
+    const int D = H * 64, n_pad = round_up(N, 64);
+    const int64_t qk_plane = (int64_t)B * N * D, vt_plane = (int64_t)B * D * n_pad;
+    Scratch sc;
+    bf16* q = sc.get<bf16>(2 * qk_plane);
+    bf16* k = sc.get<bf16>(2 * qk_plane);
+    bf16* vt = sc.get<bf16>(2 * vt_plane);
+    bf16* o = sc.get<bf16>(2 * qk_plane);
+    CWM_REQUIRE(q && k && vt && o, "cwm_bench_attention: out of device memory");
+    fill_bf16(q, 2 * qk_plane, 5, 0.5f);
+    fill_bf16(k, 2 * qk_plane, 6, 1.0f);
+    fill_bf16(vt, 2 * vt_plane, 7, 1.0f);
+    AttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = q; a.k = k; a.vt = vt; a.qk_plane = qk_plane; a.vt_plane = vt_plane; a.o = o; a.o_plane = qk_plane; a.ldo = D;
+    a.n_tok = N; a.n_pad = n_pad; a.heads = H; a.batch = B;
+    hipEvent_t e0, e1;
+    CWM_HIP_CHECK(hipEventCreate(&e0));
+    CWM_HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i)
+        if (int rc = launch_attention(a, planes, 0)) return rc;
+    CWM_HIP_CHECK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i)
+        if (int rc = launch_attention(a, planes, 0)) return rc;
+    CWM_HIP_CHECK(hipEventRecord(e1, 0));
+    CWM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CWM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = 1e3 * ms / iters;
+    return CWM_OK;
+}

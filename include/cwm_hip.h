@@ -121,6 +121,15 @@ int cwm_mask_to_perm(const uint8_t* mask_dev, int B, int Nt, int n_vis, int32_t*
 int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const uint8_t* mask_dev, int B, int T, int C, int H, int W,
                 int P, int n_vis, float* out_dev, void* stream);
 
+/* ---- diagnostics: single-kernel micro-benchmarks on random operands (tools/microbench.py) ---------
+ * epi: 0 = fp32 out + bias + in-place residual (proj/fc2 form), 1 = bias + GELU -> bf16 (fc1 form),
+ *      3 = QKV head scatter (N must be 3*64*heads, M = batch*n_tok with n_tok = M / batch).
+ * Runs `iters` back-to-back launches after 3 warm-up launches and returns the mean launch time. */
+int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters, double* avg_us);
+int cwm_bench_attention(int B, int H, int N, int mode, int iters, double* avg_us);
+/* development switches: "gemm_ablate" (bit 0 skip tile loads, bit 1 skip MFMAs, bit 2 skip LDS reads): timing only */
+int cwm_debug_set(const char* key, int value);
+
 const char* cwm_last_error(void);
 /* "cwm_hip <version> gfx950" */
 const char* cwm_version(void);

@@ -1,0 +1,57 @@
+"""Single-kernel micro-benchmarks through the C ABI (development tool, run on the GPU box).
+
+    python tools/microbench.py gemm      # GEMM shapes of the B/8 batch-32 and L/4 batch-8 forward
+    python tools/microbench.py attn
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from counterfactualworldmodels_amd import _lib  # noqa: E402
+
+GEMM_SHAPES = [
+    # (name, M, N, K, epi)
+    ("b8.enc.qkv", 25344, 2304, 768, 3),
+    ("b8.enc.proj", 25344, 768, 768, 0),
+    ("b8.enc.fc1", 25344, 3072, 768, 1),
+    ("b8.enc.fc2", 25344, 768, 3072, 0),
+    ("b8.dec.qkv", 50176, 1152, 384, 3),
+    ("b8.dec.proj", 50176, 384, 384, 0),
+    ("b8.dec.fc1", 50176, 1536, 384, 1),
+    ("b8.dec.fc2", 50176, 384, 1536, 0),
+]
+ATTN_SHAPES = [("b8.enc", 32, 12, 792), ("b8.dec", 32, 6, 1568), ("l4.enc", 8, 16, 3168), ("l4.dec", 8, 8, 6272)]
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
+    variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
+    torch.cuda.init()
+    lib = _lib.get_lib()
+    us = C.c_double()
+    if what == "gemm":
+        for name, M, N, K, epi in GEMM_SHAPES:
+            for mode in ("fast", "parity"):
+                row = []
+                for v in variants:
+                    best = 1e30
+                    for _ in range(3):
+                        _lib.check(lib.cwm_bench_gemm(M, N, K, _lib.mode_id(mode), epi, 20, C.byref(us)))
+                        best = min(best, us.value)
+                    row.append("v%d %8.1f us %7.1f TF" % (v, best, 2.0 * M * N * K / best / 1e6))
+                print("%-12s %-6s M=%d N=%d K=%d  %s" % (name, mode, M, N, K, " | ".join(row)), flush=True)
+    else:
+        for name, B, H, N in ATTN_SHAPES:
+            for mode in ("fast", "parity"):
+                best = 1e30
+                for _ in range(3):
+                    _lib.check(lib.cwm_bench_attention(B, H, N, _lib.mode_id(mode), 10, C.byref(us)))
+                    best = min(best, us.value)
+                print("%-8s %-6s B=%d H=%d N=%d  %8.1f us %7.1f TF" % (name, mode, B, H, N, best, 4.0 * B * H * N * N * 64 / best / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()
