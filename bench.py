@@ -27,6 +27,11 @@ from counterfactualworldmodels_amd import _lib, config as C, synthetic as S, vma
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
+# BASELINE configs[3]: 256 motion-counterfactual prompts over ONE frame pair, sharded over the ranks
+# (rank 0 broadcasts frame + prompt table, every rank builds + predicts its slice, all-gather).
+PROMPTS = dict(cfg="base_8x8patch_2frames_1tube", total=256, chunk=32,
+               name="ViT-base VMAE 8x8, 256 motion-counterfactual prompts on one frame pair (BASELINE configs[3])")
+
 WORKLOADS = {
     "base8": dict(cfg="base_8x8patch_2frames_1tube", batch=32, k_vis=8, clump=1,
                   name="ViT-base VMAE 8x8, batch=32 synthetic frame pairs (BASELINE configs[1])"),
@@ -80,12 +85,74 @@ def cpu_baseline(cfg, k_vis, clump, seed, budget_s=20.0):
     }
 
 
+def run_prompts(args, rank, local_rank, world, distributed):
+    """Strong-scaling variant: total work fixed at 256 prompts; value = prompts / max-over-ranks time."""
+    from counterfactualworldmodels_amd import dist as cdist, prediction
+
+    cfg = C.CONFIGS[PROMPTS["cfg"]]
+    dev = torch.device("cuda", local_rank)
+    model = vmae.PretrainVisionTransformer(cfg, mode=args.mode)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, 0).items()})
+    G = prediction.PredictorBasedGenerator(predictor=model.to(dev).eval(), imagenet_normalize_inputs=True, temporal_dim=2)
+    n = cfg.tokens_per_frame
+    gw = cfg.img_size[1] // cfg.patch
+    x0 = torch.from_numpy(S.synthetic_frames(1, cfg, 0))[:, 0:1] if rank == 0 else None  # one image; frame 2 := frame 1
+    table = torch.from_numpy(S.synthetic_prompts(PROMPTS["total"], cfg, 0)) if rank == 0 else None
+
+    def build(xb, pr):  # prompt rows (active_h, active_w, dy, dx) -> shifted frame pairs + masks, on device
+        b = pr.shape[0]
+        active = torch.ones(1, 2 * n, b, dtype=torch.bool, device=dev)
+        active[:, :n] = False
+        idx = (pr[:, 0].long() * gw + pr[:, 1].long()) + n
+        active[0, idx, torch.arange(b, device=dev)] = False
+        passive = torch.ones(1, 2 * n, b, dtype=torch.bool, device=dev)
+        passive[:, :n] = False
+        return G.create_motion_counterfactuals(xb, masks=passive, active_patches=active, shifts=pr[:, 2:4].tolist(), reset_shifts=True)
+
+    def predict(xs, ms):
+        return G.predict(xs, ms, frame=-1)
+
+    def step():
+        return cdist.sharded_counterfactual_predictions(x0, table, build, predict, dev, chunk=PROMPTS["chunk"], gather=True)
+
+    for _ in range(max(args.warmup, 1)):
+        y = step()
+    assert y.shape[0] == PROMPTS["total"]
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_gpus = world if distributed else 1
+    out = {
+        "metric": "predicted frames/sec (2x224x224, ViT-B/8)", "value": PROMPTS["total"] * args.steps / dt, "unit": "frames/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": PROMPTS["name"], "predictor": cfg.name, "prompts": PROMPTS["total"], "chunk": PROMPTS["chunk"],
+                   "mode": args.mode, "parallelism": "prompts sharded over %d rank(s): broadcast(frame, prompt table) + all_gather(predicted frames)" % n_gpus},
+    }
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="base8", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="base8", choices=sorted(WORKLOADS) + ["prompts256"])
     ap.add_argument("--mode", default="parity", choices=["parity", "fast"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,6 +168,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     n_gpus = world if distributed else 1
+    if args.workload == "prompts256":
+        return run_prompts(args, rank, local_rank, world, distributed)
 
     wl = WORKLOADS[args.workload]
     cfg = C.CONFIGS[wl["cfg"]]

@@ -95,6 +95,10 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     ),
+    "cwm_shift_prompts": (
+        C.c_int,
+        [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p] * 6,
+    ),
     "cwm_bench_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cwm_bench_attention": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cwm_debug_set": (C.c_int, [C.c_char_p, C.c_int]),

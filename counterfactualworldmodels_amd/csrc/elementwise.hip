@@ -281,6 +281,72 @@ int launch_unembed(const UnembedParams& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Motion-counterfactual prompt construction, vectorised over all B*S prompts.
+// Reference: the per-sample Python loop of `create_motion_counterfactuals` (segmentation.py:324-338)
+// calling `PatchPerturbation.forward` + `ShiftPatchesAndMask.perturb` (perturbation.py:99-113,
+// 245-289) on a static movie (`make_static_movie`, prediction.py:731-739).  For prompt i = b*S+s:
+//   frame `frame`: the destination patch (pi,pj) of every active patch (pi-dy, pj-dx) receives the
+//   active patch's pixels; everything else is the (static) input.  Pure copies: bit-exact.
+//   mask_out = (active ? masks : 1) & (shifted perturbation mask), destinations out of frame vanish.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shift_prompts_x_kernel(const ShiftPromptParams p) {
+    const int w4 = p.W / 4;
+    const int64_t total = (int64_t)p.B * p.S * p.T * p.C * p.H * w4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    int64_t r = gid;
+    const int x4 = (int)(r % w4); r /= w4;
+    const int y = (int)(r % p.H); r /= p.H;
+    const int c = (int)(r % p.C); r /= p.C;
+    const int t = (int)(r % p.T);
+    const int i = (int)(r / p.T);
+    const int b = i / p.S;
+    const int x0 = x4 * 4;
+    const int ft = p.fix_passive ? 0 : t;
+    int sy = y, sx = x0;
+    if (t == p.frame) {
+        const int gw = p.W / p.P, gh = p.H / p.P, n = gh * gw;
+        const int dy = p.shifts[2 * i], dx = p.shifts[2 * i + 1];
+        const int pi = y / p.P - dy, pj = x0 / p.P - dx;
+        if (pi >= 0 && pi < gh && pj >= 0 && pj < gw && p.active[(size_t)i * p.T * n + (size_t)p.frame * n + pi * gw + pj] == 0) {
+            sy = y - dy * p.P;
+            sx = x0 - dx * p.P;
+        }
+    }
+    const float4 v = *reinterpret_cast<const float4*>(p.x + ((((size_t)b * p.T + ft) * p.C + c) * p.H + sy) * p.W + sx);
+    *reinterpret_cast<float4*>(p.x_out + ((((size_t)i * p.T + t) * p.C + c) * p.H + y) * p.W + x0) = v;
+}
+
+__global__ __launch_bounds__(256) void shift_prompts_mask_kernel(const ShiftPromptParams p) {
+    const int gw = p.W / p.P, gh = p.H / p.P, n = gh * gw, Nt = p.T * n;
+    const int64_t total = (int64_t)p.B * p.S * Nt;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int i = (int)(gid / Nt), tau = (int)(gid - (int64_t)i * Nt);
+    const int t = tau / n, hw = tau - t * n;
+    const uint8_t act = p.active[gid];
+    const uint8_t m1 = act ? p.masks[gid] : 1;
+    uint8_t mp = act;
+    if (t == p.frame) {
+        const int dy = p.shifts[2 * i], dx = p.shifts[2 * i + 1];
+        const int pi = hw / gw - dy, pj = hw % gw - dx;
+        mp = (pi >= 0 && pi < gh && pj >= 0 && pj < gw) ? p.active[(size_t)i * Nt + (size_t)t * n + pi * gw + pj] : 1;
+    }
+    p.mask_out[gid] = (m1 && mp) ? 1 : 0;
+}
+
+int launch_shift_prompts(const ShiftPromptParams& p, hipStream_t stream) {
+    CWM_REQUIRE(p.P % 4 == 0 && p.W % 4 == 0 && p.H % p.P == 0 && p.W % p.P == 0, "shift_prompts: bad patch/image size");
+    CWM_REQUIRE(p.frame >= 0 && p.frame < p.T, "shift_prompts: frame out of range");
+    const int64_t tx = (int64_t)p.B * p.S * p.T * p.C * p.H * (p.W / 4);
+    const int64_t tm = (int64_t)p.B * p.S * p.T * (p.H / p.P) * (p.W / p.P);
+    hipLaunchKernelGGL(shift_prompts_x_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(shift_prompts_mask_kernel, dim3((unsigned)((tm + 255) / 256)), dim3(256), 0, stream, p);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 __global__ void split_bf16_kernel(const float* x, int64_t n, bf16* hi, bf16* lo) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

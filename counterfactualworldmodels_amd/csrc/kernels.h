@@ -113,6 +113,18 @@ struct UnembedParams {
 
 int launch_unembed(const UnembedParams& p, hipStream_t stream);
 
+struct ShiftPromptParams {
+    const float* x;         // [B][T][C][H][W] contiguous frames
+    int B, S, T, C, H, W, P, frame, fix_passive;
+    const uint8_t* active;  // [B*S][Nt], 0 at the active (moved) patches
+    const uint8_t* masks;   // [B*S][Nt], 0 at the passive (kept visible) patches
+    const int* shifts;      // [B*S][2] (dy, dx) in patch units
+    float* x_out;           // [B*S][T][C][H][W]
+    uint8_t* mask_out;      // [B*S][Nt]
+};
+
+int launch_shift_prompts(const ShiftPromptParams& p, hipStream_t stream);
+
 int launch_perm_to_rank(const int* perm, int* rank, int B, int Nt, hipStream_t stream);
 
 int launch_split_bf16(const float* x, int64_t n, bf16* hi, bf16* lo, hipStream_t stream);

@@ -776,6 +776,18 @@ extern "C" int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const 
     return CWM_OK;
 }
 
+extern "C" int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int P, int frame, int S, int fix_passive,
+                                 const uint8_t* active_dev, const uint8_t* masks_dev, const int32_t* shifts_dev, float* x_out_dev,
+                                 uint8_t* mask_out_dev, void* stream) {
+    CWM_REQUIRE(x_dev && active_dev && masks_dev && shifts_dev && x_out_dev && mask_out_dev, "cwm_shift_prompts: null argument");
+    CWM_REQUIRE(B > 0 && S > 0 && T > 0 && C > 0 && P > 0, "cwm_shift_prompts: bad sizes");
+    ShiftPromptParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x_dev; p.B = B; p.S = S; p.T = T; p.C = C; p.H = H; p.W = W; p.P = P; p.frame = frame; p.fix_passive = fix_passive;
+    p.active = active_dev; p.masks = masks_dev; p.shifts = shifts_dev; p.x_out = x_out_dev; p.mask_out = mask_out_dev;
+    return launch_shift_prompts(p, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // diagnostics
 // ---------------------------------------------------------------------------------------------

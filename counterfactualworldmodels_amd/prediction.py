@@ -44,6 +44,7 @@ class PredictorBasedGenerator(nn.Module):
         temporal_dim=2,
         seed=0,
         mask_generator=None,
+        max_shift_fraction=0.15,
         **kwargs,
     ):
         super().__init__()
@@ -55,6 +56,9 @@ class PredictorBasedGenerator(nn.Module):
         self.seed = seed
         self.mask_generator = mask_generator
         self.mask_rectangularizer = RectangularizeMasks("min")
+        self.max_shift_fraction = max_shift_fraction
+        self._shift_rng = np.random.RandomState(seed=0)  # PatchPerturbation.__init__ default seed (perturbation.py:26-27)
+        self.shifts = None
         self.x, self.mask, self.timestamps = None, None, None
 
     # ---- predictor management (prediction.py:75-107) ---------------------------------------------
@@ -310,6 +314,124 @@ class PredictorBasedGenerator(nn.Module):
             x = x[:, None]
         assert len(x.shape) == 5, "x must be of shape [B,C,H,W] or [B,T,C,H,W], but is %s" % (x.shape,)
         return torch.tile(x[:, frame % x.size(1), None], (1, T, 1, 1, 1))
+
+    # ---- motion counterfactuals ---------------------------------------------------
+    def reset_shifts(self):
+        self.shifts = []
+
+    def _random_mask_shift(self):
+        """`ShiftPatchesAndMask.get_random_shift(is_mask_shift=True)` (perturbation.py:209-225), integer shifts."""
+        max_shift = [int(self.max_shift_fraction * s) for s in self.inp_shape[-2:]]
+        shift = (0, 0)
+        while sum(shift) == 0:  # (sic) the reference rejects any shift whose components sum to zero
+            shift = (
+                int(self._shift_rng.randint(-max_shift[0], max_shift[0] + 1) // self.patch_size[-2]),
+                int(self._shift_rng.randint(-max_shift[1], max_shift[1] + 1) // self.patch_size[-1]),
+            )
+        return shift
+
+    def create_motion_counterfactuals(self, x, masks, active_patches=None, shifts=None, frame=1, num_samples=None,
+                                      fix_passive=True, reset_shifts=False):
+        """`FlowGenerator.create_motion_counterfactuals` (segmentation.py:278-344): shift the active patches,
+        keep the passive ones; all B*S prompts are built by one pair of HIP kernels instead of the reference's
+        per-sample Python loop.  `shifts`: S (or B*S) pairs (dy, dx) in patch units, or None for random ones.
+        Returns (x_shift [B*S,T,C,H,W], mask_shift [B*S,Nt]) in '(b s)' order, masks rectangularised."""
+        _lib.require_gpu()
+        if (getattr(self, "shifts", None) is None) or reset_shifts:
+            self.reset_shifts()
+        if len(masks.shape) == 2:
+            assert num_samples is not None, "Choose how many samples to shift with arg num_samples"
+            masks = masks.unsqueeze(-1).expand(-1, -1, num_samples)
+        else:
+            num_samples = masks.size(-1)
+        if active_patches is None:
+            active_patches = torch.ones_like(masks)
+        elif len(active_patches.shape) == 2:
+            active_patches = active_patches.unsqueeze(-1).expand(-1, -1, masks.size(-1))
+        B, N, S = masks.shape
+        assert active_patches.size(-1) in [1, S]
+        if active_patches.size(-1) == 1:
+            active_patches = active_patches.expand(-1, -1, S)
+        if len(x.shape) == 4:
+            x = x[:, None]
+        T = x.shape[1] if not fix_passive else 2
+        dev = x.device
+        if not x.is_cuda:
+            raise RuntimeError("create_motion_counterfactuals needs CUDA/HIP tensors (no CPU fallback)")
+        self.inp_shape = (B, T) + tuple(x.shape[2:])
+        xs = x[:, 0:1] if fix_passive else x
+        xs = xs.to(torch.float32).contiguous()
+        if fix_passive:  # the kernel reads frame 0 for every output frame: give it a T-frame view without copying
+            xs = xs.expand(-1, T, -1, -1, -1).contiguous() if T != 1 else xs
+        if shifts is None:
+            shifts = [self._random_mask_shift() for _ in range(S)]
+        elif hasattr(shifts, "shape"):
+            arr = shifts.detach().cpu().numpy() if isinstance(shifts, torch.Tensor) else np.asarray(shifts)
+            shifts = [tuple(int(v) for v in arr[..., s]) for s in range(arr.shape[-1])] if arr.shape[0] == 2 and arr.ndim == 2 and arr.shape[-1] in (S, 1, B * S) and arr.shape[0] != arr.shape[-1] else [tuple(int(v) for v in r) for r in arr]
+        shifts = [tuple(int(v) for v in sh) for sh in shifts]
+        if len(shifts) == 1:
+            shifts = shifts * S
+        assert len(shifts) in (S, B * S), (len(shifts), S)
+        if len(shifts) == S:
+            shifts = shifts * B
+        sh = torch.tensor(shifts, dtype=torch.int32, device=dev).contiguous()
+        act = active_patches.permute(0, 2, 1).reshape(B * S, N).to(device=dev, dtype=torch.bool).contiguous()
+        msk = masks.permute(0, 2, 1).reshape(B * S, N).to(device=dev, dtype=torch.bool).contiguous()
+        Cc, H, W = xs.shape[2:]
+        x_shift = torch.empty((B * S, T, Cc, H, W), device=dev, dtype=torch.float32)
+        mask_shift = torch.empty((B * S, N), device=dev, dtype=torch.bool)
+        with torch.cuda.device(dev):
+            _lib.check(
+                _lib.get_lib().cwm_shift_prompts(
+                    xs.data_ptr(), B, T, Cc, H, W, self.patch_size[-1], frame % T, S, int(bool(fix_passive)), act.data_ptr(),
+                    msk.data_ptr(), sh.data_ptr(), x_shift.data_ptr(), mask_shift.data_ptr(), _lib.current_stream_handle(dev),
+                )
+            )
+        for dy, dx in shifts:
+            self.shift = [dy, dx]
+            self.shifts.append(np.array(self.shift))
+        mask_shift = self.mask_rectangularizer(mask_shift)
+        return (x_shift, mask_shift)
+
+    def predict_counterfactual_videos(self, x, active_patches, passive_patches=None, shifts=None, num_samples=8,
+                                      sample_batch_size=8, fix_passive=True, frame=1, **kwargs):
+        """The predictor half of `predict_counterfactual_videos_and_flows` (segmentation.py:346-430): build the
+        motion counterfactuals and batch-predict them; returns y_mocos [B*S,T,C,H,W] (the RAFT flow step that
+        follows in the reference is outside this package's scope)."""
+        if len(x.shape) == 3:
+            x = x.unsqueeze(0).unsqueeze(1).expand(-1, 2, -1, -1, -1)
+            fix_passive = True
+        elif len(x.shape) == 4:
+            x = x.unsqueeze(1).expand(-1, 2, -1, -1, -1)
+            fix_passive = True
+        elif len(x.shape) == 5 and x.size(1) == 1:
+            x = x.expand(-1, 2, -1, -1, -1)
+        assert len(x.shape) == 5, x.shape
+        x = x[:, 0:2]
+        self.set_input(x)
+        self.reset_shifts()
+        if passive_patches is None:
+            passive_patches = self.get_zeros_mask().unsqueeze(-1)
+        elif len(passive_patches.shape) == 2:
+            passive_patches = passive_patches.unsqueeze(-1)
+        if len(active_patches.shape) == 2:
+            active_patches = active_patches.unsqueeze(-1)
+        S = max(active_patches.size(-1), passive_patches.size(-1))
+        if (S == 1) and num_samples > 1:
+            S = num_samples
+        if shifts is None:
+            shifts = [self._random_mask_shift() for _ in range(S)]
+        num_samples = len(shifts) if not hasattr(shifts, "shape") else shifts.shape[-1]
+        if (active_patches.size(-1) == 1) and (num_samples > 1):
+            active_patches = active_patches.expand(-1, -1, num_samples)
+        if (passive_patches.size(-1) == 1) and (num_samples > 1):
+            passive_patches = passive_patches.expand(-1, -1, num_samples)
+        assert active_patches.size(-1) == passive_patches.size(-1) == num_samples, (active_patches.shape, passive_patches.shape, num_samples)
+        x_mocos, masks_mocos = self.create_motion_counterfactuals(
+            x, masks=passive_patches, active_patches=active_patches, shifts=shifts, num_samples=num_samples,
+            fix_passive=fix_passive, frame=frame, reset_shifts=False)
+        return self.batch_predict_per_sample(
+            x_mocos, masks=masks_mocos, frame=None, batch_size=(sample_batch_size or x_mocos.size(0)), sample_dim=0, **kwargs)
 
     def forward(self, x, mask=None, frame=None, *args, **kwargs):
         self.set_input(x, mask)

@@ -121,6 +121,17 @@ int cwm_mask_to_perm(const uint8_t* mask_dev, int B, int Nt, int n_vis, int32_t*
 int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const uint8_t* mask_dev, int B, int T, int C, int H, int W,
                 int P, int n_vis, float* out_dev, void* stream);
 
+/* Motion-counterfactual prompt construction for B*S prompts at once.
+ * replaces: the per-sample loop of FlowGenerator.create_motion_counterfactuals (segmentation.py:324-338)
+ *           = PatchPerturbation.forward + ShiftPatchesAndMask.perturb (perturbation.py:99-113, 245-289)
+ *           on make_static_movie(x) when fix_passive=1 (prediction.py:731-739), BEFORE the final
+ *           mask_rectangularizer call (host).  x [B,T,C,H,W]; active/masks [B*S,Nt] bool ('(b s)' order,
+ *           0 = active patch / 0 = passive visible patch); shifts [B*S,2] (dy,dx) in patch units;
+ *           outputs x_out [B*S,T,C,H,W], mask_out [B*S,Nt].  Asynchronous on `stream`. */
+int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int P, int frame, int S, int fix_passive,
+                      const uint8_t* active_dev, const uint8_t* masks_dev, const int32_t* shifts_dev, float* x_out_dev,
+                      uint8_t* mask_out_dev, void* stream);
+
 /* ---- diagnostics: single-kernel micro-benchmarks on random operands (tools/microbench.py) ---------
  * epi: 0 = fp32 out + bias + in-place residual (proj/fc2 form), 1 = bias + GELU -> bf16 (fc1 form),
  *      3 = QKV head scatter (N must be 3*64*heads, M = batch*n_tok with n_tok = M / batch).

@@ -292,3 +292,61 @@ def algorithmic_flops(spec: VmaeSpec, n_vis: int) -> float:
     f += spec.dec_depth * (24.0 * Nt * Dd * Dd + 4.0 * Nt * Nt * Dd)
     f += 2.0 * Nm * Dd * spec.out_dim
     return f
+
+
+# ----------------------------------------------------------------------------------------------
+# f-1: motion-counterfactual prompt construction (shift the active patches, keep the passive ones)
+# `PatchPerturbation.forward` + `ShiftPatchesAndMask.perturb` (perturbation.py:99-113, 245-289),
+# driven per sample as in `create_motion_counterfactuals` (segmentation.py:278-344).  Pure copies
+# and boolean work: bit-exact.
+# ----------------------------------------------------------------------------------------------
+def _shift_frame(img: torch.Tensor, dy: int, dx: int, fill: float) -> torch.Tensor:
+    """`CenterCrop(F.pad(img, 2*shift on one side))` == translate by (dy, dx) with `fill`
+    (perturbation.py:227-243, 263-264): out[y, x] = img[y - dy, x - dx]."""
+    H, W = img.shape[-2:]
+    out = torch.full_like(img, fill)
+    ys0, ys1 = max(0, dy), min(H, H + dy)
+    xs0, xs1 = max(0, dx), min(W, W + dx)
+    if ys1 > ys0 and xs1 > xs0:
+        out[..., ys0:ys1, xs0:xs1] = img[..., ys0 - dy : ys1 - dy, xs0 - dx : xs1 - dx]
+    return out
+
+
+def shift_patches_and_mask(x_1tchw, mask_1n, active_1n, shift_patches, P: int, frame: int = 1):
+    """One sample of the reference loop: `self.shifter(x, mask=min(mask, active),
+    perturbation_points=~active, mask_shift=shift, frame=frame)`.
+
+    x: [1,T,C,H,W]; mask: bool [1,Nt] (True = masked; the *passive* patches are its zeros);
+    active: bool [1,Nt] (False at the active patches); shift_patches = (dy, dx) in patch units."""
+    _, T, C, H, W = x_1tchw.shape
+    gh, gw = H // P, W // P
+    dy, dx = int(shift_patches[0]), int(shift_patches[1])
+    points = ~active_1n
+    m = torch.minimum(mask_1n, active_1n).clone()
+    m[points] = True  # perturbation.py:106: the moved patches are re-masked at their source
+    pm = active_1n.view(1, T, gh, gw)  # perturbation mask = ~points
+    pm_shift = _shift_frame(pm[:, frame].float(), dy, dx, 1.0).bool()  # mask padded with 1s (:266-268)
+    mask_p = pm.clone()
+    mask_p[:, frame] = pm_shift
+    x_out = x_1tchw.clone()
+    shifted = _shift_frame(x_1tchw[:, frame], dy * P, dx * P, 0.0)  # image padded with 0s (:263-264)
+    take = (~pm_shift).repeat_interleave(P, -2).repeat_interleave(P, -1).unsqueeze(1)  # [1,1,H,W]
+    x_out[:, frame] = torch.where(take, shifted, x_1tchw[:, frame])  # :277-283
+    mask_out = torch.minimum(m, mask_p.view(1, -1))  # perturbation.py:110-111
+    return x_out, mask_out
+
+
+def create_motion_counterfactuals(x_btchw, masks_bns, active_bns, shifts, P: int, frame: int = 1, fix_passive: bool = True):
+    """`FlowGenerator.create_motion_counterfactuals` (segmentation.py:278-344) before the final
+    `mask_rectangularizer` call: returns (x_shift [B*S,...], mask_shift [B*S,Nt]) in '(b s)' order."""
+    B, N, S = masks_bns.shape
+    if fix_passive:  # make_static_movie(x[:,0:1], T=2)  (prediction.py:731-739)
+        x_btchw = x_btchw[:, 0:1].repeat(1, 2, 1, 1, 1)
+    xs, ms = [], []
+    for b in range(B):
+        for s in range(S):
+            xo, mo = shift_patches_and_mask(x_btchw[b : b + 1], masks_bns[b : b + 1, :, s], active_bns[b : b + 1, :, s],
+                                            shifts[b * S + s], P, frame)
+            xs.append(xo)
+            ms.append(mo)
+    return torch.cat(xs, 0), torch.cat(ms, 0)

@@ -27,6 +27,8 @@ import ref_import  # noqa: E402
 from counterfactualworldmodels_amd import config as C  # noqa: E402
 from counterfactualworldmodels_amd import synthetic as S  # noqa: E402
 
+S_ = S
+
 TINY = C.VmaeConfig(
     name="tiny_8x8", img_size=(32, 32), patch=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=1, dec_heads=2
 )
@@ -164,6 +166,64 @@ def run_index_cases(ns):
     print("[golden] index_ops.npz")
 
 
+def run_shift_cases(ns):
+    """f-1 fixtures: the reference's own `FlowGenerator.create_motion_counterfactuals` (segmentation.py:278-344)
+    on a 4x4 grid (tiny) and on the 28x28 B/8 grid, incl. negative and out-of-frame shifts and passive patches."""
+    assert ns.segmentation is not None, getattr(ns, "segmentation_error", None)
+
+    class DummyFlow(torch.nn.Module):
+        def forward(self, x, *a, **k):
+            return torch.zeros(x.shape[0], x.shape[1] - 1, 2, *x.shape[-2:])
+
+    out = {}
+    for tag, cfg, S in (("tiny", TINY, 12), ("base8", C.CONFIGS["base_8x8patch_2frames_1tube"], 24)):
+        m = build_ref_model(ns, cfg, 3) if tag == "tiny" else ns.vmae.base_8x8patch_2frames_1tube().eval()
+        G = ns.segmentation.FlowGenerator(predictor=m, flow_model=DummyFlow(), imagenet_normalize_inputs=True, temporal_dim=2, seed=0)
+        B = 1  # the reference loop indexes shifts[i] for i < B*S with len(shifts) == S: it only supports B == 1
+        gh = cfg.img_size[0] // cfg.patch
+        n = gh * gh
+        x = torch.from_numpy(S_.synthetic_frames(B, cfg, 21))
+        g = np.random.Generator(np.random.PCG64(31))
+        active = torch.ones(B, 2 * n, S, dtype=torch.bool)
+        active[:, :n] = False
+        passive = torch.ones(B, 2 * n, S, dtype=torch.bool)
+        passive[:, :n] = False
+        shifts = []
+        for b in range(B):
+            for s in range(S):
+                a = int(g.integers(n))
+                active[b, n + a, s] = False
+                if s % 3 == 0:  # one passive patch as well
+                    pz = int(g.integers(n))
+                    passive[b, n + pz, s] = False
+                if s % 5 == 4:  # two active patches
+                    active[b, n + int(g.integers(n)), s] = False
+        lim = gh if tag == "tiny" else 3
+        for s in range(S):
+            while True:
+                dy, dx = int(g.integers(-lim, lim + 1)), int(g.integers(-lim, lim + 1))
+                if dy or dx:
+                    break
+            shifts.append([dy, dx])
+        G.set_input(x[:, 0:2])
+        G.shifter.set_shapes(x, mask=active[..., 0])
+        torch.manual_seed(77)
+        x_shift, mask_post = G.create_motion_counterfactuals(
+            x, masks=passive, active_patches=active, shifts=[list(v) for v in shifts], num_samples=S, fix_passive=True, reset_shifts=True)
+        out[f"{tag}_active"] = active.numpy()
+        out[f"{tag}_passive"] = passive.numpy()
+        out[f"{tag}_shifts"] = np.array(shifts, dtype=np.int32)
+        out[f"{tag}_mask_post"] = mask_post.numpy()
+        out[f"{tag}_rect_seed"] = np.array(77)
+        xs = x_shift.double()
+        out[f"{tag}_x_digest"] = np.array([xs.sum().item(), (xs * xs).sum().item()])
+        out[f"{tag}_x_frame1_sub"] = x_shift[:, 1, :, :: max(1, cfg.img_size[0] // 16), :: max(1, cfg.img_size[0] // 16)].numpy().copy()
+        if tag == "tiny":
+            out["tiny_x_shift"] = x_shift.numpy()
+    np.savez_compressed(os.path.join(HERE, "shift_prompts.npz"), **out)
+    print("[golden] shift_prompts.npz")
+
+
 def run_init_case(ns):
     """Reference constructor RNG parity: seed -> freshly initialised parameters (vmae.py:90,209,371)."""
     out = {}
@@ -193,7 +253,11 @@ def main():
     if args.only == "init":
         run_init_case(ns)
         return
+    if args.only == "shift":
+        run_shift_cases(ns)
+        return
     run_init_case(ns)
+    run_shift_cases(ns)
     run_index_cases(ns)
     run_block_case(ns)
     run_model_case(ns, TINY, batch=3, k_vis=4, clump=1, seed=3, out_name="tiny_8x8_k4.npz")

@@ -120,4 +120,9 @@ def import_reference():
     ns.perturbation = importlib.import_module("cwm.models.perturbation")
     ns.patches = importlib.import_module("cwm.models.patches")
     ns.utils = importlib.import_module("cwm.models.utils")
+    try:
+        ns.segmentation = importlib.import_module("cwm.models.segmentation")
+    except Exception as e:  # pragma: no cover - optional (needs scipy etc.)
+        ns.segmentation = None
+        ns.segmentation_error = e
     return ns

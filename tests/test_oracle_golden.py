@@ -128,3 +128,27 @@ def test_flops_formula():
     assert abs(O.algorithmic_flops(O.SPECS["base_8x8patch_2frames_1tube"], 785) / 1.944e11 - 1) < 5e-3
     assert abs(O.algorithmic_flops(O.SPECS["large_4x4patch_2frames_1tube"], 3168) / 4.344e12 - 1) < 5e-3
     assert C.algorithmic_flops(C.CONFIGS["base_8x8patch_2frames_1tube"], 792) == O.algorithmic_flops(O.SPECS["base_8x8patch_2frames_1tube"], 792)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "base8"])
+def test_shift_prompts_oracle_vs_reference(tag):
+    """f-1: the oracle's motion-counterfactual construction against the fixture captured from the reference's
+    own `FlowGenerator.create_motion_counterfactuals` (pure copies / boolean ops: bit-exact, incl. the
+    post-RectangularizeMasks masks under the recorded torch seed)."""
+    g = load("shift_prompts.npz")
+    cfg = TINY if tag == "tiny" else C.CONFIGS["base_8x8patch_2frames_1tube"]
+    x = torch.from_numpy(S.synthetic_frames(1, cfg, 21))
+    active, passive, shifts = torch.from_numpy(g[f"{tag}_active"]), torch.from_numpy(g[f"{tag}_passive"]), g[f"{tag}_shifts"]
+    xs, ms = O.create_motion_counterfactuals(x, passive, active, shifts, cfg.patch)
+    torch.manual_seed(int(g[f"{tag}_rect_seed"]))
+    assert np.array_equal(O.rectangularize_masks_min(ms.clone()).numpy(), g[f"{tag}_mask_post"])
+    sub = xs[:, 1, :, :: max(1, cfg.img_size[0] // 16), :: max(1, cfg.img_size[0] // 16)].numpy()
+    assert np.array_equal(sub, g[f"{tag}_x_frame1_sub"])
+    if tag == "tiny":
+        assert np.array_equal(xs.numpy(), g["tiny_x_shift"])
+    # 4x4-grid behaviour (SURVEY.md A9): destinations outside the frame vanish, the source patch is re-masked
+    n = (cfg.img_size[0] // cfg.patch) ** 2
+    assert not ms[:, :n].any()
+    for i in range(ms.shape[0]):
+        a_src = torch.where(~active[0, n:, i])[0]
+        assert ms[i, n + a_src].all() or (shifts[i] == 0).all()
