@@ -70,6 +70,47 @@ class CwmForwardArgs(C.Structure):
     ]
 
 
+class CwmConjConfig(C.Structure):
+    _fields_ = [
+        ("main", CwmConfig),
+        ("main_max_pad", C.c_int32),
+        ("ctx_in_chans", C.c_int32),
+        ("ctx_seq_len", C.c_int32),
+        ("ctx_tubelet", C.c_int32),
+        ("ctx_enc_dim", C.c_int32),
+        ("ctx_dec_dim", C.c_int32),
+        ("ctx_enc_heads", C.c_int32),
+        ("ctx_dec_heads", C.c_int32),
+        ("ctx_max_pad", C.c_int32),
+        ("n_enc_cross", C.c_int32),
+        ("enc_cross", C.c_int32 * 16),
+        ("n_dec_cross", C.c_int32),
+        ("dec_cross", C.c_int32 * 16),
+        ("cross_heads", C.c_int32),
+        ("cross_mlp_ratio", C.c_int32),
+    ]
+
+
+class CwmConjForwardArgs(C.Structure):
+    _fields_ = [
+        ("x_dev", C.c_void_p),
+        ("x_stride_b", C.c_int64),
+        ("x_stride_c", C.c_int64),
+        ("x_stride_t", C.c_int64),
+        ("normalize", C.c_int32),
+        ("mask_dev", C.c_void_p),
+        ("batch", C.c_int32),
+        ("n_vis_max", C.c_int32),
+        ("ctx_dev", C.c_void_p),
+        ("ctx_mask_dev", C.c_void_p),
+        ("n_vis_ctx_max", C.c_int32),
+        ("y_tokens_dev", C.c_void_p),
+        ("mode", C.c_int32),
+        ("check", C.c_int32),
+        ("stream", C.c_void_p),
+    ]
+
+
 class CwmKernelStats(C.Structure):
     _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("total_flops", C.c_double)]
 
@@ -81,6 +122,13 @@ SIGNATURES = {
     "cwm_model_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "cwm_model_missing_weights": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "cwm_forward": (C.c_int, [C.c_void_p, C.POINTER(CwmForwardArgs)]),
+    "cwm_conj_create": (C.c_int, [C.POINTER(CwmConjConfig), C.POINTER(C.c_void_p)]),
+    "cwm_conj_destroy": (None, [C.c_void_p]),
+    "cwm_conj_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "cwm_conj_missing_weights": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "cwm_conj_forward": (C.c_int, [C.c_void_p, C.POINTER(CwmConjForwardArgs)]),
+    "cwm_conj_timing_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "cwm_conj_timing_collect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(CwmKernelStats)]),
     "cwm_timing_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "cwm_timing_collect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(CwmKernelStats)]),
     "cwm_split_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

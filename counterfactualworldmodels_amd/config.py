@@ -8,7 +8,7 @@ from __future__ import annotations
 
 from collections import OrderedDict
 from dataclasses import dataclass
-from typing import Dict, Tuple
+from typing import Dict, Tuple  # noqa: F401
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -124,3 +124,103 @@ def algorithmic_flops(cfg: VmaeConfig, n_vis: int) -> float:
     f += cfg.dec_depth * (24.0 * Nt * Dd * Dd + 4.0 * Nt * Nt * Dd)
     f += 2.0 * Nm * Dd * cfg.out_dim
     return f
+
+
+# ---------------------------------------------------------------------------------------------
+# IMU-conditioned conjoined padded predictor (BASELINE configs[4])
+# `imu400_base_4x4patch_2frames_1tube` (cwm/models/VideoMAE/conjoined_vmae.py:1230-1243)
+# ---------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class ConjConfig:
+    name: str = "imu400_base_4x4patch_2frames_1tube"
+    main: VmaeConfig = VmaeConfig(name="imu400_main_4x4", patch=4)
+    main_max_pad: int = 64
+    ctx_in_chans: int = 6
+    ctx_seq_len: int = 400
+    ctx_tubelet: int = 16
+    ctx_enc_dim: int = 384
+    ctx_dec_dim: int = 192
+    ctx_enc_heads: int = 12
+    ctx_dec_heads: int = 6
+    ctx_max_pad: int = 25
+    enc_cross: Tuple[int, ...] = (0, 3, 6, 9)
+    dec_cross: Tuple[int, ...] = (0, 1, 2, 3)
+    cross_heads: int = 4
+    cross_mlp_ratio: int = 2
+
+    @property
+    def ctx_tokens(self) -> int:
+        return self.ctx_seq_len // self.ctx_tubelet
+
+    @property
+    def ctx_out_dim(self) -> int:
+        return self.ctx_in_chans * self.ctx_tubelet
+
+
+CONJ_CONFIGS: Dict[str, ConjConfig] = {"imu400_base_4x4patch_2frames_1tube": ConjConfig()}
+
+
+def _cross_schema(pre: str, ci: int, cs: int, ratio: int, out: "OrderedDict[str, tuple]") -> None:
+    d = ci  # inner width D = heads * (in_dim // heads) = in_dim (transformer.py:272, 300-303)
+    out[pre + "norm1_cross.weight"] = (ci,)
+    out[pre + "norm1_cross.bias"] = (ci,)
+    out[pre + "norm1_src_cross.weight"] = (cs,)
+    out[pre + "norm1_src_cross.bias"] = (cs,)
+    out[pre + "norm2.weight"] = (ci,)
+    out[pre + "norm2.bias"] = (ci,)
+    out[pre + "norm2_src.weight"] = (cs,)
+    out[pre + "norm2_src.bias"] = (cs,)
+    out[pre + "cross_attention.qk.weight"] = (2 * d, ci)
+    out[pre + "cross_attention.qk_src.weight"] = (2 * d, cs)
+    out[pre + "cross_attention.v.weight"] = (d, ci)
+    out[pre + "cross_attention.v_src.weight"] = (d, cs)
+    out[pre + "cross_attention.projection.weight"] = (ci, d)
+    out[pre + "cross_attention.projection.bias"] = (ci,)
+    out[pre + "cross_attention.projection_src.weight"] = (cs, d)
+    out[pre + "cross_attention.projection_src.bias"] = (cs,)
+    out[pre + "mlp.trg.layers.0.weight"] = (ratio * ci, ci)
+    out[pre + "mlp.trg.layers.0.bias"] = (ratio * ci,)
+    out[pre + "mlp.trg.layers.2.weight"] = (ci, ratio * ci)
+    out[pre + "mlp.trg.layers.2.bias"] = (ci,)
+    out[pre + "mlp.src.layers.0.weight"] = (ratio * cs, cs)
+    out[pre + "mlp.src.layers.0.bias"] = (ratio * cs,)
+    out[pre + "mlp.src.layers.2.weight"] = (cs, ratio * cs)
+    out[pre + "mlp.src.layers.2.bias"] = (cs,)
+
+
+def conj_state_dict_schema(cfg: ConjConfig) -> "OrderedDict[str, tuple]":
+    """Parameter names -> shapes in the reference's order (634 tensors)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    m = cfg.main
+    main = state_dict_schema(m)
+    s["main_stream.mask_token"] = main["mask_token"]
+    s["main_stream.null_token_enc"] = (1, 1, m.enc_dim)
+    s["main_stream.null_token_dec"] = (1, 1, m.dec_dim)
+    for k, v in main.items():
+        if k != "mask_token":
+            s["main_stream." + k] = v
+    c = "context_stream."
+    s[c + "mask_token"] = (1, 1, cfg.ctx_dec_dim)
+    s[c + "null_token_enc"] = (1, 1, cfg.ctx_enc_dim)
+    s[c + "null_token_dec"] = (1, 1, cfg.ctx_dec_dim)
+    s[c + "encoder.patch_embed.proj.weight"] = (cfg.ctx_enc_dim, cfg.ctx_in_chans, cfg.ctx_tubelet, 1, 1)
+    s[c + "encoder.patch_embed.proj.bias"] = (cfg.ctx_enc_dim,)
+    for i in range(m.enc_depth):
+        _block_schema(f"{c}encoder.blocks.{i}.", cfg.ctx_enc_dim, m.mlp_ratio * cfg.ctx_enc_dim, s)
+    s[c + "encoder.norm.weight"] = (cfg.ctx_enc_dim,)
+    s[c + "encoder.norm.bias"] = (cfg.ctx_enc_dim,)
+    for i in range(m.dec_depth):
+        _block_schema(f"{c}decoder.blocks.{i}.", cfg.ctx_dec_dim, m.mlp_ratio * cfg.ctx_dec_dim, s)
+    s[c + "decoder.norm.weight"] = (cfg.ctx_dec_dim,)
+    s[c + "decoder.norm.bias"] = (cfg.ctx_dec_dim,)
+    s[c + "decoder.head.weight"] = (cfg.ctx_out_dim, cfg.ctx_dec_dim)
+    s[c + "decoder.head.bias"] = (cfg.ctx_out_dim,)
+    s[c + "encoder_to_decoder.weight"] = (cfg.ctx_dec_dim, cfg.ctx_enc_dim)
+    # present in the checkpoints, never used on this path (spacetime_separable_pos_embed=True, vmae.py:368-369)
+    s[c + "pos_embed_encoder.weight"] = (cfg.ctx_dec_dim, 2 * cfg.ctx_dec_dim)
+    s[c + "pos_embed_encoder.bias"] = (cfg.ctx_dec_dim,)
+    for i in cfg.enc_cross:
+        _cross_schema(f"encoder_conjoining_blocks.{i}-{i}.", m.enc_dim, cfg.ctx_enc_dim, cfg.cross_mlp_ratio, s)
+    for i in cfg.dec_cross:
+        _cross_schema(f"decoder_conjoining_blocks.{i}-{i}.", m.dec_dim, cfg.ctx_dec_dim, cfg.cross_mlp_ratio, s)
+    return s

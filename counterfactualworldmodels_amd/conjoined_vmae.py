@@ -1,0 +1,252 @@
+"""Host-side mirror of the IMU-conditioned conjoined padded predictor, backed by libcwm_hip.so.
+
+`ConjoinedPaddedVisionTransformer` / `imu400_base_4x4patch_2frames_1tube` keep the reference's surface
+(`cwm/models/VideoMAE/conjoined_vmae.py:889-1011, 1230-1243`): the 634 state-dict keys and shapes of
+the published checkpoint, `forward(x, mask, timestamps=None, x_context=None,
+mask_context=None, output_main=None, output_context=None)` returning the main-stream tokens
+`[B, Nt + 64 - max_visible, 48]` with rows at masked pad slots zeroed, and the attributes the wrapper
+reads (`main_stream`, `context_stream`, `max_padding_tokens`, `min_padding_tokens`, `padding_mask`,
+`_reset_padding_mask`, `get_current_inputs`, `patch_size`, `image_size`, `num_frames`, `mask_size`).
+The parameter tree holds no compute: the forward pass is one `cwm_conj_forward` call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import CONJ_CONFIGS, LN_EPS, ConjConfig, conj_state_dict_schema
+
+
+class _Params(nn.Module):
+    """Parameter container (one node of the reference's module tree); never called."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: the computation runs inside libcwm_hip.so")
+
+
+def _init_param(name: str, p: torch.Tensor) -> None:
+    if "norm" in name and name.endswith("weight"):
+        nn.init.ones_(p)
+    elif name.endswith("bias"):
+        nn.init.zeros_(p)
+    elif "token" in name:
+        nn.init.trunc_normal_(p, std=0.02, a=-0.02, b=0.02)
+    elif p.dim() >= 2:
+        nn.init.xavier_uniform_(p.view(p.shape[0], -1))
+    else:
+        nn.init.zeros_(p)
+
+
+def _build_tree(root: nn.Module, schema) -> None:
+    for key, shape in schema.items():
+        node = root
+        parts = key.split(".")
+        for part in parts[:-1]:
+            if part not in node._modules:
+                node.add_module(part, _Params())
+            node = node._modules[part]
+        p = nn.Parameter(torch.empty(shape))
+        _init_param(key, p.data)
+        node.register_parameter(parts[-1], p)
+
+
+class ConjoinedPaddedVisionTransformer(nn.Module):
+    def __init__(self, cfg: ConjConfig, mode: str = "parity", **unused):
+        super().__init__()
+        self.cfg = cfg
+        self.mode = mode
+        _lib.mode_id(mode)
+        _build_tree(self, conj_state_dict_schema(cfg))
+        m = cfg.main
+        ms, cs = self.main_stream, self.context_stream
+        ms.max_padding_tokens, ms.min_padding_tokens = cfg.main_max_pad, 0
+        cs.max_padding_tokens, cs.min_padding_tokens = cfg.ctx_max_pad, 0
+        ms.patch_size = (1, m.patch, m.patch)
+        ms.image_size = tuple(m.img_size)
+        ms.num_frames = m.num_frames
+        ms.num_patches = m.num_tokens
+        ms.padding_mask = ms.full_input_mask = ms.null_mask = None
+        ms._reset_padding_mask = lambda: self._reset_stream(ms)
+        cs.patch_size = (cfg.ctx_tubelet, 1, 1)
+        cs.image_size = (1, 1)
+        cs.num_frames = 0
+        cs.padding_mask = cs.full_input_mask = cs.null_mask = None
+        cs._reset_padding_mask = lambda: self._reset_stream(cs)
+        cs.encoder.num_tokens = cfg.ctx_tokens
+        cs.encoder.sequence_length = cfg.ctx_seq_len
+        self.num_frames = m.num_frames
+        self.get_context_input = type("IMU", (), {"num_channels": cfg.ctx_in_chans, "num_frames": None})()
+        self.get_main_input = type("RGB01", (), {"num_channels": m.in_chans, "num_frames": m.num_frames})()
+        self._output_main, self._output_context = True, False
+        self.default_cfg = {}
+        self._handle: Optional[int] = None
+        self._handle_device: Optional[torch.device] = None
+        self._loaded: Dict[str, Tuple[int, int]] = {}
+
+    # ---- reference attribute surface ---------------------------------------------------------------
+    @staticmethod
+    def _reset_stream(s):
+        s.padding_mask = s.full_input_mask = s.null_mask = None
+
+    def _reset_padding_mask(self):
+        self._reset_stream(self.main_stream)
+        self._reset_stream(self.context_stream)
+
+    @property
+    def patch_size(self):
+        return self.main_stream.patch_size
+
+    @property
+    def image_size(self):
+        return self.main_stream.image_size
+
+    @image_size.setter
+    def image_size(self, v):
+        self.main_stream.image_size = tuple(v)
+
+    @property
+    def padding_mask(self):
+        # the reference's __getattr__ falls through to the main stream and raises while it is None
+        # (conjoined_vmae.py:347-354), so hasattr(model, 'padding_mask') is False before a forward
+        if self.main_stream.padding_mask is None:
+            raise AttributeError("no attr padding_mask in the module or the main transformer stream")
+        return self.main_stream.padding_mask
+
+    @property
+    def max_padding_tokens(self):
+        return self.main_stream.max_padding_tokens
+
+    @property
+    def min_padding_tokens(self):
+        return self.main_stream.min_padding_tokens
+
+    @property
+    def mask_size(self):  # conjoined_vmae.py:356-360
+        ps = self.main_stream.patch_size
+        return (self.num_frames // ps[0], self.main_stream.image_size[-2] // ps[-2], self.main_stream.image_size[-1] // ps[-1])
+
+    def get_current_inputs(self, x, mask, *args, **kwargs):
+        """conjoined_vmae.py:722-732 with output_main only: the main stream sees (x, mask) unchanged ('rgb01')."""
+        return ((x, mask, None),)
+
+    # ---- C-ABI plumbing ------------------------------------------------------------------------------
+    def _ensure_handle(self, device: torch.device) -> int:
+        lib = _lib.get_lib()
+        if self._handle is not None and self._handle_device == device:
+            return self._handle
+        self._release()
+        c, m = self.cfg, self.cfg.main
+        cc = _lib.CwmConjConfig()
+        cc.main = _lib.CwmConfig(m.img_size[0], m.img_size[1], m.patch, m.num_frames, m.in_chans, m.enc_dim, m.enc_depth, m.enc_heads,
+                                 m.dec_dim, m.dec_depth, m.dec_heads, m.mlp_ratio, LN_EPS)
+        cc.main_max_pad = c.main_max_pad
+        cc.ctx_in_chans, cc.ctx_seq_len, cc.ctx_tubelet = c.ctx_in_chans, c.ctx_seq_len, c.ctx_tubelet
+        cc.ctx_enc_dim, cc.ctx_dec_dim, cc.ctx_enc_heads, cc.ctx_dec_heads = c.ctx_enc_dim, c.ctx_dec_dim, c.ctx_enc_heads, c.ctx_dec_heads
+        cc.ctx_max_pad = c.ctx_max_pad
+        cc.n_enc_cross, cc.n_dec_cross = len(c.enc_cross), len(c.dec_cross)
+        for i, v in enumerate(c.enc_cross):
+            cc.enc_cross[i] = v
+        for i, v in enumerate(c.dec_cross):
+            cc.dec_cross[i] = v
+        cc.cross_heads, cc.cross_mlp_ratio = c.cross_heads, c.cross_mlp_ratio
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.cwm_conj_create(C.byref(cc), C.byref(h)))
+        self._handle, self._handle_device, self._loaded = h.value, device, {}
+        return self._handle
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            try:
+                _lib.get_lib().cwm_conj_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+            self._loaded = {}
+
+    def __del__(self):
+        self._release()
+
+    def sync_weights(self, device: Optional[torch.device] = None) -> int:
+        device = device or next(self.parameters()).device
+        h = self._ensure_handle(device)
+        lib = _lib.get_lib()
+        n = 0
+        with torch.cuda.device(device):
+            for name, p in self.state_dict(keep_vars=True).items():
+                tag = (p.data_ptr(), p._version)
+                if self._loaded.get(name) == tag:
+                    continue
+                t = p.detach()
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    t = t.float().contiguous()
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                _lib.check(lib.cwm_conj_load_weight(h, name.encode(), t.data_ptr(), 1 if t.is_cuda else 0, shape, t.dim()))
+                self._loaded[name] = tag
+                n += 1
+        return n
+
+    # ---- reference forward: conjoined_vmae.py:852-887 ----------------------------------------------
+    @torch.no_grad()
+    def forward(self, x, mask, timestamps=None, x_context=None, mask_context=None, output_main=None, output_context=None,
+                *args, normalize: bool = False, check: bool = True, **kwargs):
+        _lib.require_gpu()
+        if output_context or (output_main is False):
+            raise NotImplementedError("only the main-stream output (the configuration the demos use) is implemented")
+        if x_context is None:
+            raise RuntimeError("the IMU-conditioned predictor needs x_context [B,%d,%d]" % (self.cfg.ctx_in_chans, self.cfg.ctx_seq_len))
+        if not x.is_cuda:
+            raise RuntimeError("ConjoinedPaddedVisionTransformer.forward needs CUDA/HIP tensors (no CPU fallback); got %s" % x.device)
+        c, m = self.cfg, self.cfg.main
+        if x.dim() != 5 or x.shape[1] != m.in_chans or x.shape[2] != m.num_frames or tuple(x.shape[-2:]) != tuple(m.img_size):
+            raise RuntimeError("expected x of shape [B,%d,%d,%d,%d], got %s" % (m.in_chans, m.num_frames, m.img_size[0], m.img_size[1], tuple(x.shape)))
+        dev, B, Nt = x.device, x.shape[0], m.num_tokens
+        self.sync_weights(dev)
+        if x.dtype != torch.float32:
+            x = x.float()
+        if x.stride(-1) != 1 or x.stride(-2) != x.shape[-1]:
+            x = x.contiguous()
+        mask = mask.to(device=dev, dtype=torch.bool).reshape(B, -1).contiguous()
+        if mask.shape[1] != Nt:
+            raise RuntimeError("mask has %d tokens per row, model expects %d" % (mask.shape[1], Nt))
+        ctx = x_context.to(device=dev, dtype=torch.float32).reshape(B, c.ctx_in_chans, c.ctx_seq_len).contiguous()
+        if mask_context is None:
+            mask_context = torch.zeros(B, c.ctx_tokens, dtype=torch.bool, device=dev)
+        mc = mask_context.to(device=dev, dtype=torch.bool).reshape(B, c.ctx_tokens).contiguous()
+        vis = (~mask).sum(-1)
+        vis_c = (~mc).sum(-1)
+        vmax, vmin, vcmax, vcmin = int(vis.max()), int(vis.min()), int(vis_c.max()), int(vis_c.min())
+        if vmax - vmin > c.main_max_pad or vcmax - vcmin > c.ctx_max_pad:
+            raise RuntimeError("visible-token counts differ by more than max_padding_tokens (%d / %d)" % (c.main_max_pad, c.ctx_max_pad))
+        if vmax < 1 or vcmax < 1:
+            raise RuntimeError("every stream needs at least one visible token")
+        n_out = Nt + c.main_max_pad - vmax
+        y = torch.empty((B, n_out, m.out_dim), device=dev, dtype=torch.float32)
+        args_ = _lib.CwmConjForwardArgs(
+            x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), int(normalize), mask.data_ptr(), B, vmax, ctx.data_ptr(), mc.data_ptr(),
+            vcmax, y.data_ptr(), _lib.mode_id(self.mode), int(check), _lib.current_stream_handle(dev))
+        with torch.cuda.device(dev):
+            _lib.check(_lib.get_lib().cwm_conj_forward(self._handle, C.byref(args_)))
+        # the reference leaves its padding state set until the wrapper resets it (prediction.py:451-452)
+        pad = torch.arange(c.main_max_pad, device=dev)[None] >= (vmax - vis)[:, None]
+        self.main_stream.padding_mask = pad
+        self.main_stream.full_input_mask = torch.cat([mask, pad], -1)
+        self.main_stream.null_mask = torch.cat([torch.zeros(B, Nt - vmax, dtype=torch.bool, device=dev), pad], -1)
+        return y
+
+    def timing_enable(self, kclass: int, enable: bool = True):
+        _lib.check(_lib.get_lib().cwm_conj_timing_enable(self._handle, kclass, int(enable)))
+
+    def timing_collect(self, kclass: int):
+        st = _lib.CwmKernelStats()
+        _lib.check(_lib.get_lib().cwm_conj_timing_collect(self._handle, kclass, C.byref(st)))
+        return {"launches": st.launches, "total_ms": st.total_ms, "total_flops": st.total_flops}
+
+
+def imu400_base_4x4patch_2frames_1tube(**kwargs):
+    """conjoined_vmae.py:1230-1243"""
+    return ConjoinedPaddedVisionTransformer(CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"], **kwargs)

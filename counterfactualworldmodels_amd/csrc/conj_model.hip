@@ -1,0 +1,398 @@
+// IMU-conditioned conjoined padded predictor behind the C ABI (BASELINE configs[4]).
+// Restates `ConjoinedPaddedVisionTransformer.forward` for `imu400_base_4x4patch_2frames_1tube`
+// (cwm/models/VideoMAE/conjoined_vmae.py:889-1011, 852-887, 1230-1243): two token streams (RGB "main",
+// IMU "context"), null-token padding (:49-165), cross-attention blocks BEFORE encoder blocks 0,3,6,9 and
+// AFTER every decoder block (:543-576, :688-720; cwm/models/transformer.py:253-378, 442-583).
+#include "engine.h"
+
+using namespace cwm;
+
+namespace {
+
+struct CrossW {
+    float *n1_g, *n1_b, *n1s_g, *n1s_b, *n2_g, *n2_b, *n2s_g, *n2s_b;
+    LinearW qk, qk_src, v, v_src, proj, proj_src, mlp_t0, mlp_t2, mlp_s0, mlp_s2;
+};
+
+struct StreamW {
+    int enc_dim = 0, dec_dim = 0, enc_heads = 0, dec_heads = 0, n_tok = 0, max_pad = 0, out_dim = 0, embed_k = 0, embed_kpad = 0;
+    std::vector<BlockW> enc, dec;
+    LinearW embed, e2d, head;
+    float *enc_norm_g = nullptr, *enc_norm_b = nullptr, *dec_norm_g = nullptr, *dec_norm_b = nullptr;
+    float *mask_token = nullptr, *null_enc = nullptr;
+    float *pos_enc_ext = nullptr, *pos_dec_ext = nullptr;  // [n_tok + max_pad][D]; pad rows: 0 (enc) / null_token_dec (dec)
+    // workspace
+    uint8_t* ext_mask = nullptr;
+    int* perm = nullptr;
+    bf16* tokens_in = nullptr;
+    float *x_enc = nullptr, *x_dec = nullptr;
+    StreamBuffers sb;
+};
+
+}  // namespace
+
+struct cwm_conj_model {
+    Engine eng;
+    cwm_conj_config cfg;
+    StreamW main, ctx;
+    std::vector<CrossW> enc_cross, dec_cross;
+    // workspace shared by the cross blocks
+    int ws_batch = 0, ws_vmain = 0, ws_vctx = 0;
+    int* err = nullptr;
+    float *qk = nullptr, *v = nullptr, *qk_src = nullptr, *v_src = nullptr, *scores_t = nullptr;
+    bf16 *ybuf = nullptr, *ysbuf = nullptr;
+};
+
+namespace {
+
+int make_stream(Engine& E, StreamW& S, const std::string& pre, int embed_k, std::vector<int64_t> embed_shape, int depth_e, int depth_d,
+                int mlp_ratio, bool sinusoid_f64) {
+    int rc;
+    S.embed_k = embed_k;
+    S.embed_kpad = round_up(embed_k, 64);
+    if ((rc = E.make_linear(S.embed, S.enc_dim, embed_k, true))) return rc;
+    E.add_matrix_slot(pre + "encoder.patch_embed.proj.weight", &S.embed, embed_shape);
+    E.add_vec_slot(pre + "encoder.patch_embed.proj.bias", S.embed.bias, {S.enc_dim});
+    S.enc.resize(depth_e);
+    S.dec.resize(depth_d);
+    for (int i = 0; i < depth_e; ++i)
+        if ((rc = E.make_block(S.enc[i], pre + "encoder.blocks." + std::to_string(i) + ".", S.enc_dim, mlp_ratio * S.enc_dim))) return rc;
+    if ((rc = E.make_vec(&S.enc_norm_g, S.enc_dim)) || (rc = E.make_vec(&S.enc_norm_b, S.enc_dim))) return rc;
+    E.add_vec_slot(pre + "encoder.norm.weight", S.enc_norm_g, {S.enc_dim});
+    E.add_vec_slot(pre + "encoder.norm.bias", S.enc_norm_b, {S.enc_dim});
+    if ((rc = E.make_linear(S.e2d, S.dec_dim, S.enc_dim, false))) return rc;
+    E.add_matrix_slot(pre + "encoder_to_decoder.weight", &S.e2d, {S.dec_dim, S.enc_dim});
+    for (int i = 0; i < depth_d; ++i)
+        if ((rc = E.make_block(S.dec[i], pre + "decoder.blocks." + std::to_string(i) + ".", S.dec_dim, mlp_ratio * S.dec_dim))) return rc;
+    if ((rc = E.make_vec(&S.dec_norm_g, S.dec_dim)) || (rc = E.make_vec(&S.dec_norm_b, S.dec_dim))) return rc;
+    E.add_vec_slot(pre + "decoder.norm.weight", S.dec_norm_g, {S.dec_dim});
+    E.add_vec_slot(pre + "decoder.norm.bias", S.dec_norm_b, {S.dec_dim});
+    if ((rc = E.make_linear(S.head, S.out_dim, S.dec_dim, true))) return rc;
+    E.add_matrix_slot(pre + "decoder.head.weight", &S.head, {S.out_dim, S.dec_dim});
+    E.add_vec_slot(pre + "decoder.head.bias", S.head.bias, {S.out_dim});
+    if ((rc = E.make_vec(&S.mask_token, S.dec_dim)) || (rc = E.make_vec(&S.null_enc, S.enc_dim))) return rc;
+    E.add_vec_slot(pre + "mask_token", S.mask_token, {1, 1, S.dec_dim});
+    E.add_vec_slot(pre + "null_token_enc", S.null_enc, {1, 1, S.enc_dim});
+    // positional tables with max_pad extra rows; the decoder's pad rows hold null_token_dec (_pad_pos_embed :154-165)
+    if (sinusoid_f64) {
+        if ((rc = E.make_sinusoid(&S.pos_enc_ext, S.n_tok, S.enc_dim, S.max_pad)) || (rc = E.make_sinusoid(&S.pos_dec_ext, S.n_tok, S.dec_dim, S.max_pad)))
+            return rc;
+    } else {
+        if ((rc = E.make_pos_embedding_f32(&S.pos_enc_ext, S.n_tok, S.enc_dim, S.max_pad)) ||
+            (rc = E.make_pos_embedding_f32(&S.pos_dec_ext, S.n_tok, S.dec_dim, S.max_pad)))
+            return rc;
+    }
+    E.add_vec_slot(pre + "null_token_dec", S.pos_dec_ext + (size_t)S.n_tok * S.dec_dim, {1, 1, S.dec_dim}, S.max_pad);
+    return 0;
+}
+
+int make_cross(Engine& E, CrossW& C, const std::string& pre, int ci, int cs, int ratio) {
+    int rc;
+    float** vecs[8] = {&C.n1_g, &C.n1_b, &C.n1s_g, &C.n1s_b, &C.n2_g, &C.n2_b, &C.n2s_g, &C.n2s_b};
+    const int dims[8] = {ci, ci, cs, cs, ci, ci, cs, cs};
+    const char* names[8] = {"norm1_cross.weight", "norm1_cross.bias", "norm1_src_cross.weight", "norm1_src_cross.bias",
+                            "norm2.weight", "norm2.bias", "norm2_src.weight", "norm2_src.bias"};
+    for (int i = 0; i < 8; ++i) {
+        if ((rc = E.make_vec(vecs[i], dims[i]))) return rc;
+        E.add_vec_slot(pre + names[i], *vecs[i], {dims[i]});
+    }
+    const int D = ci;
+    if ((rc = E.make_linear(C.qk, 2 * D, ci, false)) || (rc = E.make_linear(C.qk_src, 2 * D, cs, false)) || (rc = E.make_linear(C.v, D, ci, false)) ||
+        (rc = E.make_linear(C.v_src, D, cs, false)) || (rc = E.make_linear(C.proj, ci, D, true)) || (rc = E.make_linear(C.proj_src, cs, D, true)) ||
+        (rc = E.make_linear(C.mlp_t0, ratio * ci, ci, true)) || (rc = E.make_linear(C.mlp_t2, ci, ratio * ci, true)) ||
+        (rc = E.make_linear(C.mlp_s0, ratio * cs, cs, true)) || (rc = E.make_linear(C.mlp_s2, cs, ratio * cs, true)))
+        return rc;
+    E.add_matrix_slot(pre + "cross_attention.qk.weight", &C.qk, {2 * D, ci});
+    E.add_matrix_slot(pre + "cross_attention.qk_src.weight", &C.qk_src, {2 * D, cs});
+    E.add_matrix_slot(pre + "cross_attention.v.weight", &C.v, {D, ci});
+    E.add_matrix_slot(pre + "cross_attention.v_src.weight", &C.v_src, {D, cs});
+    E.add_matrix_slot(pre + "cross_attention.projection.weight", &C.proj, {ci, D});
+    E.add_vec_slot(pre + "cross_attention.projection.bias", C.proj.bias, {ci});
+    E.add_matrix_slot(pre + "cross_attention.projection_src.weight", &C.proj_src, {cs, D});
+    E.add_vec_slot(pre + "cross_attention.projection_src.bias", C.proj_src.bias, {cs});
+    E.add_matrix_slot(pre + "mlp.trg.layers.0.weight", &C.mlp_t0, {ratio * ci, ci});
+    E.add_vec_slot(pre + "mlp.trg.layers.0.bias", C.mlp_t0.bias, {ratio * ci});
+    E.add_matrix_slot(pre + "mlp.trg.layers.2.weight", &C.mlp_t2, {ci, ratio * ci});
+    E.add_vec_slot(pre + "mlp.trg.layers.2.bias", C.mlp_t2.bias, {ci});
+    E.add_matrix_slot(pre + "mlp.src.layers.0.weight", &C.mlp_s0, {ratio * cs, cs});
+    E.add_vec_slot(pre + "mlp.src.layers.0.bias", C.mlp_s0.bias, {ratio * cs});
+    E.add_matrix_slot(pre + "mlp.src.layers.2.weight", &C.mlp_s2, {cs, ratio * cs});
+    E.add_vec_slot(pre + "mlp.src.layers.2.bias", C.mlp_s2.bias, {cs});
+    return 0;
+}
+
+int stream_workspace(Engine& E, StreamW& S, int B, int vmax, int mlp_ratio, bool small) {
+    const int next = S.n_tok + S.max_pad;
+    const size_t rows_e = (size_t)B * vmax, rows_d = (size_t)B * next;
+    int rc;
+    if ((rc = E.ws(&S.ext_mask, rows_d)) || (rc = E.ws(&S.perm, rows_d)) || (rc = E.ws(&S.tokens_in, 2 * rows_e * S.embed_kpad)) ||
+        (rc = E.ws(&S.x_enc, rows_e * S.enc_dim)) || (rc = E.ws(&S.x_dec, rows_d * S.dec_dim)))
+        return rc;
+    const size_t act = std::max(rows_e * S.enc_dim, rows_d * S.dec_dim);
+    if ((rc = E.ws(&S.sb.hbuf, 2 * act)) || (rc = E.ws(&S.sb.gbuf, 2 * act * mlp_ratio))) return rc;
+    if (small) {
+        if ((rc = E.ws(&S.sb.qkv_f32, 3 * act))) return rc;
+    } else {
+        if ((rc = E.ws(&S.sb.qbuf, 2 * act)) || (rc = E.ws(&S.sb.kbuf, 2 * act))) return rc;
+        const size_t vt = std::max((size_t)B * S.enc_dim * round_up(vmax, 64), (size_t)B * S.dec_dim * round_up(next, 64));
+        if ((rc = E.ws(&S.sb.vtbuf, 2 * vt))) return rc;
+    }
+    return 0;
+}
+
+int ensure_workspace(cwm_conj_model* m, int B, int vmain, int vctx) {
+    if (m->ws_batch > 0 && B <= m->ws_batch && vmain <= m->ws_vmain && vctx <= m->ws_vctx) return 0;
+    Engine& E = m->eng;
+    if (int rc = E.free_workspace()) return rc;
+    const int Bc = std::max(B, m->ws_batch), vm = std::max(vmain, m->ws_vmain), vc = std::max(vctx, m->ws_vctx);
+    int rc;
+    if ((rc = stream_workspace(E, m->main, Bc, vm, m->cfg.main.mlp_ratio, false)) || (rc = stream_workspace(E, m->ctx, Bc, vc, m->cfg.main.mlp_ratio, true)))
+        return rc;
+    const size_t Nmax = (size_t)Bc * (m->main.n_tok + m->main.max_pad), Mmax = (size_t)Bc * (m->ctx.n_tok + m->ctx.max_pad);
+    const size_t Dmax = std::max(m->main.enc_dim, m->main.dec_dim);
+    const int Mtok = m->ctx.n_tok + m->ctx.max_pad;
+    if ((rc = E.ws(&m->err, 4)) || (rc = E.ws(&m->qk, Nmax * 2 * Dmax)) || (rc = E.ws(&m->v, Nmax * Dmax)) || (rc = E.ws(&m->qk_src, Mmax * 2 * Dmax)) ||
+        (rc = E.ws(&m->v_src, Mmax * Dmax)) || (rc = E.ws(&m->scores_t, Nmax * m->cfg.cross_heads * Mtok)) || (rc = E.ws(&m->ybuf, 2 * Nmax * Dmax)) ||
+        (rc = E.ws(&m->ysbuf, 2 * Mmax * Dmax)))
+        return rc;
+    m->ws_batch = Bc;
+    m->ws_vmain = vm;
+    m->ws_vctx = vc;
+    return 0;
+}
+
+int layernorm_to(Engine& E, const float* x, int rows, int D, const float* g, const float* b, bf16* out, int planes, hipStream_t s) {
+    LayerNormParams ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = x; ln.ldx = D; ln.gamma = g; ln.beta = b; ln.eps = E.ln_eps; ln.D = D; ln.rows = rows;
+    ln.out = out; ln.out_plane = (int64_t)rows * D; ln.ldo = D;
+    return launch_layernorm(ln, planes, s);
+}
+
+int linear_f32(Engine& E, const bf16* A, int rows, int K, const LinearW& L, float* C, const float* resid, int planes, hipStream_t s) {
+    GemmParams g = gemm_base(A, (int64_t)rows * K, K, L, rows);
+    g.epi = EPI_F32; g.C = C; g.ldc = L.N; g.resid = resid; g.ldr = L.N;
+    return E.run_gemm(g, planes, s);
+}
+
+int linear_gelu(Engine& E, const bf16* A, int rows, int K, const LinearW& L, bf16* out, int planes, hipStream_t s) {
+    GemmParams g = gemm_base(A, (int64_t)rows * K, K, L, rows);
+    g.epi = EPI_BF16_GELU; g.out_hi = out; g.out_plane = (int64_t)rows * L.N; g.ldo = L.N;
+    return E.run_gemm(g, planes, s);
+}
+
+// CrossAttentionTransformerBlock.forward (transformer.py:559-583) with with_self_attention=False
+int run_cross(cwm_conj_model* m, const CrossW& C, float* x, int N, int ci, float* src, int M, int cs, int B, int planes, hipStream_t s) {
+    Engine& E = m->eng;
+    const int D = ci, heads = m->cfg.cross_heads, hd = D / heads;
+    const int rows = B * N, rows_s = B * M;
+    int rc;
+    if ((rc = layernorm_to(E, x, rows, ci, C.n1_g, C.n1_b, m->main.sb.hbuf, planes, s))) return rc;
+    if ((rc = layernorm_to(E, src, rows_s, cs, C.n1s_g, C.n1s_b, m->ctx.sb.hbuf, planes, s))) return rc;
+    if ((rc = linear_f32(E, m->main.sb.hbuf, rows, ci, C.qk, m->qk, nullptr, planes, s))) return rc;
+    if ((rc = linear_f32(E, m->main.sb.hbuf, rows, ci, C.v, m->v, nullptr, planes, s))) return rc;
+    if ((rc = linear_f32(E, m->ctx.sb.hbuf, rows_s, cs, C.qk_src, m->qk_src, nullptr, planes, s))) return rc;
+    if ((rc = linear_f32(E, m->ctx.sb.hbuf, rows_s, cs, C.v_src, m->v_src, nullptr, planes, s))) return rc;
+    CrossAttnParams ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.qk = m->qk; ca.v = m->v; ca.qk_src = m->qk_src; ca.v_src = m->v_src; ca.B = B; ca.N = N; ca.M = M; ca.heads = heads; ca.head_dim = hd;
+    ca.scale = 1.0f / sqrtf((float)hd);
+    ca.y = m->ybuf; ca.y_plane = (int64_t)rows * D; ca.y_src = m->ysbuf; ca.y_src_plane = (int64_t)rows_s * D; ca.scores_t = m->scores_t;
+    if ((rc = launch_cross_attention(ca, planes, s))) return rc;
+    if ((rc = linear_f32(E, m->ybuf, rows, D, C.proj, x, x, planes, s))) return rc;          // x += proj(y) + b
+    if ((rc = linear_f32(E, m->ysbuf, rows_s, D, C.proj_src, src, src, planes, s))) return rc;
+    if ((rc = layernorm_to(E, x, rows, ci, C.n2_g, C.n2_b, m->main.sb.hbuf, planes, s))) return rc;
+    if ((rc = linear_gelu(E, m->main.sb.hbuf, rows, ci, C.mlp_t0, m->main.sb.gbuf, planes, s))) return rc;
+    if ((rc = linear_f32(E, m->main.sb.gbuf, rows, C.mlp_t0.N, C.mlp_t2, x, x, planes, s))) return rc;
+    if ((rc = layernorm_to(E, src, rows_s, cs, C.n2s_g, C.n2s_b, m->ctx.sb.hbuf, planes, s))) return rc;
+    if ((rc = linear_gelu(E, m->ctx.sb.hbuf, rows_s, cs, C.mlp_s0, m->ctx.sb.gbuf, planes, s))) return rc;
+    return linear_f32(E, m->ctx.sb.gbuf, rows_s, C.mlp_s0.N, C.mlp_s2, src, src, planes, s);
+}
+
+// tokens + pos | null tokens, gathered by the padded mask (pad_and_mask_input, conjoined_vmae.py:125-134)
+int embed_stream(cwm_conj_model* m, StreamW& S, int B, int vmax, int planes, hipStream_t s) {
+    Engine& E = m->eng;
+    const int next = S.n_tok + S.max_pad;
+    GemmParams g = gemm_base(S.tokens_in, (int64_t)B * vmax * S.embed_kpad, S.embed_kpad, S.embed, B * vmax);
+    g.epi = EPI_F32; g.C = S.x_enc; g.ldc = S.enc_dim;
+    g.resid = S.pos_enc_ext; g.ldr = S.enc_dim; g.resid_rowmap = S.perm; g.rows_in = vmax; g.rows_out = vmax; g.map_stride = next;
+    if (int rc = E.run_gemm(g, planes, s)) return rc;
+    return launch_fix_pad_rows(S.x_enc, S.perm, B, next, vmax, S.n_tok, S.enc_dim, S.null_enc, s);
+}
+
+// encoder.norm, encoder_to_decoder, [x_vis + pos_ext[vis] | mask_token + pos_ext[masked]]
+int to_decoder(cwm_conj_model* m, StreamW& S, int B, int vmax, int planes, hipStream_t s) {
+    Engine& E = m->eng;
+    const int next = S.n_tok + S.max_pad;
+    int rc;
+    if ((rc = layernorm_to(E, S.x_enc, B * vmax, S.enc_dim, S.enc_norm_g, S.enc_norm_b, S.sb.hbuf, planes, s))) return rc;
+    GemmParams g = gemm_base(S.sb.hbuf, (int64_t)B * vmax * S.enc_dim, S.enc_dim, S.e2d, B * vmax);
+    g.epi = EPI_F32; g.C = S.x_dec; g.ldc = S.dec_dim;
+    g.resid = S.pos_dec_ext; g.ldr = S.dec_dim; g.resid_rowmap = S.perm; g.rows_in = vmax; g.rows_out = next; g.map_stride = next;
+    if ((rc = E.run_gemm(g, planes, s))) return rc;
+    return launch_fill_mask_tokens(S.x_dec, S.mask_token, S.pos_dec_ext, S.perm, B, next, vmax, S.dec_dim, s);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int cwm_conj_create(const cwm_conj_config* cfg, cwm_conj_model** out) {
+    CWM_REQUIRE(cfg && out, "cwm_conj_create: null argument");
+    const cwm_conj_config& c = *cfg;
+    const cwm_config& mc = c.main;
+    CWM_REQUIRE(mc.patch > 0 && mc.patch % 4 == 0 && mc.img_h % mc.patch == 0 && mc.img_w % mc.patch == 0 && mc.img_w % 4 == 0, "bad image/patch size");
+    CWM_REQUIRE(mc.enc_dim == 64 * mc.enc_heads && mc.dec_dim == 64 * mc.dec_heads, "main stream needs head_dim 64");
+    CWM_REQUIRE(mc.enc_dim % 128 == 0 && mc.dec_dim % 128 == 0 && mc.enc_dim <= 1024, "main stream widths must be multiples of 128");
+    CWM_REQUIRE(c.ctx_seq_len % c.ctx_tubelet == 0 && c.ctx_seq_len / c.ctx_tubelet + c.ctx_max_pad <= 64, "context stream: at most 64 tokens incl. padding");
+    CWM_REQUIRE(c.ctx_enc_dim % c.ctx_enc_heads == 0 && c.ctx_dec_dim % c.ctx_dec_heads == 0 && c.ctx_enc_dim / c.ctx_enc_heads <= 64 &&
+                    c.ctx_dec_dim / c.ctx_dec_heads <= 64, "context stream head_dim must be <= 64");
+    CWM_REQUIRE(c.ctx_enc_dim % 16 == 0 && c.ctx_dec_dim % 16 == 0 && c.ctx_enc_dim <= 1024, "context widths must be multiples of 16");
+    CWM_REQUIRE(c.cross_heads > 0 && mc.enc_dim / c.cross_heads <= 192 && mc.enc_dim % c.cross_heads == 0 && mc.dec_dim % c.cross_heads == 0, "cross attention head_dim must be <= 192");
+    CWM_REQUIRE(c.n_enc_cross >= 0 && c.n_enc_cross <= 16 && c.n_dec_cross >= 0 && c.n_dec_cross <= 16, "too many conjoining blocks");
+    cwm_conj_model* m = new cwm_conj_model();
+    m->cfg = c;
+    Engine& E = m->eng;
+    E.ln_eps = mc.ln_eps;
+    CWM_HIP_CHECK(hipGetDevice(&E.device));
+    StreamW& A = m->main;
+    A.enc_dim = mc.enc_dim; A.dec_dim = mc.dec_dim; A.enc_heads = mc.enc_heads; A.dec_heads = mc.dec_heads;
+    A.n_tok = (mc.img_h / mc.patch) * (mc.img_w / mc.patch) * mc.num_frames; A.max_pad = c.main_max_pad; A.out_dim = mc.in_chans * mc.patch * mc.patch;
+    StreamW& S = m->ctx;
+    S.enc_dim = c.ctx_enc_dim; S.dec_dim = c.ctx_dec_dim; S.enc_heads = c.ctx_enc_heads; S.dec_heads = c.ctx_dec_heads;
+    S.n_tok = c.ctx_seq_len / c.ctx_tubelet; S.max_pad = c.ctx_max_pad; S.out_dim = c.ctx_in_chans * c.ctx_tubelet;
+    int rc = 0;
+    do {
+        if ((rc = make_stream(E, A, "main_stream.", mc.in_chans * mc.patch * mc.patch, {mc.enc_dim, mc.in_chans, 1, mc.patch, mc.patch}, mc.enc_depth,
+                              mc.dec_depth, mc.mlp_ratio, true)))
+            break;
+        if ((rc = make_stream(E, S, "context_stream.", c.ctx_in_chans * c.ctx_tubelet, {c.ctx_enc_dim, c.ctx_in_chans, c.ctx_tubelet, 1, 1}, mc.enc_depth,
+                              mc.dec_depth, mc.mlp_ratio, false)))
+            break;
+        // loaded from the checkpoints but never used on this path (vmae.py:368-369)
+        E.add_ignored_slot("context_stream.pos_embed_encoder.weight", {c.ctx_dec_dim, 2 * c.ctx_dec_dim});
+        E.add_ignored_slot("context_stream.pos_embed_encoder.bias", {c.ctx_dec_dim});
+        m->enc_cross.resize(c.n_enc_cross);
+        m->dec_cross.resize(c.n_dec_cross);
+        for (int i = 0; i < c.n_enc_cross && !rc; ++i) {
+            const std::string k = std::to_string(c.enc_cross[i]);
+            rc = make_cross(E, m->enc_cross[i], "encoder_conjoining_blocks." + k + "-" + k + ".", mc.enc_dim, c.ctx_enc_dim, c.cross_mlp_ratio);
+        }
+        for (int i = 0; i < c.n_dec_cross && !rc; ++i) {
+            const std::string k = std::to_string(c.dec_cross[i]);
+            rc = make_cross(E, m->dec_cross[i], "decoder_conjoining_blocks." + k + "-" + k + ".", mc.dec_dim, c.ctx_dec_dim, c.cross_mlp_ratio);
+        }
+    } while (0);
+    if (rc) {
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return CWM_OK;
+}
+
+extern "C" void cwm_conj_destroy(cwm_conj_model* m) { delete m; }
+
+extern "C" int cwm_conj_load_weight(cwm_conj_model* m, const char* key, const float* data, int on_device, const int64_t* shape, int ndim) {
+    CWM_REQUIRE(m, "cwm_conj_load_weight: null model");
+    return m->eng.load_weight(key, data, on_device, shape, ndim);
+}
+
+extern "C" int cwm_conj_missing_weights(cwm_conj_model* m, char* buf, int buflen) { return m->eng.missing_weights(buf, buflen); }
+
+extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* a) {
+    CWM_REQUIRE(m && a, "cwm_conj_forward: null argument");
+    CWM_REQUIRE(a->x_dev && a->mask_dev && a->ctx_dev && a->ctx_mask_dev && a->y_tokens_dev, "cwm_conj_forward: x, mask, context, context mask and y are required");
+    CWM_REQUIRE(a->mode == CWM_MODE_FAST || a->mode == CWM_MODE_PARITY, "cwm_conj_forward: bad mode %d", a->mode);
+    const cwm_conj_config& c = m->cfg;
+    const cwm_config& mc = c.main;
+    StreamW& A = m->main;
+    StreamW& S = m->ctx;
+    const int B = a->batch, vm = a->n_vis_max, vc = a->n_vis_ctx_max;
+    const int Nx = A.n_tok + A.max_pad, Mx = S.n_tok + S.max_pad;
+    CWM_REQUIRE(B > 0 && vm > 0 && vm < Nx && vc > 0 && vc <= S.n_tok, "cwm_conj_forward: bad batch / visible counts (%d, %d, %d)", B, vm, vc);
+    {
+        char miss[256];
+        const int nmiss = m->eng.missing_weights(miss, sizeof(miss));
+        CWM_REQUIRE(nmiss == 0, "cwm_conj_forward: %d state-dict tensors not loaded (first: %s)", nmiss, miss);
+    }
+    if (int rc = ensure_workspace(m, B, vm, vc)) return rc;
+    Engine& E = m->eng;
+    hipStream_t s = (hipStream_t)a->stream;
+    const int planes = a->mode == CWM_MODE_PARITY ? 2 : 1;
+    int rc;
+
+    // a13: padded masks -> permutations [visible slots ascending | masked slots ascending] over n_tok + max_pad slots
+    CWM_HIP_CHECK(hipMemsetAsync(m->err, 0, sizeof(int), s));
+    if ((rc = launch_pad_mask(a->mask_dev, B, A.n_tok, A.max_pad, vm, A.ext_mask, s))) return rc;
+    if ((rc = launch_mask_to_perm(A.ext_mask, B, Nx, vm, A.perm, m->err, s))) return rc;
+    if ((rc = launch_pad_mask(a->ctx_mask_dev, B, S.n_tok, S.max_pad, vc, S.ext_mask, s))) return rc;
+    if ((rc = launch_mask_to_perm(S.ext_mask, B, Mx, vc, S.perm, m->err, s))) return rc;
+
+    // a2/a14: tokenise both streams (visible slots only)
+    PatchGatherParams pg;
+    memset(&pg, 0, sizeof(pg));
+    pg.x = a->x_dev; pg.sb = a->x_stride_b; pg.sc = a->x_stride_c; pg.st = a->x_stride_t; pg.normalize = a->normalize;
+    pg.C = mc.in_chans; pg.H = mc.img_h; pg.W = mc.img_w; pg.P = mc.patch; pg.perm = A.perm; pg.Nt = A.n_tok; pg.perm_stride = Nx; pg.n_rows = vm; pg.B = B;
+    pg.out = A.tokens_in; pg.out_plane = (int64_t)B * vm * A.embed_kpad; pg.ld = A.embed_kpad;
+    if ((rc = launch_patch_gather(pg, planes, s))) return rc;
+    if ((rc = embed_stream(m, A, B, vm, planes, s))) return rc;
+    ImuGatherParams ig;
+    memset(&ig, 0, sizeof(ig));
+    ig.imu = a->ctx_dev; ig.B = B; ig.C = c.ctx_in_chans; ig.L = c.ctx_seq_len; ig.tubelet = c.ctx_tubelet; ig.perm = S.perm; ig.perm_stride = Mx;
+    ig.n_rows = vc; ig.n_real = S.n_tok; ig.out = S.tokens_in; ig.out_plane = (int64_t)B * vc * S.embed_kpad; ig.ld = S.embed_kpad;
+    if ((rc = launch_imu_gather(ig, planes, s))) return rc;
+    if ((rc = embed_stream(m, S, B, vc, planes, s))) return rc;
+
+    // encoder: cross block BEFORE the self-attention blocks listed in enc_cross (forward_encoder_blocks :543-576)
+    for (int i = 0; i < mc.enc_depth; ++i) {
+        for (int k = 0; k < c.n_enc_cross; ++k)
+            if (c.enc_cross[k] == i && (rc = run_cross(m, m->enc_cross[k], A.x_enc, vm, A.enc_dim, S.x_enc, vc, S.enc_dim, B, planes, s))) return rc;
+        if ((rc = E.run_block(A.enc[i], A.x_enc, B, vm, A.enc_dim, A.enc_heads, planes, A.sb, s))) return rc;
+        if ((rc = E.run_block_small(S.enc[i], S.x_enc, B, vc, S.enc_dim, S.enc_heads, planes, S.sb, s))) return rc;
+    }
+    if ((rc = to_decoder(m, A, B, vm, planes, s)) || (rc = to_decoder(m, S, B, vc, planes, s))) return rc;
+
+    // decoder: cross block AFTER the blocks listed in dec_cross (forward_decoder_blocks :688-720)
+    for (int i = 0; i < mc.dec_depth; ++i) {
+        if ((rc = E.run_block(A.dec[i], A.x_dec, B, Nx, A.dec_dim, A.dec_heads, planes, A.sb, s))) return rc;
+        if ((rc = E.run_block_small(S.dec[i], S.x_dec, B, Mx, S.dec_dim, S.dec_heads, planes, S.sb, s))) return rc;
+        for (int k = 0; k < c.n_dec_cross; ++k)
+            if (c.dec_cross[k] == i && (rc = run_cross(m, m->dec_cross[k], A.x_dec, Nx, A.dec_dim, S.x_dec, Mx, S.dec_dim, B, planes, s))) return rc;
+    }
+
+    // main output: head(norm(x[:, -n_out:])) * ~null_mask   (conjoined_decode :984-1002)
+    const int n_out = Nx - vm;
+    LayerNormParams ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = A.x_dec; ln.ldx = A.dec_dim; ln.gamma = A.dec_norm_g; ln.beta = A.dec_norm_b; ln.eps = E.ln_eps; ln.D = A.dec_dim;
+    ln.rows = B * n_out; ln.rows_out_per_b = n_out; ln.rows_in_per_b = Nx; ln.in_offset = vm;
+    ln.out = A.sb.hbuf; ln.out_plane = (int64_t)B * n_out * A.dec_dim; ln.ldo = A.dec_dim;
+    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+    GemmParams g = gemm_base(A.sb.hbuf, ln.out_plane, A.dec_dim, A.head, B * n_out);
+    g.epi = EPI_F32; g.C = a->y_tokens_dev; g.ldc = A.out_dim;
+    if ((rc = E.run_gemm(g, planes, s))) return rc;
+    if ((rc = launch_zero_pad_out_rows(a->y_tokens_dev, A.perm, B, Nx, vm, n_out, A.n_tok, A.out_dim, s))) return rc;
+
+    if (a->check) {
+        int herr = 0;
+        CWM_HIP_CHECK(hipMemcpyAsync(&herr, m->err, sizeof(int), hipMemcpyDeviceToHost, s));
+        CWM_HIP_CHECK(hipStreamSynchronize(s));
+        if (herr) {
+            cwm_set_error("n_vis_max / n_vis_ctx_max do not match the masks (a row has more visible tokens, or the padding budget is exceeded)");
+            return CWM_ERR_MASK;
+        }
+    }
+    return CWM_OK;
+}
+
+extern "C" int cwm_conj_timing_enable(cwm_conj_model* m, int kclass, int enable) {
+    CWM_REQUIRE(m, "cwm_conj_timing_enable: null model");
+    return m->eng.timing_enable(kclass, enable);
+}
+
+extern "C" int cwm_conj_timing_collect(cwm_conj_model* m, int kclass, cwm_kernel_stats* out) {
+    CWM_REQUIRE(m, "cwm_conj_timing_collect: null model");
+    return m->eng.timing_collect(kclass, out);
+}

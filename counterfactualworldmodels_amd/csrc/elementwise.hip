@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const PatchGatherPara
     const int rem = (int)(gid - (int64_t)row * per_row);
     const int c = rem / p.P, ph = rem - c * p.P;
     const int b = row / p.n_rows, i = row - b * p.n_rows;
-    const int tau = p.perm[(size_t)b * p.Nt + i];
+    const int tau = p.perm[(size_t)b * (p.perm_stride ? p.perm_stride : p.Nt) + i];
     const int gw = p.W / p.P;
     const int n = (p.H / p.P) * gw;
     const int t = tau / n, hw = tau - t * n;
@@ -168,14 +168,15 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const PatchGatherPara
     const float mean = (c == 0) ? 0.485f : (c == 1) ? 0.456f : 0.406f;
     const float stdv = (c == 0) ? 0.229f : (c == 1) ? 0.224f : 0.225f;
     bf16* dst = p.out + (size_t)row * p.ld + c * p.P * p.P + ph * p.P;
+    const bool pad_slot = tau >= p.Nt;  // null-token pad slot of a padded predictor: no pixels behind it
     for (int pw = 0; pw < p.P; pw += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(src + pw);
+        const float4 v = pad_slot ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(src + pw);
         float f[4] = {v.x, v.y, v.z, v.w};
         bf16x4 hv, lv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float a = f[e];
-            if (p.normalize) a = (a - mean) / stdv;
+            if (p.normalize && !pad_slot) a = (a - mean) / stdv;
             bf16 hi, lo;
             split_bf16(a, hi, lo);
             hv[e] = hi;

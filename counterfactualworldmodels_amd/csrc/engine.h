@@ -1,0 +1,111 @@
+// Shared host-side machinery of the model handles behind the C ABI: packed weights, state-dict slots,
+// activation workspace, timed launches and the transformer Block sequence.  Used by model.hip (plain
+// VMAE predictor) and conj_model.hip (IMU-conditioned conjoined predictor).
+#pragma once
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cwm_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace cwm {
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct LinearW {
+    bf16* w = nullptr;  // [2][Npad][Kpad]
+    int64_t plane = 0;
+    int N = 0, K = 0, Npad = 0, Kpad = 0;
+    float* bias = nullptr;  // [Npad] (zero-filled) or nullptr when the layer has no bias
+};
+
+struct BlockW {
+    float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+    LinearW qkv, proj, fc1, fc2;
+};
+
+enum SlotKind { SLOT_MATRIX, SLOT_VECTOR, SLOT_IGNORED };
+
+struct Slot {
+    SlotKind kind = SLOT_VECTOR;
+    std::vector<int64_t> shape;
+    LinearW* lin = nullptr;  // SLOT_MATRIX
+    float* dst = nullptr;    // SLOT_VECTOR (device)
+    int repeat = 1;          // SLOT_VECTOR: number of consecutive copies written at dst
+    int64_t numel = 0;
+    bool loaded = false;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    double flops;
+};
+
+struct KernelTimer {
+    bool enabled = false;
+    std::vector<EventPair> pool;
+    size_t used = 0;
+    cwm_kernel_stats acc = {0, 0.0, 0.0};
+};
+
+// Activation buffers of one token stream (bf16 planes are [2][rows][width], plane stride set per use).
+struct StreamBuffers {
+    bf16 *hbuf = nullptr, *gbuf = nullptr, *qbuf = nullptr, *kbuf = nullptr, *vtbuf = nullptr;
+    float* qkv_f32 = nullptr;  // only for streams whose head_dim != 64 (small-sequence attention path)
+};
+
+struct Engine {
+    int device = 0;
+    float ln_eps = 1e-6f;
+    std::map<std::string, Slot> slots;
+    std::vector<void*> allocs;     // weights etc., freed on destroy
+    std::vector<void*> ws_allocs;  // workspace, re-allocated when it has to grow
+    KernelTimer timers[CWM_KCLASS_COUNT];
+
+    ~Engine();
+    int alloc(void** p, size_t bytes, bool zero, bool workspace);
+    template <typename T>
+    int ws(T** p, size_t count) {
+        void* v = nullptr;
+        if (int rc = alloc(&v, count * sizeof(T), true, true)) return rc;
+        *p = (T*)v;
+        return 0;
+    }
+    int free_workspace();
+
+    int make_linear(LinearW& L, int N, int K, bool bias);
+    int make_vec(float** v, int n);
+    void add_matrix_slot(const std::string& key, LinearW* L, std::vector<int64_t> shape);
+    void add_vec_slot(const std::string& key, float* dst, std::vector<int64_t> shape, int repeat = 1);
+    void add_ignored_slot(const std::string& key, std::vector<int64_t> shape);
+    int make_block(BlockW& b, const std::string& pre, int D, int hidden);
+    int make_sinusoid(float** dst, int n_pos, int d, int extra_rows = 0);      // VideoMAE/utils.py:251-268 (float64 host)
+    int make_pos_embedding_f32(float** dst, int n_pos, int d, int extra_rows = 0);  // transformer.py:37-52 (float32)
+
+    int load_weight(const char* key, const float* data, int on_device, const int64_t* shape, int ndim);
+    int missing_weights(char* buf, int buflen);
+
+    int run_gemm(const GemmParams& p, int planes, hipStream_t s);
+    int run_attention(const AttnParams& p, int planes, hipStream_t s);
+    // Block.forward (VideoMAE/utils.py:146-153) on a residual stream x[B*n_tok, D] (in place), head_dim 64
+    int run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, StreamBuffers& sb, hipStream_t s);
+    // same for short sequences with any head_dim (fp32 VALU attention): the IMU context stream
+    int run_block_small(const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, StreamBuffers& sb, hipStream_t s);
+
+    int timing_enable(int kclass, int enable);
+    int timing_collect(int kclass, cwm_kernel_stats* out);
+};
+
+GemmParams gemm_base(const bf16* A, int64_t a_plane, int lda, const LinearW& L, int M);
+
+// fp32 [N][K] -> bf16 (hi, lo) planes [Npad][Kpad], zero padded
+int launch_pack_weight(const float* src, int N, int K, bf16* hi, bf16* lo, int Npad, int Kpad, hipStream_t stream);
+
+}  // namespace cwm

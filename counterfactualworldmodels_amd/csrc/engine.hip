@@ -1,0 +1,395 @@
+// Engine: weight packing, state-dict slots, workspace, timed launches, transformer Block sequence.
+#include <stdarg.h>
+
+#include "engine.h"
+
+using namespace cwm;
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (C ABI never throws)
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void cwm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* cwm_last_error(void) { return g_err; }
+extern "C" const char* cwm_version(void) { return "cwm_hip 0.2.0 gfx950"; }
+
+namespace cwm {
+
+__global__ void pack_weight_kernel(const float* src, int N, int K, bf16* hi, bf16* lo, int Npad, int Kpad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Npad * Kpad) return;
+    const int n = (int)(i / Kpad), k = (int)(i - (int64_t)n * Kpad);
+    float v = (n < N && k < K) ? src[(size_t)n * K + k] : 0.f;
+    bf16 h, l;
+    split_bf16(v, h, l);
+    hi[i] = h;
+    lo[i] = l;
+}
+
+int launch_pack_weight(const float* src, int N, int K, bf16* hi, bf16* lo, int Npad, int Kpad, hipStream_t stream) {
+    const int64_t total = (int64_t)Npad * Kpad;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, N, K, hi, lo, Npad, Kpad);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+Engine::~Engine() {
+    (void)hipDeviceSynchronize();
+    for (void* p : allocs) (void)hipFree(p);
+    for (void* p : ws_allocs) (void)hipFree(p);
+    for (auto& t : timers)
+        for (auto& e : t.pool) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+}
+
+int Engine::alloc(void** p, size_t bytes, bool zero, bool workspace) {
+    CWM_HIP_CHECK(hipMalloc(p, bytes ? bytes : 16));
+    (workspace ? ws_allocs : allocs).push_back(*p);
+    if (zero) CWM_HIP_CHECK(hipMemset(*p, 0, bytes ? bytes : 16));
+    return 0;
+}
+
+int Engine::free_workspace() {
+    CWM_HIP_CHECK(hipDeviceSynchronize());
+    for (void* p : ws_allocs) (void)hipFree(p);
+    ws_allocs.clear();
+    return 0;
+}
+
+int Engine::make_linear(LinearW& L, int N, int K, bool bias) {
+    L.N = N;
+    L.K = K;
+    L.Npad = round_up(N, 128);
+    L.Kpad = round_up(K, 64);
+    L.plane = (int64_t)L.Npad * L.Kpad;
+    void* p;
+    if (int rc = alloc(&p, (size_t)2 * L.plane * sizeof(bf16), true, false)) return rc;
+    L.w = (bf16*)p;
+    if (bias) {
+        if (int rc = alloc(&p, (size_t)L.Npad * sizeof(float), true, false)) return rc;
+        L.bias = (float*)p;
+    }
+    return 0;
+}
+
+int Engine::make_vec(float** v, int n) {
+    void* p;
+    if (int rc = alloc(&p, (size_t)n * sizeof(float), true, false)) return rc;
+    *v = (float*)p;
+    return 0;
+}
+
+void Engine::add_matrix_slot(const std::string& key, LinearW* L, std::vector<int64_t> shape) {
+    Slot s;
+    s.kind = SLOT_MATRIX;
+    s.shape = shape;
+    s.lin = L;
+    s.numel = (int64_t)L->N * L->K;
+    slots[key] = s;
+}
+
+void Engine::add_vec_slot(const std::string& key, float* dst, std::vector<int64_t> shape, int repeat) {
+    Slot s;
+    s.kind = SLOT_VECTOR;
+    s.shape = shape;
+    s.dst = dst;
+    s.repeat = repeat;
+    s.numel = 1;
+    for (auto d : shape) s.numel *= d;
+    slots[key] = s;
+}
+
+void Engine::add_ignored_slot(const std::string& key, std::vector<int64_t> shape) {
+    Slot s;
+    s.kind = SLOT_IGNORED;
+    s.shape = shape;
+    s.numel = 1;
+    for (auto d : shape) s.numel *= d;
+    slots[key] = s;
+}
+
+int Engine::make_block(BlockW& b, const std::string& pre, int D, int hidden) {
+    int rc;
+    if ((rc = make_vec(&b.ln1_g, D)) || (rc = make_vec(&b.ln1_b, D)) || (rc = make_vec(&b.ln2_g, D)) || (rc = make_vec(&b.ln2_b, D)))
+        return rc;
+    if ((rc = make_linear(b.qkv, 3 * D, D, true)) || (rc = make_linear(b.proj, D, D, true)) || (rc = make_linear(b.fc1, hidden, D, true)) ||
+        (rc = make_linear(b.fc2, D, hidden, true)))
+        return rc;
+    add_vec_slot(pre + "norm1.weight", b.ln1_g, {D});
+    add_vec_slot(pre + "norm1.bias", b.ln1_b, {D});
+    add_vec_slot(pre + "norm2.weight", b.ln2_g, {D});
+    add_vec_slot(pre + "norm2.bias", b.ln2_b, {D});
+    // qkv bias = [q_bias | 0 | v_bias]  (VideoMAE/utils.py:89-93: there is no k bias)
+    add_vec_slot(pre + "attn.q_bias", b.qkv.bias, {D});
+    add_vec_slot(pre + "attn.v_bias", b.qkv.bias + 2 * D, {D});
+    add_matrix_slot(pre + "attn.qkv.weight", &b.qkv, {3 * D, D});
+    add_matrix_slot(pre + "attn.proj.weight", &b.proj, {D, D});
+    add_vec_slot(pre + "attn.proj.bias", b.proj.bias, {D});
+    add_matrix_slot(pre + "mlp.fc1.weight", &b.fc1, {hidden, D});
+    add_vec_slot(pre + "mlp.fc1.bias", b.fc1.bias, {hidden});
+    add_matrix_slot(pre + "mlp.fc2.weight", &b.fc2, {D, hidden});
+    add_vec_slot(pre + "mlp.fc2.bias", b.fc2.bias, {D});
+    return 0;
+}
+
+// `get_sinusoid_encoding_table` (VideoMAE/utils.py:251-268): float64 on the host, cast to fp32.
+int Engine::make_sinusoid(float** dst, int n_pos, int d, int extra_rows) {
+    std::vector<float> tab((size_t)(n_pos + extra_rows) * d, 0.f);
+    for (int pos = 0; pos < n_pos; ++pos)
+        for (int j = 0; j < d; ++j) {
+            const double ang = (double)pos / pow(10000.0, 2.0 * (double)(j / 2) / (double)d);
+            tab[(size_t)pos * d + j] = (float)((j & 1) ? cos(ang) : sin(ang));
+        }
+    if (int rc = make_vec(dst, (n_pos + extra_rows) * d)) return rc;
+    CWM_HIP_CHECK(hipMemcpy(*dst, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// `pos_embedding` (transformer.py:37-52): the same formula evaluated in float32 (torch ops restated:
+// freqs = powf(10000, 2*trunc(j/2)/d) with the division done in float32, angle = pos / freqs).
+int Engine::make_pos_embedding_f32(float** dst, int n_pos, int d, int extra_rows) {
+    std::vector<float> tab((size_t)(n_pos + extra_rows) * d, 0.f);
+    for (int j = 0; j < d; ++j) {
+        const float e = (2.0f * (float)(j / 2)) / (float)d;
+        const float freq = powf(10000.0f, e);
+        for (int pos = 0; pos < n_pos; ++pos) {
+            const float ang = (float)pos / freq;
+            tab[(size_t)pos * d + j] = (j & 1) ? cosf(ang) : sinf(ang);
+        }
+    }
+    if (int rc = make_vec(dst, (n_pos + extra_rows) * d)) return rc;
+    CWM_HIP_CHECK(hipMemcpy(*dst, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int Engine::load_weight(const char* key, const float* data, int on_device, const int64_t* shape, int ndim) {
+    CWM_REQUIRE(key && data && shape, "load_weight: null argument");
+    auto it = slots.find(key);
+    CWM_REQUIRE(it != slots.end(), "unexpected key in state_dict: %s", key);
+    Slot& s = it->second;
+    bool same = (int)s.shape.size() == ndim;
+    for (int i = 0; same && i < ndim; ++i) same = s.shape[i] == shape[i];
+    CWM_REQUIRE(same, "size mismatch for %s", key);
+    if (s.kind == SLOT_IGNORED) {
+        s.loaded = true;
+        return CWM_OK;
+    }
+    if (s.kind == SLOT_VECTOR) {
+        for (int r = 0; r < s.repeat; ++r)
+            CWM_HIP_CHECK(hipMemcpy(s.dst + (size_t)r * s.numel, data, (size_t)s.numel * sizeof(float),
+                                    on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    } else {
+        LinearW& L = *s.lin;
+        const float* src = data;
+        float* tmp = nullptr;
+        if (!on_device) {
+            CWM_HIP_CHECK(hipMalloc((void**)&tmp, (size_t)s.numel * sizeof(float)));
+            hipError_t e = hipMemcpy(tmp, data, (size_t)s.numel * sizeof(float), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(tmp);
+                cwm_set_error("hipMemcpy failed: %s", hipGetErrorString(e));
+                return CWM_ERR_HIP;
+            }
+            src = tmp;
+        }
+        const int64_t total = (int64_t)L.Npad * L.Kpad;
+        hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, src, L.N, L.K, L.w, L.w + L.plane,
+                           L.Npad, L.Kpad);
+        hipError_t e = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (e != hipSuccess) {
+            cwm_set_error("pack_weight failed: %s", hipGetErrorString(e));
+            return CWM_ERR_HIP;
+        }
+    }
+    s.loaded = true;
+    return CWM_OK;
+}
+
+int Engine::missing_weights(char* buf, int buflen) {
+    int missing = 0;
+    if (buf && buflen > 0) buf[0] = 0;
+    for (auto& kv : slots)
+        if (!kv.second.loaded) {
+            if (!missing && buf && buflen > 0) snprintf(buf, buflen, "%s", kv.first.c_str());
+            ++missing;
+        }
+    return missing;
+}
+
+// ---- timed launches ---------------------------------------------------------------------------
+static int timer_begin(KernelTimer& t, double flops, hipStream_t s, EventPair** out) {
+    *out = nullptr;
+    if (!t.enabled) return 0;
+    if (t.used == t.pool.size()) {
+        EventPair e;
+        CWM_HIP_CHECK(hipEventCreate(&e.a));
+        CWM_HIP_CHECK(hipEventCreate(&e.b));
+        t.pool.push_back(e);
+    }
+    EventPair& e = t.pool[t.used++];
+    e.flops = flops;
+    CWM_HIP_CHECK(hipEventRecord(e.a, s));
+    *out = &e;
+    return 0;
+}
+
+static int timer_end(EventPair* e, hipStream_t s) {
+    if (e) CWM_HIP_CHECK(hipEventRecord(e->b, s));
+    return 0;
+}
+
+int Engine::run_gemm(const GemmParams& p, int planes, hipStream_t s) {
+    EventPair* e;
+    if (int rc = timer_begin(timers[CWM_KCLASS_GEMM], 2.0 * p.M * (double)p.N * p.K, s, &e)) return rc;
+    if (int rc = launch_gemm(p, planes, s)) return rc;
+    return timer_end(e, s);
+}
+
+int Engine::run_attention(const AttnParams& p, int planes, hipStream_t s) {
+    EventPair* e;
+    const double fl = 4.0 * (double)p.n_tok * p.n_tok * 64.0 * p.heads * p.batch;
+    if (int rc = timer_begin(timers[CWM_KCLASS_ATTENTION], fl, s, &e)) return rc;
+    if (int rc = launch_attention(p, planes, s)) return rc;
+    return timer_end(e, s);
+}
+
+int Engine::timing_enable(int kclass, int enable) {
+    CWM_REQUIRE(kclass >= 0 && kclass < CWM_KCLASS_COUNT, "timing_enable: bad kernel class");
+    KernelTimer& t = timers[kclass];
+    t.enabled = enable != 0;
+    while (enable && t.pool.size() < 512) {
+        EventPair e;
+        CWM_HIP_CHECK(hipEventCreate(&e.a));
+        CWM_HIP_CHECK(hipEventCreate(&e.b));
+        e.flops = 0;
+        t.pool.push_back(e);
+    }
+    return CWM_OK;
+}
+
+int Engine::timing_collect(int kclass, cwm_kernel_stats* out) {
+    CWM_REQUIRE(out && kclass >= 0 && kclass < CWM_KCLASS_COUNT, "timing_collect: bad argument");
+    KernelTimer& t = timers[kclass];
+    for (size_t i = 0; i < t.used; ++i) {
+        CWM_HIP_CHECK(hipEventSynchronize(t.pool[i].b));
+        float ms = 0.f;
+        CWM_HIP_CHECK(hipEventElapsedTime(&ms, t.pool[i].a, t.pool[i].b));
+        t.acc.launches += 1;
+        t.acc.total_ms += ms;
+        t.acc.total_flops += t.pool[i].flops;
+    }
+    t.used = 0;
+    *out = t.acc;
+    t.acc = {0, 0.0, 0.0};
+    return CWM_OK;
+}
+
+GemmParams gemm_base(const bf16* A, int64_t a_plane, int lda, const LinearW& L, int M) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A;
+    p.a_plane = a_plane;
+    p.lda = lda;
+    p.W = L.w;
+    p.w_plane = L.plane;
+    p.M = M;
+    p.N = L.N;
+    p.K = L.Kpad;
+    p.bias = L.bias;
+    return p;
+}
+
+// Block.forward (VideoMAE/utils.py:146-153): x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x)))
+int Engine::run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, StreamBuffers& sb, hipStream_t s) {
+    const int M = B * n_tok;
+    const int64_t hplane = (int64_t)M * D;
+    const int hidden = w.fc1.N;
+    const int n_pad = round_up(n_tok, 64);
+    int rc;
+    LayerNormParams ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = x; ln.ldx = D; ln.gamma = w.ln1_g; ln.beta = w.ln1_b; ln.eps = ln_eps; ln.D = D; ln.rows = M;
+    ln.out = sb.hbuf; ln.out_plane = hplane; ln.ldo = D;
+    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+
+    GemmParams g = gemm_base(sb.hbuf, hplane, D, w.qkv, M);
+    g.epi = EPI_QKV;
+    g.rows_in = n_tok; g.rows_out = n_tok; g.map_stride = n_tok;
+    g.q_out = sb.qbuf; g.k_out = sb.kbuf; g.vt_out = sb.vtbuf;
+    g.qk_plane = hplane; g.vt_plane = (int64_t)B * D * n_pad;
+    g.qkv_dim = D; g.heads = H; g.head_dim = D / H; g.n_tok = n_tok; g.n_pad = n_pad;
+    g.q_scale = 1.0f / sqrtf((float)(D / H));
+    if ((rc = run_gemm(g, planes, s))) return rc;
+
+    AttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = sb.qbuf; a.k = sb.kbuf; a.vt = sb.vtbuf; a.qk_plane = hplane; a.vt_plane = (int64_t)B * D * n_pad;
+    a.o = sb.hbuf; a.o_plane = hplane; a.ldo = D; a.n_tok = n_tok; a.n_pad = n_pad; a.heads = H; a.batch = B;
+    if ((rc = run_attention(a, planes, s))) return rc;
+
+    g = gemm_base(sb.hbuf, hplane, D, w.proj, M);
+    g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
+    if ((rc = run_gemm(g, planes, s))) return rc;
+
+    ln.gamma = w.ln2_g; ln.beta = w.ln2_b;
+    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+
+    g = gemm_base(sb.hbuf, hplane, D, w.fc1, M);
+    g.epi = EPI_BF16_GELU; g.out_hi = sb.gbuf; g.out_plane = (int64_t)M * hidden; g.ldo = hidden;
+    if ((rc = run_gemm(g, planes, s))) return rc;
+
+    g = gemm_base(sb.gbuf, (int64_t)M * hidden, hidden, w.fc2, M);
+    g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
+    return run_gemm(g, planes, s);
+}
+
+// The same Block for a short sequence (n_tok <= 64) with any head_dim <= 64: qkv stays fp32 and the
+// attention is the small fp32 VALU kernel (the IMU context stream: 25/50 tokens, head_dim 32).
+int Engine::run_block_small(const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, StreamBuffers& sb, hipStream_t s) {
+    const int M = B * n_tok;
+    const int64_t hplane = (int64_t)M * D;
+    const int hidden = w.fc1.N;
+    int rc;
+    LayerNormParams ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = x; ln.ldx = D; ln.gamma = w.ln1_g; ln.beta = w.ln1_b; ln.eps = ln_eps; ln.D = D; ln.rows = M;
+    ln.out = sb.hbuf; ln.out_plane = hplane; ln.ldo = D;
+    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+
+    GemmParams g = gemm_base(sb.hbuf, hplane, D, w.qkv, M);
+    g.epi = EPI_F32; g.C = sb.qkv_f32; g.ldc = 3 * D;
+    if ((rc = run_gemm(g, planes, s))) return rc;
+
+    SmallAttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.qkv = sb.qkv_f32; a.B = B; a.n_tok = n_tok; a.heads = H; a.head_dim = D / H;
+    a.o = sb.hbuf; a.o_plane = hplane; a.ldo = D;
+    if ((rc = launch_small_attention(a, planes, s))) return rc;
+
+    g = gemm_base(sb.hbuf, hplane, D, w.proj, M);
+    g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
+    if ((rc = run_gemm(g, planes, s))) return rc;
+
+    ln.gamma = w.ln2_g; ln.beta = w.ln2_b;
+    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+
+    g = gemm_base(sb.hbuf, hplane, D, w.fc1, M);
+    g.epi = EPI_BF16_GELU; g.out_hi = sb.gbuf; g.out_plane = (int64_t)M * hidden; g.ldo = hidden;
+    if ((rc = run_gemm(g, planes, s))) return rc;
+
+    g = gemm_base(sb.gbuf, (int64_t)M * hidden, hidden, w.fc2, M);
+    g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
+    return run_gemm(g, planes, s);
+}
+
+}  // namespace cwm

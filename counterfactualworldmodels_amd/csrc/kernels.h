@@ -87,8 +87,9 @@ struct PatchGatherParams {
     int64_t sb, sc, st;
     int normalize;   // apply (x - mean_c)/std_c in-kernel (prediction.py:309-310)
     int C, H, W, P;
-    const int* perm; // [B][Nt]
-    int Nt, n_rows;  // rows per sample to gather (= n_vis)
+    const int* perm; // [B][perm_stride]
+    int Nt, n_rows;  // real tokens per sample; rows per sample to gather (= n_vis)
+    int perm_stride; // 0 = Nt; padded predictors: Nt + max_padding_tokens (entries >= Nt are pad slots)
     int B;
     bf16* out;       // [planes][B*n_rows][ld]  patch vector order (c, ph, pw), zero-padded to ld
     int64_t out_plane;
@@ -124,6 +125,49 @@ struct ShiftPromptParams {
 };
 
 int launch_shift_prompts(const ShiftPromptParams& p, hipStream_t stream);
+
+// ---- IMU-conditioned conjoined predictor (conj_kernels.hip) ------------------------------------------
+struct SmallAttnParams {
+    const float* qkv;  // [B*n_tok][3*heads*head_dim] fp32 (bias already added; q NOT yet scaled)
+    int B, n_tok, heads, head_dim;
+    bf16* o;           // [planes][B*n_tok][ldo]
+    int64_t o_plane;
+    int ldo;
+};
+int launch_small_attention(const SmallAttnParams& p, int planes, hipStream_t stream);
+
+// ext_mask[b] = [mask[b] | pad slot j masked unless j < vmax - visible(b)]  (conjoined_vmae.py:49-116)
+int launch_pad_mask(const uint8_t* mask, int B, int N, int P, int vmax, uint8_t* ext_mask, hipStream_t stream);
+// rows of x[B*n_rows][D] whose permutation entry is a pad slot (>= n_real) are set to `token` (null_token_enc)
+int launch_fix_pad_rows(float* x, const int* perm, int B, int perm_stride, int n_rows, int n_real, int D, const float* token, hipStream_t stream);
+// rows j of y[B][n_out][D] whose slot perm[b][n_vis + j] is a pad slot are zeroed (x * ~null_mask, conjoined_vmae.py:998-1002)
+int launch_zero_pad_out_rows(float* y, const int* perm, int B, int perm_stride, int n_vis, int n_out, int n_real, int D, hipStream_t stream);
+
+struct ImuGatherParams {
+    const float* imu;  // [B][C][L]
+    int B, C, L, tubelet;
+    const int* perm;   // [B][perm_stride]
+    int perm_stride, n_rows, n_real;
+    bf16* out;         // [planes][B*n_rows][ld], K order (c, s), zero padded
+    int64_t out_plane;
+    int ld;
+};
+int launch_imu_gather(const ImuGatherParams& p, int planes, hipStream_t stream);
+
+struct CrossAttnParams {
+    const float* qk;      // [B*N][2D] main stream (fp32)
+    const float* v;       // [B*N][D]
+    const float* qk_src;  // [B*M][2D] context stream
+    const float* v_src;   // [B*M][D]
+    int B, N, M, heads, head_dim;  // D = heads*head_dim
+    float scale;
+    bf16* y;              // [planes][B*N][D]  main-stream update (softmax over the M context tokens)
+    int64_t y_plane;
+    bf16* y_src;          // [planes][B*M][D]  context update (softmax over the N main tokens)
+    int64_t y_src_plane;
+    float* scores_t;      // scratch [B][heads][M][N]
+};
+int launch_cross_attention(const CrossAttnParams& p, int planes, hipStream_t stream);
 
 int launch_perm_to_rank(const int* perm, int* rank, int B, int Nt, hipStream_t stream);
 

@@ -3,338 +3,49 @@
 // `PretrainVisionTransformerEncoder.forward_features` (:152-173), `...Decoder.forward` (:246-255) and
 // `Block.forward` (cwm/models/VideoMAE/utils.py:146-153) as a fixed sequence of HIP kernel launches
 // on the caller's stream.
-#include <math.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <string.h>
-
-#include <algorithm>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/cwm_hip.h"
-#include "common.h"
-#include "kernels.h"
+#include "engine.h"
 
 using namespace cwm;
 
-// ---------------------------------------------------------------------------------------------
-// error plumbing
-// ---------------------------------------------------------------------------------------------
-static thread_local char g_err[1024] = "";
-
-void cwm_set_error(const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
-
-extern "C" const char* cwm_last_error(void) { return g_err; }
-extern "C" const char* cwm_version(void) { return "cwm_hip 0.1.0 gfx950"; }
-
-static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-
-// ---------------------------------------------------------------------------------------------
-// weights
-// ---------------------------------------------------------------------------------------------
-namespace {
-
-struct LinearW {
-    bf16* w = nullptr;  // [2][Npad][Kpad]
-    int64_t plane = 0;
-    int N = 0, K = 0, Npad = 0, Kpad = 0;
-    float* bias = nullptr;  // [Npad] (zero-filled) or nullptr when the layer has no bias
-};
-
-struct BlockW {
-    float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
-    LinearW qkv, proj, fc1, fc2;
-};
-
-enum SlotKind { SLOT_MATRIX, SLOT_VECTOR };
-
-struct Slot {
-    SlotKind kind;
-    std::vector<int64_t> shape;
-    LinearW* lin = nullptr;  // SLOT_MATRIX
-    float* dst = nullptr;    // SLOT_VECTOR (device)
-    int64_t numel = 0;
-    bool loaded = false;
-};
-
-struct EventPair {
-    hipEvent_t a, b;
-    double flops;
-};
-
-struct KernelTimer {
-    bool enabled = false;
-    std::vector<EventPair> pool;
-    size_t used = 0;
-    cwm_kernel_stats acc = {0, 0.0, 0.0};
-};
-
-}  // namespace
-
 struct cwm_model {
+    Engine eng;
     cwm_config cfg;
-    int device = 0;
     int Nt = 0, n_per_frame = 0, patch_k = 0, patch_kpad = 0, out_dim = 0;
     std::vector<BlockW> enc, dec;
     LinearW patch, e2d, head;
     float *enc_norm_g = nullptr, *enc_norm_b = nullptr, *dec_norm_g = nullptr, *dec_norm_b = nullptr;
     float* mask_token = nullptr;
     float *pos_enc = nullptr, *pos_dec = nullptr;  // [Nt][De], [Nt][Dd] sinusoid tables
-    std::map<std::string, Slot> slots;
-    std::vector<void*> allocs;  // everything to hipFree on destroy (weights)
     // workspace (grown on demand)
     int ws_batch = 0, ws_nvis = 0;
-    std::vector<void*> ws_allocs;
     int *perm = nullptr, *rank = nullptr, *err = nullptr;
-    bf16 *patches = nullptr, *hbuf = nullptr, *gbuf = nullptr, *qbuf = nullptr, *kbuf = nullptr, *vtbuf = nullptr;
+    bf16* patches = nullptr;
     float *x_enc = nullptr, *x_dec = nullptr;
-    size_t hbuf_plane = 0, gbuf_plane = 0, qk_plane_cap = 0, vt_plane_cap = 0, patches_plane = 0;
-    KernelTimer timers[CWM_KCLASS_COUNT];
+    StreamBuffers sb;
 };
 
 namespace {
 
-__global__ void pack_weight_kernel(const float* src, int N, int K, bf16* hi, bf16* lo, int Npad, int Kpad) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)Npad * Kpad) return;
-    const int n = (int)(i / Kpad), k = (int)(i - (int64_t)n * Kpad);
-    float v = (n < N && k < K) ? src[(size_t)n * K + k] : 0.f;
-    bf16 h, l;
-    split_bf16(v, h, l);
-    hi[i] = h;
-    lo[i] = l;
-}
-
-int dev_alloc(cwm_model* m, void** p, size_t bytes, bool zero, std::vector<void*>& list) {
-    CWM_HIP_CHECK(hipMalloc(p, bytes ? bytes : 16));
-    list.push_back(*p);
-    if (zero) CWM_HIP_CHECK(hipMemset(*p, 0, bytes ? bytes : 16));
-    (void)m;
-    return 0;
-}
-
-int make_linear(cwm_model* m, LinearW& L, int N, int K, bool bias) {
-    L.N = N;
-    L.K = K;
-    L.Npad = round_up(N, 128);
-    L.Kpad = round_up(K, 64);
-    L.plane = (int64_t)L.Npad * L.Kpad;
-    void* p;
-    if (int rc = dev_alloc(m, &p, (size_t)2 * L.plane * sizeof(bf16), true, m->allocs)) return rc;
-    L.w = (bf16*)p;
-    if (bias) {
-        if (int rc = dev_alloc(m, &p, (size_t)L.Npad * sizeof(float), true, m->allocs)) return rc;
-        L.bias = (float*)p;
-    }
-    return 0;
-}
-
-int make_vec(cwm_model* m, float** v, int n) {
-    void* p;
-    if (int rc = dev_alloc(m, &p, (size_t)n * sizeof(float), true, m->allocs)) return rc;
-    *v = (float*)p;
-    return 0;
-}
-
-void add_matrix_slot(cwm_model* m, const std::string& key, LinearW* L, std::vector<int64_t> shape) {
-    Slot s;
-    s.kind = SLOT_MATRIX;
-    s.shape = shape;
-    s.lin = L;
-    s.numel = (int64_t)L->N * L->K;
-    m->slots[key] = s;
-}
-
-void add_vec_slot(cwm_model* m, const std::string& key, float* dst, std::vector<int64_t> shape) {
-    Slot s;
-    s.kind = SLOT_VECTOR;
-    s.shape = shape;
-    s.dst = dst;
-    s.numel = 1;
-    for (auto d : shape) s.numel *= d;
-    m->slots[key] = s;
-}
-
-int make_block(cwm_model* m, BlockW& b, const std::string& pre, int D, int hidden) {
-    int rc;
-    if ((rc = make_vec(m, &b.ln1_g, D)) || (rc = make_vec(m, &b.ln1_b, D)) || (rc = make_vec(m, &b.ln2_g, D)) ||
-        (rc = make_vec(m, &b.ln2_b, D)))
-        return rc;
-    if ((rc = make_linear(m, b.qkv, 3 * D, D, true)) || (rc = make_linear(m, b.proj, D, D, true)) ||
-        (rc = make_linear(m, b.fc1, hidden, D, true)) || (rc = make_linear(m, b.fc2, D, hidden, true)))
-        return rc;
-    add_vec_slot(m, pre + "norm1.weight", b.ln1_g, {D});
-    add_vec_slot(m, pre + "norm1.bias", b.ln1_b, {D});
-    add_vec_slot(m, pre + "norm2.weight", b.ln2_g, {D});
-    add_vec_slot(m, pre + "norm2.bias", b.ln2_b, {D});
-    // qkv bias = [q_bias | 0 | v_bias]  (VideoMAE/utils.py:89-93: there is no k bias)
-    add_vec_slot(m, pre + "attn.q_bias", b.qkv.bias, {D});
-    add_vec_slot(m, pre + "attn.v_bias", b.qkv.bias + 2 * D, {D});
-    add_matrix_slot(m, pre + "attn.qkv.weight", &b.qkv, {3 * D, D});
-    add_matrix_slot(m, pre + "attn.proj.weight", &b.proj, {D, D});
-    add_vec_slot(m, pre + "attn.proj.bias", b.proj.bias, {D});
-    add_matrix_slot(m, pre + "mlp.fc1.weight", &b.fc1, {hidden, D});
-    add_vec_slot(m, pre + "mlp.fc1.bias", b.fc1.bias, {hidden});
-    add_matrix_slot(m, pre + "mlp.fc2.weight", &b.fc2, {D, hidden});
-    add_vec_slot(m, pre + "mlp.fc2.bias", b.fc2.bias, {D});
-    return 0;
-}
-
-// `get_sinusoid_encoding_table` (VideoMAE/utils.py:251-268): float64 on the host, cast to fp32.
-int make_sinusoid(cwm_model* m, float** dst, int n_pos, int d) {
-    std::vector<float> tab((size_t)n_pos * d);
-    for (int pos = 0; pos < n_pos; ++pos)
-        for (int j = 0; j < d; ++j) {
-            const double ang = (double)pos / pow(10000.0, 2.0 * (double)(j / 2) / (double)d);
-            tab[(size_t)pos * d + j] = (float)((j & 1) ? cos(ang) : sin(ang));
-        }
-    if (int rc = make_vec(m, dst, n_pos * d)) return rc;
-    CWM_HIP_CHECK(hipMemcpy(*dst, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
-    return 0;
-}
-
 int ensure_workspace(cwm_model* m, int B, int n_vis) {
     if (B <= m->ws_batch && n_vis <= m->ws_nvis && m->ws_batch > 0) return 0;
-    CWM_HIP_CHECK(hipDeviceSynchronize());
-    for (void* p : m->ws_allocs) (void)hipFree(p);
-    m->ws_allocs.clear();
+    Engine& E = m->eng;
+    if (int rc = E.free_workspace()) return rc;
     const cwm_config& c = m->cfg;
-    const int Bc = B > m->ws_batch ? B : m->ws_batch;
-    const int Nv = n_vis > m->ws_nvis ? n_vis : m->ws_nvis;
-    const int Nt = m->Nt;
+    const int Bc = std::max(B, m->ws_batch), Nv = std::max(n_vis, m->ws_nvis), Nt = m->Nt;
     const size_t rows_e = (size_t)Bc * Nv, rows_d = (size_t)Bc * Nt;
-    void* p;
     int rc;
-#define WS(ptr, type, count)                                                                  \
-    if ((rc = dev_alloc(m, &p, (size_t)(count) * sizeof(type), true, m->ws_allocs))) return rc; \
-    ptr = (type*)p;
-    WS(m->perm, int, rows_d);
-    WS(m->rank, int, rows_d);
-    WS(m->err, int, 4);
-    m->patches_plane = rows_e * m->patch_kpad;
-    WS(m->patches, bf16, 2 * m->patches_plane);
-    WS(m->x_enc, float, rows_e * c.enc_dim);
-    WS(m->x_dec, float, rows_d * c.dec_dim);
+    if ((rc = E.ws(&m->perm, rows_d)) || (rc = E.ws(&m->rank, rows_d)) || (rc = E.ws(&m->err, 4))) return rc;
+    if ((rc = E.ws(&m->patches, 2 * rows_e * m->patch_kpad))) return rc;
+    if ((rc = E.ws(&m->x_enc, rows_e * c.enc_dim)) || (rc = E.ws(&m->x_dec, rows_d * c.dec_dim))) return rc;
     const size_t act = std::max(rows_e * c.enc_dim, rows_d * c.dec_dim);
-    m->hbuf_plane = act;
-    WS(m->hbuf, bf16, 2 * act);
-    m->gbuf_plane = act * c.mlp_ratio;
-    WS(m->gbuf, bf16, 2 * m->gbuf_plane);
-    m->qk_plane_cap = act;
-    WS(m->qbuf, bf16, 2 * act);
-    WS(m->kbuf, bf16, 2 * act);
-    const size_t vt_e = (size_t)Bc * c.enc_dim * round_up(Nv, 64);
-    const size_t vt_d = (size_t)Bc * c.dec_dim * round_up(Nt, 64);
-    m->vt_plane_cap = std::max(vt_e, vt_d);
-    WS(m->vtbuf, bf16, 2 * m->vt_plane_cap);
-#undef WS
+    if ((rc = E.ws(&m->sb.hbuf, 2 * act)) || (rc = E.ws(&m->sb.gbuf, 2 * act * c.mlp_ratio)) || (rc = E.ws(&m->sb.qbuf, 2 * act)) ||
+        (rc = E.ws(&m->sb.kbuf, 2 * act)))
+        return rc;
+    const size_t vt = std::max((size_t)Bc * c.enc_dim * round_up(Nv, 64), (size_t)Bc * c.dec_dim * round_up(Nt, 64));
+    if ((rc = E.ws(&m->sb.vtbuf, 2 * vt))) return rc;
     m->ws_batch = Bc;
     m->ws_nvis = Nv;
     return 0;
-}
-
-// ---- timed launches ---------------------------------------------------------------------------
-int timer_begin(cwm_model* m, int kclass, double flops, hipStream_t s, EventPair** out) {
-    *out = nullptr;
-    KernelTimer& t = m->timers[kclass];
-    if (!t.enabled) return 0;
-    if (t.used == t.pool.size()) {
-        EventPair e;
-        CWM_HIP_CHECK(hipEventCreate(&e.a));
-        CWM_HIP_CHECK(hipEventCreate(&e.b));
-        t.pool.push_back(e);
-    }
-    EventPair& e = t.pool[t.used++];
-    e.flops = flops;
-    CWM_HIP_CHECK(hipEventRecord(e.a, s));
-    *out = &e;
-    return 0;
-}
-
-int timer_end(EventPair* e, hipStream_t s) {
-    if (e) CWM_HIP_CHECK(hipEventRecord(e->b, s));
-    return 0;
-}
-
-int run_gemm(cwm_model* m, const GemmParams& p, int planes, hipStream_t s) {
-    EventPair* e;
-    if (int rc = timer_begin(m, CWM_KCLASS_GEMM, 2.0 * p.M * (double)p.N * p.K, s, &e)) return rc;
-    if (int rc = launch_gemm(p, planes, s)) return rc;
-    return timer_end(e, s);
-}
-
-int run_attention(cwm_model* m, const AttnParams& p, int planes, hipStream_t s) {
-    EventPair* e;
-    const double fl = 4.0 * (double)p.n_tok * p.n_tok * 64.0 * p.heads * p.batch;
-    if (int rc = timer_begin(m, CWM_KCLASS_ATTENTION, fl, s, &e)) return rc;
-    if (int rc = launch_attention(p, planes, s)) return rc;
-    return timer_end(e, s);
-}
-
-GemmParams gemm_base(const bf16* A, int64_t a_plane, int lda, const LinearW& L, int M) {
-    GemmParams p;
-    memset(&p, 0, sizeof(p));
-    p.A = A;
-    p.a_plane = a_plane;
-    p.lda = lda;
-    p.W = L.w;
-    p.w_plane = L.plane;
-    p.M = M;
-    p.N = L.N;
-    p.K = L.Kpad;
-    p.bias = L.bias;
-    return p;
-}
-
-// Block.forward (VideoMAE/utils.py:146-153): x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x)))
-int run_block(cwm_model* m, const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, hipStream_t s) {
-    const int M = B * n_tok;
-    const int64_t hplane = (int64_t)M * D;
-    const int hidden = w.fc1.N;
-    const int n_pad = round_up(n_tok, 64);
-    int rc;
-    LayerNormParams ln;
-    memset(&ln, 0, sizeof(ln));
-    ln.x = x; ln.ldx = D; ln.gamma = w.ln1_g; ln.beta = w.ln1_b; ln.eps = m->cfg.ln_eps; ln.D = D; ln.rows = M;
-    ln.out = m->hbuf; ln.out_plane = hplane; ln.ldo = D;
-    if ((rc = launch_layernorm(ln, planes, s))) return rc;
-
-    GemmParams g = gemm_base(m->hbuf, hplane, D, w.qkv, M);
-    g.epi = EPI_QKV;
-    g.rows_in = n_tok; g.rows_out = n_tok; g.map_stride = n_tok;
-    g.q_out = m->qbuf; g.k_out = m->kbuf; g.vt_out = m->vtbuf;
-    g.qk_plane = hplane; g.vt_plane = (int64_t)B * D * n_pad;
-    g.qkv_dim = D; g.heads = H; g.head_dim = D / H; g.n_tok = n_tok; g.n_pad = n_pad;
-    g.q_scale = 1.0f / sqrtf((float)(D / H));
-    if ((rc = run_gemm(m, g, planes, s))) return rc;
-
-    AttnParams a;
-    memset(&a, 0, sizeof(a));
-    a.q = m->qbuf; a.k = m->kbuf; a.vt = m->vtbuf; a.qk_plane = hplane; a.vt_plane = (int64_t)B * D * n_pad;
-    a.o = m->hbuf; a.o_plane = hplane; a.ldo = D; a.n_tok = n_tok; a.n_pad = n_pad; a.heads = H; a.batch = B;
-    if ((rc = run_attention(m, a, planes, s))) return rc;
-
-    g = gemm_base(m->hbuf, hplane, D, w.proj, M);
-    g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
-    if ((rc = run_gemm(m, g, planes, s))) return rc;
-
-    ln.gamma = w.ln2_g; ln.beta = w.ln2_b;
-    if ((rc = launch_layernorm(ln, planes, s))) return rc;
-
-    g = gemm_base(m->hbuf, hplane, D, w.fc1, M);
-    g.epi = EPI_BF16_GELU; g.out_hi = m->gbuf; g.out_plane = (int64_t)M * hidden; g.ldo = hidden;
-    if ((rc = run_gemm(m, g, planes, s))) return rc;
-
-    g = gemm_base(m->gbuf, (int64_t)M * hidden, hidden, w.fc2, M);
-    g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
-    return run_gemm(m, g, planes, s);
 }
 
 }  // namespace
@@ -354,7 +65,9 @@ extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
     CWM_REQUIRE(c.in_chans == 3 && c.num_frames >= 1 && c.mlp_ratio >= 1 && c.enc_depth >= 1 && c.dec_depth >= 1, "unsupported config");
     cwm_model* m = new cwm_model();
     m->cfg = c;
-    CWM_HIP_CHECK(hipGetDevice(&m->device));
+    Engine& E = m->eng;
+    E.ln_eps = c.ln_eps;
+    CWM_HIP_CHECK(hipGetDevice(&E.device));
     m->n_per_frame = (c.img_h / c.patch) * (c.img_w / c.patch);
     m->Nt = m->n_per_frame * c.num_frames;
     m->patch_k = c.in_chans * c.patch * c.patch;
@@ -364,30 +77,30 @@ extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
     m->enc.resize(c.enc_depth);
     m->dec.resize(c.dec_depth);
     do {
-        if ((rc = make_linear(m, m->patch, c.enc_dim, m->patch_k, true))) break;
-        add_matrix_slot(m, "encoder.patch_embed.proj.weight", &m->patch, {c.enc_dim, c.in_chans, 1, c.patch, c.patch});
-        add_vec_slot(m, "encoder.patch_embed.proj.bias", m->patch.bias, {c.enc_dim});
+        if ((rc = E.make_linear(m->patch, c.enc_dim, m->patch_k, true))) break;
+        E.add_matrix_slot("encoder.patch_embed.proj.weight", &m->patch, {c.enc_dim, c.in_chans, 1, c.patch, c.patch});
+        E.add_vec_slot("encoder.patch_embed.proj.bias", m->patch.bias, {c.enc_dim});
         for (int i = 0; i < c.enc_depth && !rc; ++i)
-            rc = make_block(m, m->enc[i], "encoder.blocks." + std::to_string(i) + ".", c.enc_dim, c.mlp_ratio * c.enc_dim);
+            rc = E.make_block(m->enc[i], "encoder.blocks." + std::to_string(i) + ".", c.enc_dim, c.mlp_ratio * c.enc_dim);
         if (rc) break;
-        if ((rc = make_vec(m, &m->enc_norm_g, c.enc_dim)) || (rc = make_vec(m, &m->enc_norm_b, c.enc_dim))) break;
-        add_vec_slot(m, "encoder.norm.weight", m->enc_norm_g, {c.enc_dim});
-        add_vec_slot(m, "encoder.norm.bias", m->enc_norm_b, {c.enc_dim});
-        if ((rc = make_linear(m, m->e2d, c.dec_dim, c.enc_dim, false))) break;
-        add_matrix_slot(m, "encoder_to_decoder.weight", &m->e2d, {c.dec_dim, c.enc_dim});
-        if ((rc = make_vec(m, &m->mask_token, c.dec_dim))) break;
-        add_vec_slot(m, "mask_token", m->mask_token, {1, 1, c.dec_dim});
+        if ((rc = E.make_vec(&m->enc_norm_g, c.enc_dim)) || (rc = E.make_vec(&m->enc_norm_b, c.enc_dim))) break;
+        E.add_vec_slot("encoder.norm.weight", m->enc_norm_g, {c.enc_dim});
+        E.add_vec_slot("encoder.norm.bias", m->enc_norm_b, {c.enc_dim});
+        if ((rc = E.make_linear(m->e2d, c.dec_dim, c.enc_dim, false))) break;
+        E.add_matrix_slot("encoder_to_decoder.weight", &m->e2d, {c.dec_dim, c.enc_dim});
+        if ((rc = E.make_vec(&m->mask_token, c.dec_dim))) break;
+        E.add_vec_slot("mask_token", m->mask_token, {1, 1, c.dec_dim});
         for (int i = 0; i < c.dec_depth && !rc; ++i)
-            rc = make_block(m, m->dec[i], "decoder.blocks." + std::to_string(i) + ".", c.dec_dim, c.mlp_ratio * c.dec_dim);
+            rc = E.make_block(m->dec[i], "decoder.blocks." + std::to_string(i) + ".", c.dec_dim, c.mlp_ratio * c.dec_dim);
         if (rc) break;
-        if ((rc = make_vec(m, &m->dec_norm_g, c.dec_dim)) || (rc = make_vec(m, &m->dec_norm_b, c.dec_dim))) break;
-        add_vec_slot(m, "decoder.norm.weight", m->dec_norm_g, {c.dec_dim});
-        add_vec_slot(m, "decoder.norm.bias", m->dec_norm_b, {c.dec_dim});
-        if ((rc = make_linear(m, m->head, m->out_dim, c.dec_dim, true))) break;
-        add_matrix_slot(m, "decoder.head.weight", &m->head, {m->out_dim, c.dec_dim});
-        add_vec_slot(m, "decoder.head.bias", m->head.bias, {m->out_dim});
-        if ((rc = make_sinusoid(m, &m->pos_enc, m->Nt, c.enc_dim))) break;  // vmae.py:75
-        if ((rc = make_sinusoid(m, &m->pos_dec, m->Nt, c.dec_dim))) break;  // vmae.py:366
+        if ((rc = E.make_vec(&m->dec_norm_g, c.dec_dim)) || (rc = E.make_vec(&m->dec_norm_b, c.dec_dim))) break;
+        E.add_vec_slot("decoder.norm.weight", m->dec_norm_g, {c.dec_dim});
+        E.add_vec_slot("decoder.norm.bias", m->dec_norm_b, {c.dec_dim});
+        if ((rc = E.make_linear(m->head, m->out_dim, c.dec_dim, true))) break;
+        E.add_matrix_slot("decoder.head.weight", &m->head, {m->out_dim, c.dec_dim});
+        E.add_vec_slot("decoder.head.bias", m->head.bias, {m->out_dim});
+        if ((rc = E.make_sinusoid(&m->pos_enc, m->Nt, c.enc_dim))) break;  // vmae.py:75
+        if ((rc = E.make_sinusoid(&m->pos_dec, m->Nt, c.dec_dim))) break;  // vmae.py:366
     } while (0);
     if (rc) {
         cwm_model_destroy(m);
@@ -397,67 +110,14 @@ extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
     return CWM_OK;
 }
 
-extern "C" void cwm_model_destroy(cwm_model* m) {
-    if (!m) return;
-    (void)hipDeviceSynchronize();
-    for (void* p : m->allocs) (void)hipFree(p);
-    for (void* p : m->ws_allocs) (void)hipFree(p);
-    for (auto& t : m->timers)
-        for (auto& e : t.pool) {
-            (void)hipEventDestroy(e.a);
-            (void)hipEventDestroy(e.b);
-        }
-    delete m;
-}
+extern "C" void cwm_model_destroy(cwm_model* m) { delete m; }
 
 extern "C" int cwm_model_load_weight(cwm_model* m, const char* key, const float* data, int on_device, const int64_t* shape, int ndim) {
-    CWM_REQUIRE(m && key && data && shape, "cwm_model_load_weight: null argument");
-    auto it = m->slots.find(key);
-    CWM_REQUIRE(it != m->slots.end(), "unexpected key in state_dict: %s", key);
-    Slot& s = it->second;
-    bool same = (int)s.shape.size() == ndim;
-    for (int i = 0; same && i < ndim; ++i) same = s.shape[i] == shape[i];
-    CWM_REQUIRE(same, "size mismatch for %s", key);
-    if (s.kind == SLOT_VECTOR) {
-        CWM_HIP_CHECK(hipMemcpy(s.dst, data, (size_t)s.numel * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    } else {
-        LinearW& L = *s.lin;
-        const float* src = data;
-        float* tmp = nullptr;
-        if (!on_device) {
-            CWM_HIP_CHECK(hipMalloc((void**)&tmp, (size_t)s.numel * sizeof(float)));
-            hipError_t e = hipMemcpy(tmp, data, (size_t)s.numel * sizeof(float), hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                (void)hipFree(tmp);
-                cwm_set_error("hipMemcpy failed: %s", hipGetErrorString(e));
-                return CWM_ERR_HIP;
-            }
-            src = tmp;
-        }
-        const int64_t total = (int64_t)L.Npad * L.Kpad;
-        hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, src, L.N, L.K, L.w,
-                           L.w + L.plane, L.Npad, L.Kpad);
-        hipError_t e = hipDeviceSynchronize();
-        if (tmp) (void)hipFree(tmp);
-        if (e != hipSuccess) {
-            cwm_set_error("pack_weight failed: %s", hipGetErrorString(e));
-            return CWM_ERR_HIP;
-        }
-    }
-    s.loaded = true;
-    return CWM_OK;
+    CWM_REQUIRE(m, "cwm_model_load_weight: null model");
+    return m->eng.load_weight(key, data, on_device, shape, ndim);
 }
 
-extern "C" int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen) {
-    int missing = 0;
-    if (buf && buflen > 0) buf[0] = 0;
-    for (auto& kv : m->slots)
-        if (!kv.second.loaded) {
-            if (!missing && buf && buflen > 0) snprintf(buf, buflen, "%s", kv.first.c_str());
-            ++missing;
-        }
-    return missing;
-}
+extern "C" int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen) { return m->eng.missing_weights(buf, buflen); }
 
 extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     CWM_REQUIRE(m && a, "cwm_forward: null argument");
@@ -469,10 +129,11 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     CWM_REQUIRE(Nv > 0 && Nm > 0, "cwm_forward: need 0 < n_vis (%d) < num tokens (%d)", Nv, Nt);
     {
         char miss[256];
-        const int nmiss = cwm_model_missing_weights(m, miss, sizeof(miss));
+        const int nmiss = m->eng.missing_weights(miss, sizeof(miss));
         CWM_REQUIRE(nmiss == 0, "cwm_forward: %d state-dict tensors not loaded (first: %s)", nmiss, miss);
     }
     if (int rc = ensure_workspace(m, B, Nv)) return rc;
+    Engine& E = m->eng;
     hipStream_t s = (hipStream_t)a->stream;
     const int planes = a->mode == CWM_MODE_PARITY ? 2 : 1;
     int rc;
@@ -492,35 +153,35 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     GemmParams g = gemm_base(m->patches, pg.out_plane, m->patch_kpad, m->patch, B * Nv);
     g.epi = EPI_F32; g.C = m->x_enc; g.ldc = c.enc_dim;
     g.resid = m->pos_enc; g.ldr = c.enc_dim; g.resid_rowmap = m->perm; g.rows_in = Nv; g.rows_out = Nv; g.map_stride = Nt;
-    if ((rc = run_gemm(m, g, planes, s))) return rc;
+    if ((rc = E.run_gemm(g, planes, s))) return rc;
 
     // a4-a6: encoder blocks over the visible tokens
     for (int i = 0; i < c.enc_depth; ++i)
-        if ((rc = run_block(m, m->enc[i], m->x_enc, B, Nv, c.enc_dim, c.enc_heads, planes, s))) return rc;
+        if ((rc = E.run_block(m->enc[i], m->x_enc, B, Nv, c.enc_dim, c.enc_heads, planes, m->sb, s))) return rc;
 
     // a7: encoder.norm, encoder_to_decoder (no bias); a8: + pos[vis] written straight into x_full rows [0,Nv)
     LayerNormParams ln;
     memset(&ln, 0, sizeof(ln));
     ln.x = m->x_enc; ln.ldx = c.enc_dim; ln.gamma = m->enc_norm_g; ln.beta = m->enc_norm_b; ln.eps = c.ln_eps; ln.D = c.enc_dim;
-    ln.rows = B * Nv; ln.out = m->hbuf; ln.out_plane = (int64_t)B * Nv * c.enc_dim; ln.ldo = c.enc_dim;
+    ln.rows = B * Nv; ln.out = m->sb.hbuf; ln.out_plane = (int64_t)B * Nv * c.enc_dim; ln.ldo = c.enc_dim;
     if ((rc = launch_layernorm(ln, planes, s))) return rc;
-    g = gemm_base(m->hbuf, ln.out_plane, c.enc_dim, m->e2d, B * Nv);
+    g = gemm_base(m->sb.hbuf, ln.out_plane, c.enc_dim, m->e2d, B * Nv);
     g.epi = EPI_F32; g.C = m->x_dec; g.ldc = c.dec_dim;
     g.resid = m->pos_dec; g.ldr = c.dec_dim; g.resid_rowmap = m->perm; g.rows_in = Nv; g.rows_out = Nt; g.map_stride = Nt;
-    if ((rc = run_gemm(m, g, planes, s))) return rc;
+    if ((rc = E.run_gemm(g, planes, s))) return rc;
     if ((rc = launch_fill_mask_tokens(m->x_dec, m->mask_token, m->pos_dec, m->perm, B, Nt, Nv, c.dec_dim, s))) return rc;
 
     // a9: decoder blocks over the full token set, norm + head on the last Nm tokens
     for (int i = 0; i < c.dec_depth; ++i)
-        if ((rc = run_block(m, m->dec[i], m->x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, s))) return rc;
+        if ((rc = E.run_block(m->dec[i], m->x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, m->sb, s))) return rc;
     memset(&ln, 0, sizeof(ln));
     ln.x = m->x_dec; ln.ldx = c.dec_dim; ln.gamma = m->dec_norm_g; ln.beta = m->dec_norm_b; ln.eps = c.ln_eps; ln.D = c.dec_dim;
     ln.rows = B * Nm; ln.rows_out_per_b = Nm; ln.rows_in_per_b = Nt; ln.in_offset = Nv;
-    ln.out = m->hbuf; ln.out_plane = (int64_t)B * Nm * c.dec_dim; ln.ldo = c.dec_dim;
+    ln.out = m->sb.hbuf; ln.out_plane = (int64_t)B * Nm * c.dec_dim; ln.ldo = c.dec_dim;
     if ((rc = launch_layernorm(ln, planes, s))) return rc;
-    g = gemm_base(m->hbuf, ln.out_plane, c.dec_dim, m->head, B * Nm);
+    g = gemm_base(m->sb.hbuf, ln.out_plane, c.dec_dim, m->head, B * Nm);
     g.epi = EPI_F32; g.C = a->y_tokens_dev; g.ldc = m->out_dim;
-    if ((rc = run_gemm(m, g, planes, s))) return rc;
+    if ((rc = E.run_gemm(g, planes, s))) return rc;
 
     // a11: patch un-embed scatter
     if (a->y_video_dev) {
@@ -549,36 +210,13 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
 }
 
 extern "C" int cwm_timing_enable(cwm_model* m, int kclass, int enable) {
-    CWM_REQUIRE(m && kclass >= 0 && kclass < CWM_KCLASS_COUNT, "cwm_timing_enable: bad argument");
-    KernelTimer& t = m->timers[kclass];
-    t.enabled = enable != 0;
-    if (enable && t.pool.size() < 512) {
-        while (t.pool.size() < 512) {
-            EventPair e;
-            CWM_HIP_CHECK(hipEventCreate(&e.a));
-            CWM_HIP_CHECK(hipEventCreate(&e.b));
-            e.flops = 0;
-            t.pool.push_back(e);
-        }
-    }
-    return CWM_OK;
+    CWM_REQUIRE(m, "cwm_timing_enable: null model");
+    return m->eng.timing_enable(kclass, enable);
 }
 
 extern "C" int cwm_timing_collect(cwm_model* m, int kclass, cwm_kernel_stats* out) {
-    CWM_REQUIRE(m && out && kclass >= 0 && kclass < CWM_KCLASS_COUNT, "cwm_timing_collect: bad argument");
-    KernelTimer& t = m->timers[kclass];
-    for (size_t i = 0; i < t.used; ++i) {
-        CWM_HIP_CHECK(hipEventSynchronize(t.pool[i].b));
-        float ms = 0.f;
-        CWM_HIP_CHECK(hipEventElapsedTime(&ms, t.pool[i].a, t.pool[i].b));
-        t.acc.launches += 1;
-        t.acc.total_ms += ms;
-        t.acc.total_flops += t.pool[i].flops;
-    }
-    t.used = 0;
-    *out = t.acc;
-    t.acc = {0, 0.0, 0.0};
-    return CWM_OK;
+    CWM_REQUIRE(m, "cwm_timing_collect: null model");
+    return m->eng.timing_collect(kclass, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -664,8 +302,7 @@ extern "C" int cwm_linear(const float* a_dev, const float* w_dev, const float* b
     CWM_REQUIRE(A && W && bias && (!gelu || G), "cwm_linear: out of device memory");
     hipLaunchKernelGGL(pad_split_rows_kernel, dim3((unsigned)(((int64_t)M * Kp + 255) / 256)), dim3(256), 0, s, a_dev, M, K, A,
                        A + (size_t)M * Kp, Kp);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)(((int64_t)Np * Kp + 255) / 256)), dim3(256), 0, s, w_dev, N, K, W,
-                       W + (size_t)Np * Kp, Np, Kp);
+    if (int rc = launch_pack_weight(w_dev, N, K, W, W + (size_t)Np * Kp, Np, Kp, s)) return rc;
     if (bias_dev) CWM_HIP_CHECK(hipMemcpyAsync(bias, bias_dev, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, s));
     GemmParams p;
     memset(&p, 0, sizeof(p));

@@ -144,7 +144,9 @@ class PredictorBasedGenerator(nn.Module):
         self.mask = self.generate_mask(self.x if x is None else x)
 
     def reset_padding_masks(self):
-        pass  # only padded (conjoined) predictors carry padding state (prediction.py:121-129)
+        """prediction.py:121-129"""
+        if hasattr(self.predictor, "main_stream"):
+            self.predictor._reset_padding_mask()
 
     def get_zeros_mask(self, x=None, frame=-1):
         if x is None:
@@ -215,7 +217,12 @@ class PredictorBasedGenerator(nn.Module):
             _, y = self.predictor.predict_video(x, mask, normalize=self.imagenet_normalize_inputs)
         else:
             y = self.predictor(self._preprocess(x), mask, *args, **kwargs)
+            if hasattr(self.predictor, "main_stream"):  # padded conjoined predictor: drop the pad rows (prediction.py:424-428)
+                num_pad = self.predictor.main_stream.max_padding_tokens - self.predictor.main_stream.min_padding_tokens
+                y = y[:, :-num_pad]
             if len(y.shape) != 5:
+                # NB the reference un-embeds with unnormalize(normalize(x)) (prediction.py:436-446); we use the raw
+                # input itself, which differs from that by at most one fp32 ulp at the visible pixels
                 y = self.pred_patches_to_video(y, x, mask=mask)
         if frame is not None:
             frame = frame % y.size(1)

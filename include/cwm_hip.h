@@ -49,6 +49,7 @@ typedef struct cwm_config {
 } cwm_config;
 
 typedef struct cwm_model cwm_model;
+struct cwm_kernel_stats;
 
 /* replaces: model construction via the factories, vmae.py:597-619 */
 int cwm_model_create(const cwm_config* cfg, cwm_model** out);
@@ -87,6 +88,49 @@ typedef struct cwm_forward_args {
  *           = PretrainVisionTransformer.forward vmae.py:539-560,
  * and optionally `pred_patches_to_video` prediction.py:245-259. */
 int cwm_forward(cwm_model* m, const cwm_forward_args* args);
+
+/* ---- IMU-conditioned conjoined padded predictor (BASELINE configs[4]) ------------------------------
+ * replaces: ConjoinedPaddedVisionTransformer.forward for the `imu400_base_4x4patch_2frames_1tube` family
+ * (cwm/models/VideoMAE/conjoined_vmae.py:889-1011, 852-887; factory :1230-1243), i.e. two token streams
+ * (RGB + IMU) with null-token padding (:49-165), ImuEncoder tokenisation (:1013-1147) and
+ * CrossAttentionTransformerBlock / BidirectionalCrossAttention (cwm/models/transformer.py:253-378, 442-583). */
+typedef struct cwm_conj_config {
+    cwm_config main;            /* RGB stream (patch 4, 768/12/12 - 384/6/4 for the shipped factory) */
+    int32_t main_max_pad;       /* max_padding_tokens of the RGB stream (64) */
+    int32_t ctx_in_chans, ctx_seq_len, ctx_tubelet;   /* 6, 400, 16 */
+    int32_t ctx_enc_dim, ctx_dec_dim, ctx_enc_heads, ctx_dec_heads; /* 384, 192, 12, 6 */
+    int32_t ctx_max_pad;        /* 25 */
+    int32_t n_enc_cross, enc_cross[16]; /* cross block BEFORE these encoder layers (0,3,6,9) */
+    int32_t n_dec_cross, dec_cross[16]; /* cross block AFTER these decoder layers (0,1,2,3) */
+    int32_t cross_heads, cross_mlp_ratio; /* 4, 2 */
+} cwm_conj_config;
+
+typedef struct cwm_conj_model cwm_conj_model;
+int cwm_conj_create(const cwm_conj_config* cfg, cwm_conj_model** out);
+void cwm_conj_destroy(cwm_conj_model* m);
+int cwm_conj_load_weight(cwm_conj_model* m, const char* key, const float* data, int on_device, const int64_t* shape, int ndim);
+int cwm_conj_missing_weights(cwm_conj_model* m, char* buf, int buflen);
+
+typedef struct cwm_conj_forward_args {
+    const float* x_dev;          /* frames, strides as in cwm_forward_args */
+    int64_t x_stride_b, x_stride_c, x_stride_t;
+    int32_t normalize;
+    const uint8_t* mask_dev;     /* bool [B, Nt]; rows MAY have different visible counts (null-token padding) */
+    int32_t batch;
+    int32_t n_vis_max;           /* max over rows of the visible count (max - min must be <= main_max_pad) */
+    const float* ctx_dev;        /* IMU [B, ctx_in_chans, ctx_seq_len] contiguous fp32 */
+    const uint8_t* ctx_mask_dev; /* bool [B, ctx_seq_len / ctx_tubelet] */
+    int32_t n_vis_ctx_max;
+    float* y_tokens_dev;         /* out [B, Nt + main_max_pad - n_vis_max, in_chans*patch*patch]; rows at masked pad slots are 0 */
+    int32_t mode;
+    int32_t check;
+    void* stream;
+} cwm_conj_forward_args;
+
+/* replaces: `self.predictor(self._preprocess(x), mask, x_context=..., mask_context=...)` (prediction.py:419-422) */
+int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* args);
+int cwm_conj_timing_enable(cwm_conj_model* m, int kclass, int enable);
+int cwm_conj_timing_collect(cwm_conj_model* m, int kclass, struct cwm_kernel_stats* out);
 
 /* ---- timing hooks (bench.py roofline): HIP events around every launch of one kernel class ------ */
 #define CWM_KCLASS_GEMM 0

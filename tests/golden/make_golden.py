@@ -224,6 +224,92 @@ def run_shift_cases(ns):
     print("[golden] shift_prompts.npz")
 
 
+TINY_CONJ_MAIN = C.VmaeConfig(name="tiny_conj_main", img_size=(32, 32), patch=4, enc_dim=128, enc_depth=2, enc_heads=2,
+                               dec_dim=128, dec_depth=1, dec_heads=2)
+TINY_CONJ = C.ConjConfig(name="tiny_conj", main=TINY_CONJ_MAIN, main_max_pad=8, ctx_seq_len=64, ctx_enc_dim=64, ctx_dec_dim=64,
+                         ctx_enc_heads=2, ctx_dec_heads=2, ctx_max_pad=4, enc_cross=(0,), dec_cross=(0,))
+
+
+def build_ref_conj(ns, cfg: C.ConjConfig, seed: int):
+    from functools import partial
+
+    conj = ns.conj
+    if cfg.name == "imu400_base_4x4patch_2frames_1tube":
+        m = conj.imu400_base_4x4patch_2frames_1tube()
+    else:
+        mc = cfg.main
+        main_kw = dict(encoder_func=ns.vmae.PretrainVisionTransformerEncoder, tubelet_size=1, decoder_num_classes=None,
+                       min_padding_tokens=0, max_padding_tokens=cfg.main_max_pad)
+        ctx_kw = dict(encoder_func=conj.ImuEncoder, tubelet_size=cfg.ctx_tubelet, spacetime_separable_pos_embed=True,
+                      encoder_embed_dim=cfg.ctx_enc_dim, decoder_embed_dim=cfg.ctx_dec_dim, sequence_length=cfg.ctx_seq_len,
+                      decoder_num_classes=cfg.ctx_out_dim, min_padding_tokens=0, max_padding_tokens=cfg.ctx_max_pad,
+                      concat_dummy_token=False)
+        m = conj.ConjoinedPaddedVisionTransformer(
+            img_size=mc.img_size[0], patch_size=(mc.patch, mc.patch), encoder_embed_dim=mc.enc_dim, encoder_depth=mc.enc_depth,
+            encoder_num_heads=mc.enc_heads, encoder_num_classes=0, decoder_embed_dim=mc.dec_dim, decoder_num_heads=mc.dec_heads,
+            decoder_depth=mc.dec_depth, mlp_ratio=4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+            main_model_func=conj.PaddedVisionTransformer, main_model_kwargs=main_kw, main_input="rgb01",
+            main_input_kwargs={"unnormalize": False}, context_model_func=conj.PaddedVisionTransformer, context_model_kwargs=ctx_kw,
+            context_input="imu", conjoin_encoder_layers=list(cfg.enc_cross), conjoin_decoder_layers=True)
+    sch = C.conj_state_dict_schema(cfg)
+    sd = m.state_dict()
+    assert list(sch) == list(sd) and all(tuple(sd[k].shape) == sch[k] for k in sd)
+    m.load_state_dict({k: torch.from_numpy(S.synthetic_tensor(k, shp, seed)) for k, shp in sch.items()})
+    return m.eval().requires_grad_(False)
+
+
+def run_conj_cases(ns, skip_large=False):
+    """BASELINE configs[4]: the IMU-conditioned conjoined padded predictor (conjoined_vmae.py:889-1011, 1230-1243)."""
+    # ---- tiny, ragged visible counts in both streams, through the model and through the reference wrapper
+    cfg = TINY_CONJ
+    m = build_ref_conj(ns, cfg, 5)
+    g = np.random.Generator(np.random.PCG64(2))
+    B, n = 3, cfg.main.tokens_per_frame
+    x = torch.from_numpy(g.random((B, 2, 3, 32, 32), dtype=np.float32))
+    mask = torch.zeros(B, 2 * n, dtype=torch.bool)
+    mask[:, n:] = True
+    for b, vis in enumerate(([3, 9], [5], [6, 7, 16])):
+        mask[b, [n + v for v in vis]] = False
+    imu = torch.from_numpy((g.standard_normal((B, 6, cfg.ctx_seq_len)) * 0.1).astype(np.float32))
+    mc = torch.zeros(B, cfg.ctx_tokens, dtype=torch.bool)
+    mc[0, 1] = True
+    mc[1, 0] = True
+    mc[1, 3] = True
+    G = ns.prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2, seed=0)
+    out = {"x": x.numpy(), "mask": mask.numpy(), "imu": imu.numpy(), "mask_context": mc.numpy(), "seed": np.array(5)}
+    with torch.no_grad():
+        m._reset_padding_mask()
+        out["y_tokens"] = m(G._preprocess(x), mask.clone(), x_context=imu, mask_context=mc).numpy()
+        m._reset_padding_mask()
+        # equal visible counts (the normal case after RectangularizeMasks): no visible pads, last P rows are zero
+        mask_eq = torch.from_numpy(S.synthetic_masks(2, cfg.main, 3, 9))
+        mc_eq = torch.zeros(2, cfg.ctx_tokens, dtype=torch.bool)
+        out["mask_eq"] = mask_eq.numpy()
+        out["y_tokens_eq"] = m(G._preprocess(x[:2]), mask_eq.clone(), x_context=imu[:2], mask_context=mc_eq).numpy()
+        m._reset_padding_mask()
+        torch.manual_seed(3)
+        video = G.predict(x[:2], mask_eq.clone(), frame=None, x_context=imu[:2], mask_context=mc_eq)
+        out["video_eq"] = video.numpy()
+    np.savez_compressed(os.path.join(HERE, "conj_tiny.npz"), **out)
+    print("[golden] conj_tiny.npz", out["y_tokens"].shape, out["video_eq"].shape)
+    if skip_large:
+        return
+    # ---- full size, B=2 with 4 and 6 visible frame-2 patches (exercises the null-token padding)
+    cfg = C.CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"]
+    t0 = time.time()
+    m = build_ref_conj(ns, cfg, 0)
+    x = torch.from_numpy(S.synthetic_frames(2, cfg.main, 0))
+    mask = torch.from_numpy(np.stack([S.synthetic_masks(1, cfg.main, 4, 0)[0], S.synthetic_masks(1, cfg.main, 6, 1)[0]]))
+    imu = torch.from_numpy((np.random.Generator(np.random.PCG64(7)).standard_normal((2, 6, 400)) * 0.1).astype(np.float32))
+    mc = torch.zeros(2, 25, dtype=torch.bool)
+    mean = torch.tensor(C.IMAGENET_MEAN).view(1, 3, 1, 1, 1)
+    std = torch.tensor(C.IMAGENET_STD).view(1, 3, 1, 1, 1)
+    with torch.no_grad():
+        y = m((x.transpose(1, 2) - mean) / std, mask.clone(), x_context=imu, mask_context=mc)
+    np.savez_compressed(os.path.join(HERE, "conj_imu400_b2.npz"), mask=mask.numpy(), imu=imu.numpy(), y_tokens=y.numpy(), seed=np.array(0))
+    print(f"[golden] conj_imu400_b2.npz {tuple(y.shape)} std {y.std():.4f} ({time.time() - t0:.1f}s)")
+
+
 def run_init_case(ns):
     """Reference constructor RNG parity: seed -> freshly initialised parameters (vmae.py:90,209,371)."""
     out = {}
@@ -256,8 +342,12 @@ def main():
     if args.only == "shift":
         run_shift_cases(ns)
         return
+    if args.only == "conj":
+        run_conj_cases(ns, args.skip_large)
+        return
     run_init_case(ns)
     run_shift_cases(ns)
+    run_conj_cases(ns, args.skip_large)
     run_index_cases(ns)
     run_block_case(ns)
     run_model_case(ns, TINY, batch=3, k_vis=4, clump=1, seed=3, out_name="tiny_8x8_k4.npz")

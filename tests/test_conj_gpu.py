@@ -1,0 +1,78 @@
+"""BASELINE configs[4]: the IMU-conditioned conjoined padded predictor on the GPU (through the host mirror and
+the C ABI) against the reference's golden outputs and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from counterfactualworldmodels_amd import config as C, conjoined_vmae as CV, prediction, synthetic as S
+from oracle import conj_oracle as CO, vmae_oracle as V
+from test_conj_oracle import TINY_CONJ, TINY_SPEC, conj_weights
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def build(cfg, seed, mode="parity"):
+    m = CV.ConjoinedPaddedVisionTransformer(cfg, mode=mode)
+    m.load_state_dict(conj_weights(cfg, seed))
+    return m.cuda().eval()
+
+
+def test_tiny_conj_golden_ragged_and_wrapper():
+    g = np.load(os.path.join(GOLDEN, "conj_tiny.npz"))
+    m = build(TINY_CONJ, int(g["seed"]))
+    G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+    x, mask, imu, mc = (torch.from_numpy(g[k]).cuda() for k in ("x", "mask", "imu", "mask_context"))
+    y = m(G._preprocess(x), mask, x_context=imu, mask_context=mc).cpu().numpy()
+    assert y.shape == g["y_tokens"].shape
+    assert np.abs(y - g["y_tokens"]).max() <= 3e-4
+    assert hasattr(m, "padding_mask")
+    G.reset_padding_masks()
+    assert not hasattr(m, "padding_mask")
+    # zero rows exactly where the reference has them (masked pad slots)
+    assert np.array_equal(np.abs(y).sum(-1) == 0, np.abs(g["y_tokens"]).sum(-1) == 0)
+    mask_eq = torch.from_numpy(g["mask_eq"]).cuda()
+    mc_eq = torch.zeros(2, TINY_CONJ.ctx_tokens, dtype=torch.bool, device="cuda")
+    y_eq = m(G._preprocess(x[:2]), mask_eq, x_context=imu[:2], mask_context=mc_eq).cpu().numpy()
+    assert np.abs(y_eq - g["y_tokens_eq"]).max() <= 3e-4
+    video = G.predict(x[:2], mask_eq.clone(), frame=None, x_context=imu[:2], mask_context=mc_eq).cpu().numpy()
+    assert video.shape == g["video_eq"].shape and np.abs(video - g["video_eq"]).max() <= 3e-4
+    # fast mode stays close on this shallow model
+    m.mode = "fast"
+    yf = m(G._preprocess(x), mask, x_context=imu, mask_context=mc).cpu().numpy()
+    assert np.abs(yf - g["y_tokens"]).max() <= 8e-2
+
+
+def test_imu400_full_size_golden():
+    g = np.load(os.path.join(GOLDEN, "conj_imu400_b2.npz"))
+    cfg = C.CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"]
+    m = build(cfg, int(g["seed"]))
+    x = torch.from_numpy(S.synthetic_frames(2, cfg.main, 0))
+    mask, imu = torch.from_numpy(g["mask"]).cuda(), torch.from_numpy(g["imu"]).cuda()
+    y = m(V.preprocess(x).cuda(), mask, x_context=imu, mask_context=torch.zeros(2, 25, dtype=torch.bool, device="cuda")).cpu().numpy()
+    err = np.abs(y - g["y_tokens"]).max()
+    print(f"[imu400 B=2 ragged] parity-mode max-abs vs reference: {err:.3e}")
+    assert y.shape == g["y_tokens"].shape and err <= 1e-3, err
+    assert np.array_equal(np.abs(y).sum(-1) == 0, np.abs(g["y_tokens"]).sum(-1) == 0)
+    m.mode = "fast"
+    yf = m(V.preprocess(x).cuda(), mask, x_context=imu, mask_context=torch.zeros(2, 25, dtype=torch.bool, device="cuda")).cpu().numpy()
+    print(f"[imu400 B=2 ragged] fast-mode max-abs vs reference: {np.abs(yf - g['y_tokens']).max():.3e}")
+    assert np.abs(yf - g["y_tokens"]).max() <= 2.5e-1
+
+
+def test_conj_errors():
+    m = build(TINY_CONJ, 5)
+    x = torch.zeros(2, 3, 2, 32, 32, device="cuda")
+    mask = torch.zeros(2, 128, dtype=torch.bool, device="cuda")
+    mask[:, 64:] = True
+    imu = torch.zeros(2, 6, 64, device="cuda")
+    with pytest.raises(RuntimeError):
+        m(x, mask)  # no IMU
+    bad = mask.clone()
+    bad[0, 64:80] = False  # 16 more visible than row 1: exceeds max_padding_tokens = 8
+    with pytest.raises(RuntimeError):
+        m(x, bad, x_context=imu)
+    with pytest.raises(RuntimeError):
+        m(x.cpu(), mask.cpu(), x_context=imu.cpu())
