@@ -147,12 +147,65 @@ def run_prompts(args, rank, local_rank, world, distributed):
         print(json.dumps(out))
 
 
+def run_imu(args, rank, local_rank, world, distributed):
+    """BASELINE configs[4]: IMU-conditioned conjoined base-4x4 predictor, batch 16 (weak scaling over ranks)."""
+    from counterfactualworldmodels_amd import conjoined_vmae as CV
+
+    cfg = C.CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"]
+    dev = torch.device("cuda", local_rank)
+    B = args.batch or 16
+    model = CV.ConjoinedPaddedVisionTransformer(cfg, mode=args.mode)
+    model.load_state_dict({k: torch.from_numpy(S.synthetic_tensor(k, shp, 0)) for k, shp in C.conj_state_dict_schema(cfg).items()})
+    model = model.to(dev).eval()
+    x = torch.from_numpy(S.synthetic_frames(B, cfg.main, rank)).to(dev).transpose(1, 2)  # [B,C,T,H,W] view, raw frames
+    mask = torch.from_numpy(S.synthetic_masks(B, cfg.main, 4, rank)).to(dev)
+    g = torch.Generator().manual_seed(rank)
+    imu = (torch.randn(B, 6, 400, generator=g) * 0.1).to(dev)
+    mc = torch.zeros(B, 25, dtype=torch.bool, device=dev)
+
+    def step():
+        return model(x, mask, x_context=imu, mask_context=mc, normalize=True, check=False)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_gpus = world if distributed else 1
+    flops_pair = 1.422e12  # SURVEY.md §8(d), cfg 5 (k=4)
+    value = B * n_gpus * args.steps / dt
+    out = {
+        "metric": "predicted frames/sec (2x224x224, IMU-conditioned ViT-B/4)", "value": value, "unit": "frames/s", "n_gpus": n_gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "IMU-conditioned ViT-base 4x4 (conjoined RGB+IMU streams), batch=16 (BASELINE configs[4])", "predictor": cfg.name,
+                   "per_gpu_batch": B, "mode": args.mode, "tokens_decoder": cfg.main.num_tokens + cfg.main_max_pad},
+        "model_tflops": flops_pair * value / 1e12, "model_frac_of_bf16_peak": flops_pair * value / 1e12 / (PEAK_BF16_TFLOPS * n_gpus),
+    }
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="base8", choices=sorted(WORKLOADS) + ["prompts256"])
+    ap.add_argument("--workload", default="base8", choices=sorted(WORKLOADS) + ["prompts256", "imu4"])
     ap.add_argument("--mode", default="parity", choices=["parity", "fast"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,6 +223,8 @@ def main():
     n_gpus = world if distributed else 1
     if args.workload == "prompts256":
         return run_prompts(args, rank, local_rank, world, distributed)
+    if args.workload == "imu4":
+        return run_imu(args, rank, local_rank, world, distributed)
 
     wl = WORKLOADS[args.workload]
     cfg = C.CONFIGS[wl["cfg"]]
