@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     const float inv = 1.0f / l_tot;
     const int q = q0 + qcol;
     if (q < N) {
-        bf16* orow = p.o + ((size_t)b * N + q) * p.ldo + h * 64;
+        const int64_t orow = (int64_t)b * N + q;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -235,8 +235,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
                     if constexpr (PLANES == 2) lo4[e] = (bf16)(v - (float)hi);
                 }
                 const int d0 = db * 32 + 8 * g + 4 * hh;
-                *reinterpret_cast<bf16x4*>(orow + d0) = hi4;
-                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(orow + p.o_plane + d0) = lo4;
+                bf16* dst = p.o + a_pos<PLANES>(orow, p.ldo, h * 64 + d0);  // GEMM A-operand layout (common.h)
+                *reinterpret_cast<bf16x4*>(dst) = hi4;
+                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + kLoOffset) = lo4;
             }
     }
 }

@@ -23,6 +23,17 @@ __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
     lo = (bf16)(v - (float)hi);
 }
 
+// GEMM A/W operand layout.  PLANES == 1 ("fast"): plain [rows][ld] bf16.  PLANES == 2 ("parity"): ONE buffer
+// [rows][2*ld] with the hi and lo planes interleaved per 32-element k block -- [32 hi | 32 lo] = one 128-byte
+// line -- so that the GEMM's LDS-DMA requests are full cache lines in both modes (64-byte half-line requests
+// measured ~1.5x slower per byte).  a_pos() is the position of the hi element; the lo element is 32 further.
+template <int PLANES>
+__device__ __forceinline__ size_t a_pos(int64_t row, int ld, int col) {
+    if constexpr (PLANES == 1) return (size_t)row * ld + col;
+    else return (size_t)row * 2 * ld + ((col >> 5) << 6) + (col & 31);
+}
+constexpr int kLoOffset = 32;
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -89,8 +89,9 @@ __global__ void imu_gather_kernel(const ImuGatherParams p) {
     }
     bf16 hi, lo;
     split_bf16(v, hi, lo);
-    p.out[gid] = hi;
-    if constexpr (PLANES == 2) p.out[gid + p.out_plane] = lo;
+    bf16* dst = p.out + a_pos<PLANES>(row, p.ld, k);
+    *dst = hi;
+    if constexpr (PLANES == 2) dst[kLoOffset] = lo;
 }
 
 int launch_imu_gather(const ImuGatherParams& p, int planes, hipStream_t stream) {
@@ -145,14 +146,14 @@ __global__ __launch_bounds__(64) void small_attention_kernel(const SmallAttnPara
             if (d < hd) o[d] = fmaf(pm, vs[m][d], o[d] * alpha);
     }
     const float inv = 1.0f / l;
-    bf16* dst = p.o + ((size_t)b * N + t) * p.ldo + h * hd;
 #pragma unroll
     for (int d = 0; d < MAXD; ++d)
         if (d < hd) {
             bf16 hi, lo;
             split_bf16(o[d] * inv, hi, lo);
-            dst[d] = hi;
-            if constexpr (PLANES == 2) dst[d + p.o_plane] = lo;
+            bf16* dst = p.o + a_pos<PLANES>((int64_t)b * N + t, p.ldo, h * hd + d);
+            *dst = hi;
+            if constexpr (PLANES == 2) dst[kLoOffset] = lo;
         }
 }
 
@@ -237,15 +238,15 @@ __global__ __launch_bounds__(256) void cross_attn_main_kernel(const CrossAttnPar
         }
     }
     const float inv = 1.0f / l;
-    bf16* dst = p.y + ((size_t)b * p.N + n) * D + h * hd;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int d = lane + 64 * i;
         if (d < hd) {
             bf16 hi, lo;
             split_bf16(o[i] * inv, hi, lo);
-            dst[d] = hi;
-            if constexpr (PLANES == 2) dst[d + p.y_plane] = lo;
+            bf16* dst = p.y + a_pos<PLANES>((int64_t)b * p.N + n, D, h * hd + d);
+            *dst = hi;
+            if constexpr (PLANES == 2) dst[kLoOffset] = lo;
         }
     }
 }
@@ -292,9 +293,9 @@ __global__ __launch_bounds__(256) void cross_attn_src_kernel(const CrossAttnPara
     if (t < hd) {
         bf16 hi, lo;
         split_bf16(acc / red[0], hi, lo);
-        bf16* dst = p.y_src + ((size_t)b * p.M + m) * D + h * hd + t;
+        bf16* dst = p.y_src + a_pos<PLANES>((int64_t)b * p.M + m, D, h * hd + t);
         *dst = hi;
-        if constexpr (PLANES == 2) dst[p.y_src_plane] = lo;
+        if constexpr (PLANES == 2) dst[kLoOffset] = lo;
     }
 }
 

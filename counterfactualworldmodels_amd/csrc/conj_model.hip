@@ -170,13 +170,13 @@ int layernorm_to(Engine& E, const float* x, int rows, int D, const float* g, con
 }
 
 int linear_f32(Engine& E, const bf16* A, int rows, int K, const LinearW& L, float* C, const float* resid, int planes, hipStream_t s) {
-    GemmParams g = gemm_base(A, (int64_t)rows * K, K, L, rows);
+    GemmParams g = gemm_base(A, K, L, rows, planes);
     g.epi = EPI_F32; g.C = C; g.ldc = L.N; g.resid = resid; g.ldr = L.N;
     return E.run_gemm(g, planes, s);
 }
 
 int linear_gelu(Engine& E, const bf16* A, int rows, int K, const LinearW& L, bf16* out, int planes, hipStream_t s) {
-    GemmParams g = gemm_base(A, (int64_t)rows * K, K, L, rows);
+    GemmParams g = gemm_base(A, K, L, rows, planes);
     g.epi = EPI_BF16_GELU; g.out_hi = out; g.out_plane = (int64_t)rows * L.N; g.ldo = L.N;
     return E.run_gemm(g, planes, s);
 }
@@ -213,7 +213,7 @@ int run_cross(cwm_conj_model* m, const CrossW& C, float* x, int N, int ci, float
 int embed_stream(cwm_conj_model* m, StreamW& S, int B, int vmax, int planes, hipStream_t s) {
     Engine& E = m->eng;
     const int next = S.n_tok + S.max_pad;
-    GemmParams g = gemm_base(S.tokens_in, (int64_t)B * vmax * S.embed_kpad, S.embed_kpad, S.embed, B * vmax);
+    GemmParams g = gemm_base(S.tokens_in, S.embed_kpad, S.embed, B * vmax, planes);
     g.epi = EPI_F32; g.C = S.x_enc; g.ldc = S.enc_dim;
     g.resid = S.pos_enc_ext; g.ldr = S.enc_dim; g.resid_rowmap = S.perm; g.rows_in = vmax; g.rows_out = vmax; g.map_stride = next;
     if (int rc = E.run_gemm(g, planes, s)) return rc;
@@ -226,7 +226,7 @@ int to_decoder(cwm_conj_model* m, StreamW& S, int B, int vmax, int planes, hipSt
     const int next = S.n_tok + S.max_pad;
     int rc;
     if ((rc = layernorm_to(E, S.x_enc, B * vmax, S.enc_dim, S.enc_norm_g, S.enc_norm_b, S.sb.hbuf, planes, s))) return rc;
-    GemmParams g = gemm_base(S.sb.hbuf, (int64_t)B * vmax * S.enc_dim, S.enc_dim, S.e2d, B * vmax);
+    GemmParams g = gemm_base(S.sb.hbuf, S.enc_dim, S.e2d, B * vmax, planes);
     g.epi = EPI_F32; g.C = S.x_dec; g.ldc = S.dec_dim;
     g.resid = S.pos_dec_ext; g.ldr = S.dec_dim; g.resid_rowmap = S.perm; g.rows_in = vmax; g.rows_out = next; g.map_stride = next;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
@@ -370,7 +370,7 @@ extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* 
     ln.rows = B * n_out; ln.rows_out_per_b = n_out; ln.rows_in_per_b = Nx; ln.in_offset = vm;
     ln.out = A.sb.hbuf; ln.out_plane = (int64_t)B * n_out * A.dec_dim; ln.ldo = A.dec_dim;
     if ((rc = launch_layernorm(ln, planes, s))) return rc;
-    GemmParams g = gemm_base(A.sb.hbuf, ln.out_plane, A.dec_dim, A.head, B * n_out);
+    GemmParams g = gemm_base(A.sb.hbuf, A.dec_dim, A.head, B * n_out, planes);
     g.epi = EPI_F32; g.C = a->y_tokens_dev; g.ldc = A.out_dim;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
     if ((rc = launch_zero_pad_out_rows(a->y_tokens_dev, A.perm, B, Nx, vm, n_out, A.n_tok, A.out_dim, s))) return rc;

@@ -46,11 +46,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
         }
     }
     const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
-    bf16* out = p.out + (size_t)r * p.ldo;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
         const int idx = lane * 2 + i * 128;
         if (idx < p.D) {
+            bf16* out = p.out + a_pos<PLANES>(r, p.ldo, idx);
             const float2 g = *reinterpret_cast<const float2*>(p.gamma + idx);
             const float2 be = *reinterpret_cast<const float2*>(p.beta + idx);
             const float y0 = (v[i].x - mean) * rstd * g.x + be.x;
@@ -59,10 +59,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
             split_bf16(y0, h0, l0);
             split_bf16(y1, h1, l1);
             bf16x2 hv = {h0, h1};
-            *reinterpret_cast<bf16x2*>(out + idx) = hv;
+            *reinterpret_cast<bf16x2*>(out) = hv;
             if constexpr (PLANES == 2) {
                 bf16x2 lv = {l0, l1};
-                *reinterpret_cast<bf16x2*>(out + p.out_plane + idx) = lv;
+                *reinterpret_cast<bf16x2*>(out + kLoOffset) = lv;
             }
             if (p.out_f32) *reinterpret_cast<float2*>(p.out_f32 + (size_t)r * p.D + idx) = make_float2(y0, y1);
         }
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const PatchGatherPara
     const float* src = p.x + b * p.sb + c * p.sc + t * p.st + (int64_t)(hy * p.P + ph) * p.W + wx * p.P;
     const float mean = (c == 0) ? 0.485f : (c == 1) ? 0.456f : 0.406f;
     const float stdv = (c == 0) ? 0.229f : (c == 1) ? 0.224f : 0.225f;
-    bf16* dst = p.out + (size_t)row * p.ld + c * p.P * p.P + ph * p.P;
+    const int kbase = c * p.P * p.P + ph * p.P;
     const bool pad_slot = tau >= p.Nt;  // null-token pad slot of a padded predictor: no pixels behind it
     for (int pw = 0; pw < p.P; pw += 4) {
         const float4 v = pad_slot ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(src + pw);
@@ -182,16 +182,17 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const PatchGatherPara
             hv[e] = hi;
             lv[e] = lo;
         }
-        *reinterpret_cast<bf16x4*>(dst + pw) = hv;
-        if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + p.out_plane + pw) = lv;
+        bf16* dst = p.out + a_pos<PLANES>(row, p.ld, kbase + pw);
+        *reinterpret_cast<bf16x4*>(dst) = hv;
+        if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + kLoOffset) = lv;
     }
     // zero the K padding (K = C*P*P rounded up to ld) once per row
     if (rem == 0) {
         const int K = p.C * p.P * p.P;
-        bf16* rowp = p.out + (size_t)row * p.ld;
         for (int k = K; k < p.ld; ++k) {
-            rowp[k] = (bf16)0.f;
-            if constexpr (PLANES == 2) rowp[p.out_plane + k] = (bf16)0.f;
+            bf16* z = p.out + a_pos<PLANES>(row, p.ld, k);
+            *z = (bf16)0.f;
+            if constexpr (PLANES == 2) z[kLoOffset] = (bf16)0.f;
         }
     }
 }

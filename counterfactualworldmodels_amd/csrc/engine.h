@@ -20,7 +20,8 @@ namespace cwm {
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct LinearW {
-    bf16* w = nullptr;  // [2][Npad][Kpad]
+    bf16* w = nullptr;     // fast mode:   [Npad][Kpad]   bf16(weight)
+    bf16* w_il = nullptr;  // parity mode: [Npad][2*Kpad] hi/lo interleaved per 32-k block (common.h a_pos)
     int64_t plane = 0;
     int N = 0, K = 0, Npad = 0, Kpad = 0;
     float* bias = nullptr;  // [Npad] (zero-filled) or nullptr when the layer has no bias
@@ -103,9 +104,9 @@ struct Engine {
     int timing_collect(int kclass, cwm_kernel_stats* out);
 };
 
-GemmParams gemm_base(const bf16* A, int64_t a_plane, int lda, const LinearW& L, int M);
+GemmParams gemm_base(const bf16* A, int lda, const LinearW& L, int M, int planes);
 
-// fp32 [N][K] -> bf16 (hi, lo) planes [Npad][Kpad], zero padded
-int launch_pack_weight(const float* src, int N, int K, bf16* hi, bf16* lo, int Npad, int Kpad, hipStream_t stream);
+// fp32 [N][K] -> bf16 [Npad][Kpad] (hi only) and [Npad][2*Kpad] (hi/lo interleaved), zero padded
+int launch_pack_weight(const float* src, int N, int K, bf16* hi, bf16* il, int Npad, int Kpad, hipStream_t stream);
 
 }  // namespace cwm

@@ -22,20 +22,24 @@ extern "C" const char* cwm_version(void) { return "cwm_hip 0.2.0 gfx950"; }
 
 namespace cwm {
 
-__global__ void pack_weight_kernel(const float* src, int N, int K, bf16* hi, bf16* lo, int Npad, int Kpad) {
+__global__ void pack_weight_kernel(const float* src, int N, int K, bf16* hi, bf16* il, int Npad, int Kpad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)Npad * Kpad) return;
     const int n = (int)(i / Kpad), k = (int)(i - (int64_t)n * Kpad);
     float v = (n < N && k < K) ? src[(size_t)n * K + k] : 0.f;
     bf16 h, l;
     split_bf16(v, h, l);
-    hi[i] = h;
-    lo[i] = l;
+    if (hi) hi[i] = h;
+    if (il) {
+        bf16* d = il + a_pos<2>(n, Kpad, k);
+        d[0] = h;
+        d[kLoOffset] = l;
+    }
 }
 
-int launch_pack_weight(const float* src, int N, int K, bf16* hi, bf16* lo, int Npad, int Kpad, hipStream_t stream) {
+int launch_pack_weight(const float* src, int N, int K, bf16* hi, bf16* il, int Npad, int Kpad, hipStream_t stream) {
     const int64_t total = (int64_t)Npad * Kpad;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, N, K, hi, lo, Npad, Kpad);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, N, K, hi, il, Npad, Kpad);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -72,8 +76,10 @@ int Engine::make_linear(LinearW& L, int N, int K, bool bias) {
     L.Kpad = round_up(K, 64);
     L.plane = (int64_t)L.Npad * L.Kpad;
     void* p;
-    if (int rc = alloc(&p, (size_t)2 * L.plane * sizeof(bf16), true, false)) return rc;
+    if (int rc = alloc(&p, (size_t)L.plane * sizeof(bf16), true, false)) return rc;
     L.w = (bf16*)p;
+    if (int rc = alloc(&p, (size_t)2 * L.plane * sizeof(bf16), true, false)) return rc;
+    L.w_il = (bf16*)p;
     if (bias) {
         if (int rc = alloc(&p, (size_t)L.Npad * sizeof(float), true, false)) return rc;
         L.bias = (float*)p;
@@ -202,8 +208,8 @@ int Engine::load_weight(const char* key, const float* data, int on_device, const
             src = tmp;
         }
         const int64_t total = (int64_t)L.Npad * L.Kpad;
-        hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, src, L.N, L.K, L.w, L.w + L.plane,
-                           L.Npad, L.Kpad);
+        hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, src, L.N, L.K, L.w, L.w_il, L.Npad,
+                           L.Kpad);
         hipError_t e = hipDeviceSynchronize();
         if (tmp) (void)hipFree(tmp);
         if (e != hipSuccess) {
@@ -294,14 +300,12 @@ int Engine::timing_collect(int kclass, cwm_kernel_stats* out) {
     return CWM_OK;
 }
 
-GemmParams gemm_base(const bf16* A, int64_t a_plane, int lda, const LinearW& L, int M) {
+GemmParams gemm_base(const bf16* A, int lda, const LinearW& L, int M, int planes) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A;
-    p.a_plane = a_plane;
     p.lda = lda;
-    p.W = L.w;
-    p.w_plane = L.plane;
+    p.W = planes == 2 ? L.w_il : L.w;
     p.M = M;
     p.N = L.N;
     p.K = L.Kpad;
@@ -322,7 +326,7 @@ int Engine::run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H,
     ln.out = sb.hbuf; ln.out_plane = hplane; ln.ldo = D;
     if ((rc = launch_layernorm(ln, planes, s))) return rc;
 
-    GemmParams g = gemm_base(sb.hbuf, hplane, D, w.qkv, M);
+    GemmParams g = gemm_base(sb.hbuf, D, w.qkv, M, planes);
     g.epi = EPI_QKV;
     g.rows_in = n_tok; g.rows_out = n_tok; g.map_stride = n_tok;
     g.q_out = sb.qbuf; g.k_out = sb.kbuf; g.vt_out = sb.vtbuf;
@@ -337,18 +341,18 @@ int Engine::run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H,
     a.o = sb.hbuf; a.o_plane = hplane; a.ldo = D; a.n_tok = n_tok; a.n_pad = n_pad; a.heads = H; a.batch = B;
     if ((rc = run_attention(a, planes, s))) return rc;
 
-    g = gemm_base(sb.hbuf, hplane, D, w.proj, M);
+    g = gemm_base(sb.hbuf, D, w.proj, M, planes);
     g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
     if ((rc = run_gemm(g, planes, s))) return rc;
 
     ln.gamma = w.ln2_g; ln.beta = w.ln2_b;
     if ((rc = launch_layernorm(ln, planes, s))) return rc;
 
-    g = gemm_base(sb.hbuf, hplane, D, w.fc1, M);
+    g = gemm_base(sb.hbuf, D, w.fc1, M, planes);
     g.epi = EPI_BF16_GELU; g.out_hi = sb.gbuf; g.out_plane = (int64_t)M * hidden; g.ldo = hidden;
     if ((rc = run_gemm(g, planes, s))) return rc;
 
-    g = gemm_base(sb.gbuf, (int64_t)M * hidden, hidden, w.fc2, M);
+    g = gemm_base(sb.gbuf, hidden, w.fc2, M, planes);
     g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
     return run_gemm(g, planes, s);
 }
@@ -366,7 +370,7 @@ int Engine::run_block_small(const BlockW& w, float* x, int B, int n_tok, int D, 
     ln.out = sb.hbuf; ln.out_plane = hplane; ln.ldo = D;
     if ((rc = launch_layernorm(ln, planes, s))) return rc;
 
-    GemmParams g = gemm_base(sb.hbuf, hplane, D, w.qkv, M);
+    GemmParams g = gemm_base(sb.hbuf, D, w.qkv, M, planes);
     g.epi = EPI_F32; g.C = sb.qkv_f32; g.ldc = 3 * D;
     if ((rc = run_gemm(g, planes, s))) return rc;
 
@@ -376,18 +380,18 @@ int Engine::run_block_small(const BlockW& w, float* x, int B, int n_tok, int D, 
     a.o = sb.hbuf; a.o_plane = hplane; a.ldo = D;
     if ((rc = launch_small_attention(a, planes, s))) return rc;
 
-    g = gemm_base(sb.hbuf, hplane, D, w.proj, M);
+    g = gemm_base(sb.hbuf, D, w.proj, M, planes);
     g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
     if ((rc = run_gemm(g, planes, s))) return rc;
 
     ln.gamma = w.ln2_g; ln.beta = w.ln2_b;
     if ((rc = launch_layernorm(ln, planes, s))) return rc;
 
-    g = gemm_base(sb.hbuf, hplane, D, w.fc1, M);
+    g = gemm_base(sb.hbuf, D, w.fc1, M, planes);
     g.epi = EPI_BF16_GELU; g.out_hi = sb.gbuf; g.out_plane = (int64_t)M * hidden; g.ldo = hidden;
     if ((rc = run_gemm(g, planes, s))) return rc;
 
-    g = gemm_base(sb.gbuf, (int64_t)M * hidden, hidden, w.fc2, M);
+    g = gemm_base(sb.gbuf, hidden, w.fc2, M, planes);
     g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
     return run_gemm(g, planes, s);
 }

@@ -11,8 +11,10 @@
 //   VGPRs, no ds_write pass) into a 2-stage LDS ring; tile t+1 is in flight while tile t is multiplied.
 //   An LDS-DMA piece lands linearly (lane l -> base + 16 l), so the bank-conflict XOR swizzle is applied
 //   to the per-lane SOURCE address and again on the fragment reads (measured SQ_LDS_BANK_CONFLICT = 0)
-// * PLANES==2 ("parity" mode): operands are (hi, lo) bf16 planes and each product is
-//   hi*hi + hi*lo + lo*hi, fp32-accumulated -> ~2^-16 relative operand error instead of 2^-9
+// * PLANES==2 ("parity" mode): operands are split into bf16 hi + lo and each product is
+//   hi*hi + hi*lo + lo*hi, fp32-accumulated -> ~2^-16 relative operand error instead of 2^-9.  hi and lo
+//   are stored interleaved per 32-k block ([32 hi | 32 lo] = one 128-byte line, common.h a_pos) so the
+//   tile rows are full cache lines in both modes (64-byte half-line DMA requests filled LDS ~1.5x slower)
 // * XCD-aware, grouped tile order so that co-resident tiles of one XCD share A panels / W tiles in L2
 // * accumulators are kept TRANSPOSED (D^T = W_frag . A_frag^T): a lane then owns 4 consecutive output
 //   columns of one row, so every epilogue access is a 16-byte (fp32) / 8-byte (bf16) vector; the V third
@@ -115,8 +117,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
                     }
-                    dst = p.out_hi + (size_t)rm.out_row * p.ldo + n;
-                    plane = p.out_plane;
+                    dst = p.out_hi + a_pos<PLANES>(rm.out_row, p.ldo, n);  // A-operand layout of the next GEMM
+                    plane = kLoOffset;
                 }
                 bf16x4 hv, lv;
 #pragma unroll
@@ -181,12 +183,12 @@ __device__ __forceinline__ void epilogue_cols_vt(const GemmParams& p, const f32x
 template <int PLANES>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     constexpr int BM = 128, BN = 128;
-    constexpr int BK = (PLANES == 1) ? 64 : 32;
-    constexpr int CPR = BK / 8;        // 16-byte chunks per tile row
-    constexpr int RPI = 64 / CPR;      // tile rows covered by one 1-KiB DMA piece
-    constexpr int NI = BM / RPI / 4;   // DMA pieces per wave per operand plane
-    constexpr int TILE_BYTES = BM * BK * 2;
-    constexpr int STAGE_BYTES = TILE_BYTES * 2 * PLANES;
+    // every K tile row is one 128-byte line in LDS and in memory: 64 k of the single plane (fast), or
+    // 32 k as [32 hi | 32 lo] (parity, interleaved operand layout: common.h a_pos)
+    constexpr int BK = 64 / PLANES;    // logical k per tile
+    constexpr int NI = BM / 8 / 4;     // 1-KiB DMA pieces (8 rows each) per wave per operand
+    constexpr int TILE_BYTES = BM * 128;
+    constexpr int STAGE_BYTES = TILE_BYTES * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -214,22 +216,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     const bf16* w_src[NI];
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {
-        const int row = (wave * NI + jj) * RPI + lane / CPR;
-        const int logical = (lane % CPR) ^ lds_swizzle<BK>(row);
-        a_src[jj] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + logical * 8;
-        w_src[jj] = p.W + (size_t)(n0 + row) * p.K + logical * 8;
+        const int row = (wave * NI + jj) * 8 + lane / 8;
+        const int logical = (lane % 8) ^ lds_swizzle<64>(row);
+        a_src[jj] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda * PLANES + logical * 8;
+        w_src[jj] = p.W + (size_t)(n0 + row) * p.K * PLANES + logical * 8;
     }
     auto issue_tile = [&](int stage, int k0) {
 #pragma unroll
-        for (int pl = 0; pl < PLANES; ++pl)
-#pragma unroll
-            for (int jj = 0; jj < NI; ++jj) {
-                const int j = wave * NI + jj;
-                char* da = smem + stage * STAGE_BYTES + pl * TILE_BYTES + j * 1024;
-                char* dw = smem + stage * STAGE_BYTES + (PLANES + pl) * TILE_BYTES + j * 1024;
-                __builtin_amdgcn_global_load_lds((gbl_void*)(a_src[jj] + (size_t)pl * p.a_plane + k0), (lds_void*)da, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gbl_void*)(w_src[jj] + (size_t)pl * p.w_plane + k0), (lds_void*)dw, 16, 0, 0);
-            }
+        for (int jj = 0; jj < NI; ++jj) {
+            const int j = wave * NI + jj;
+            char* da = smem + stage * STAGE_BYTES + j * 1024;
+            char* dw = smem + stage * STAGE_BYTES + TILE_BYTES + j * 1024;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(a_src[jj] + k0), (lds_void*)da, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(w_src[jj] + k0), (lds_void*)dw, 16, 0, 0);
+        }
     };
 
     // the V third of a QKV projection is accumulated in the plain orientation (block-uniform choice)
@@ -242,14 +242,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment read offsets (row within tile, k-chunk within a 32-wide k-step)
+    // 16-byte chunks of a 128-byte row: fast = [k 0..31 | k 32..63] -> two k-steps; parity = [hi | lo] of one k-step
     const int frow = lane & 15, fq = lane >> 4;
-    int a_off[4][BK / 32], b_off[4][BK / 32];
+    int a_off[4][2], b_off[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            a_off[i][kk] = lds_off<BK>(wr * 64 + i * 16 + frow, kk * 4 + fq);
-            b_off[i][kk] = lds_off<BK>(wc * 64 + i * 16 + frow, kk * 4 + fq);
+        for (int half = 0; half < 2; ++half) {
+            a_off[i][half] = lds_off<64>(wr * 64 + i * 16 + frow, half * 4 + fq);
+            b_off[i][half] = TILE_BYTES + lds_off<64>(wc * 64 + i * 16 + frow, half * 4 + fq);
         }
 
     const int nk = p.K / BK;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         __syncthreads();  // hipcc drains vmcnt before the barrier: tile t has landed; stage cur^1 is free
-        if (t + 1 < nk && !(p.ablate & 1)) issue_tile(cur ^ 1, (t + 1) * BK);
+        if (t + 1 < nk && !(p.ablate & 1)) issue_tile(cur ^ 1, (t + 1) * 64);  // 64 elements = 128 bytes per tile row
         const char* base = smem + cur * STAGE_BYTES;
         if (p.ablate & 4) continue;
 #pragma unroll
@@ -267,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
             for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    af[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * TILE_BYTES + a_off[i][kk]);
-                    bfr[pl][i] = *reinterpret_cast<const bf16x8*>(base + (PLANES + pl) * TILE_BYTES + b_off[i][kk]);
+                    af[pl][i] = *reinterpret_cast<const bf16x8*>(base + a_off[i][PLANES == 1 ? kk : pl]);
+                    bfr[pl][i] = *reinterpret_cast<const bf16x8*>(base + b_off[i][PLANES == 1 ? kk : pl]);
                 }
             if (p.ablate & 2) {
 #pragma unroll

@@ -12,10 +12,10 @@ enum GemmEpilogue : int {
 };
 
 struct GemmParams {
-    // operands: A[planes][M][lda], W[planes][Npad][K]  (bf16, K-contiguous)
+    // operands (bf16, K-contiguous) in the A-operand layout of the mode (common.h a_pos): fast A[M][lda], W[Npad][K];
+    // parity A[M][2*lda], W[Npad][2*K] with hi/lo interleaved per 32-k block.  lda / K are LOGICAL k counts.
     const bf16* A;
     const bf16* W;
-    int64_t a_plane, w_plane;
     int lda;
     int M, N, K;
     const float* bias;  // [N] or nullptr

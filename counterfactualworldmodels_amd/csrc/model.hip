@@ -150,7 +150,7 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     pg.out = m->patches; pg.out_plane = (int64_t)B * Nv * m->patch_kpad; pg.ld = m->patch_kpad;
     if ((rc = launch_patch_gather(pg, planes, s))) return rc;
 
-    GemmParams g = gemm_base(m->patches, pg.out_plane, m->patch_kpad, m->patch, B * Nv);
+    GemmParams g = gemm_base(m->patches, m->patch_kpad, m->patch, B * Nv, planes);
     g.epi = EPI_F32; g.C = m->x_enc; g.ldc = c.enc_dim;
     g.resid = m->pos_enc; g.ldr = c.enc_dim; g.resid_rowmap = m->perm; g.rows_in = Nv; g.rows_out = Nv; g.map_stride = Nt;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
@@ -165,7 +165,7 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     ln.x = m->x_enc; ln.ldx = c.enc_dim; ln.gamma = m->enc_norm_g; ln.beta = m->enc_norm_b; ln.eps = c.ln_eps; ln.D = c.enc_dim;
     ln.rows = B * Nv; ln.out = m->sb.hbuf; ln.out_plane = (int64_t)B * Nv * c.enc_dim; ln.ldo = c.enc_dim;
     if ((rc = launch_layernorm(ln, planes, s))) return rc;
-    g = gemm_base(m->sb.hbuf, ln.out_plane, c.enc_dim, m->e2d, B * Nv);
+    g = gemm_base(m->sb.hbuf, c.enc_dim, m->e2d, B * Nv, planes);
     g.epi = EPI_F32; g.C = m->x_dec; g.ldc = c.dec_dim;
     g.resid = m->pos_dec; g.ldr = c.dec_dim; g.resid_rowmap = m->perm; g.rows_in = Nv; g.rows_out = Nt; g.map_stride = Nt;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
@@ -179,7 +179,7 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     ln.rows = B * Nm; ln.rows_out_per_b = Nm; ln.rows_in_per_b = Nt; ln.in_offset = Nv;
     ln.out = m->sb.hbuf; ln.out_plane = (int64_t)B * Nm * c.dec_dim; ln.ldo = c.dec_dim;
     if ((rc = launch_layernorm(ln, planes, s))) return rc;
-    g = gemm_base(m->sb.hbuf, ln.out_plane, c.dec_dim, m->head, B * Nm);
+    g = gemm_base(m->sb.hbuf, c.dec_dim, m->head, B * Nm, planes);
     g.epi = EPI_F32; g.C = a->y_tokens_dev; g.ldc = m->out_dim;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
 
@@ -238,15 +238,18 @@ struct Scratch {
     }
 };
 
-__global__ void pad_split_rows_kernel(const float* src, int rows, int K, bf16* hi, bf16* lo, int Kpad) {
+// fp32 [rows][K] -> GEMM A-operand layout of the given mode (common.h a_pos), K zero-padded to Kpad
+template <int PLANES>
+__global__ void pad_split_rows_kernel(const float* src, int rows, int K, bf16* out, int Kpad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)rows * Kpad) return;
     const int r = (int)(i / Kpad), k = (int)(i - (int64_t)r * Kpad);
     const float v = k < K ? src[(size_t)r * K + k] : 0.f;
     bf16 h, l;
     split_bf16(v, h, l);
-    hi[i] = h;
-    lo[i] = l;
+    bf16* d = out + a_pos<PLANES>(r, Kpad, k);
+    d[0] = h;
+    if constexpr (PLANES == 2) d[kLoOffset] = l;
 }
 
 // qkv [B,N,3,H,64] fp32 -> Q (scaled), K [B*H,N,64], V^T [B*H,64,n_pad]
@@ -275,10 +278,14 @@ __global__ void qkv_scatter_kernel(const float* qkv, int B, int N, int H, int n_
     }
 }
 
-__global__ void merge_planes_kernel(const bf16* hi, const bf16* lo, float* out, int64_t n) {
+// GEMM A-operand layout -> fp32 [rows][ld]
+template <int PLANES>
+__global__ void merge_planes_kernel(const bf16* in, float* out, int rows, int ld) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    out[i] = (float)hi[i] + (lo ? (float)lo[i] : 0.f);
+    if (i >= (int64_t)rows * ld) return;
+    const int r = (int)(i / ld), c = (int)(i - (int64_t)r * ld);
+    const bf16* s = in + a_pos<PLANES>(r, ld, c);
+    out[i] = (float)s[0] + (PLANES == 2 ? (float)s[kLoOffset] : 0.f);
 }
 }  // namespace
 
@@ -300,23 +307,29 @@ extern "C" int cwm_linear(const float* a_dev, const float* w_dev, const float* b
     float* bias = sc.get<float>(Np, true);
     bf16* G = gelu ? sc.get<bf16>((size_t)2 * M * N) : nullptr;
     CWM_REQUIRE(A && W && bias && (!gelu || G), "cwm_linear: out of device memory");
-    hipLaunchKernelGGL(pad_split_rows_kernel, dim3((unsigned)(((int64_t)M * Kp + 255) / 256)), dim3(256), 0, s, a_dev, M, K, A,
-                       A + (size_t)M * Kp, Kp);
-    if (int rc = launch_pack_weight(w_dev, N, K, W, W + (size_t)Np * Kp, Np, Kp, s)) return rc;
+    const unsigned gridA = (unsigned)(((int64_t)M * Kp + 255) / 256);
+    if (planes == 2)
+        hipLaunchKernelGGL(pad_split_rows_kernel<2>, dim3(gridA), dim3(256), 0, s, a_dev, M, K, A, Kp);
+    else
+        hipLaunchKernelGGL(pad_split_rows_kernel<1>, dim3(gridA), dim3(256), 0, s, a_dev, M, K, A, Kp);
+    if (int rc = launch_pack_weight(w_dev, N, K, planes == 1 ? W : nullptr, planes == 2 ? W : nullptr, Np, Kp, s)) return rc;
     if (bias_dev) CWM_HIP_CHECK(hipMemcpyAsync(bias, bias_dev, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, s));
     GemmParams p;
     memset(&p, 0, sizeof(p));
-    p.A = A; p.a_plane = (int64_t)M * Kp; p.lda = Kp; p.W = W; p.w_plane = (int64_t)Np * Kp;
+    p.A = A; p.lda = Kp; p.W = W;
     p.M = M; p.N = N; p.K = Kp; p.bias = bias;
     if (gelu) {
-        p.epi = EPI_BF16_GELU; p.out_hi = G; p.out_plane = (int64_t)M * N; p.ldo = N;
+        p.epi = EPI_BF16_GELU; p.out_hi = G; p.ldo = N;
     } else {
         p.epi = EPI_F32; p.C = c_dev; p.ldc = N; p.resid = resid_dev; p.ldr = N;
     }
     if (int rc = launch_gemm(p, planes, s)) return rc;
     if (gelu) {
-        const int64_t n = (int64_t)M * N;
-        hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, G, planes == 2 ? G + n : nullptr, c_dev, n);
+        const unsigned gridG = (unsigned)(((int64_t)M * N + 255) / 256);
+        if (planes == 2)
+            hipLaunchKernelGGL(merge_planes_kernel<2>, dim3(gridG), dim3(256), 0, s, G, c_dev, M, N);
+        else
+            hipLaunchKernelGGL(merge_planes_kernel<1>, dim3(gridG), dim3(256), 0, s, G, c_dev, M, N);
     }
     CWM_HIP_CHECK(hipStreamSynchronize(s));
     return CWM_OK;
@@ -345,8 +358,10 @@ extern "C" int cwm_attention(const float* qkv_dev, float* o_dev, int B, int N, i
     a.q = q; a.k = k; a.vt = vt; a.qk_plane = qk_plane; a.vt_plane = vt_plane; a.o = o; a.o_plane = qk_plane; a.ldo = D;
     a.n_tok = N; a.n_pad = n_pad; a.heads = H; a.batch = B;
     if (int rc = launch_attention(a, planes, s)) return rc;
-    hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)((qk_plane + 255) / 256)), dim3(256), 0, s, o, planes == 2 ? o + qk_plane : nullptr,
-                       o_dev, qk_plane);
+    if (planes == 2)
+        hipLaunchKernelGGL(merge_planes_kernel<2>, dim3((unsigned)((qk_plane + 255) / 256)), dim3(256), 0, s, o, o_dev, B * N, D);
+    else
+        hipLaunchKernelGGL(merge_planes_kernel<1>, dim3((unsigned)((qk_plane + 255) / 256)), dim3(256), 0, s, o, o_dev, B * N, D);
     CWM_HIP_CHECK(hipStreamSynchronize(s));
     return CWM_OK;
 }
@@ -481,10 +496,10 @@ extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters,
     fill_f32(Cm, (int64_t)M * N, 4, 1.0f);
     GemmParams p;
     memset(&p, 0, sizeof(p));
-    p.A = A; p.a_plane = (int64_t)M * Kp; p.lda = Kp; p.W = W; p.w_plane = (int64_t)Np * Kp;
+    p.A = A; p.lda = Kp; p.W = W;
     p.M = M; p.N = N; p.K = Kp; p.bias = bias;
     if (epi == 1) {
-        p.epi = EPI_BF16_GELU; p.out_hi = G; p.out_plane = (int64_t)M * N; p.ldo = N;
+        p.epi = EPI_BF16_GELU; p.out_hi = G; p.ldo = N;
     } else if (epi == 3) {
         CWM_REQUIRE(N % 192 == 0, "cwm_bench_gemm: QKV epilogue needs N = 3*64*heads");
         const int D = N / 3, H = D / 64, n_tok = 792 <= M && M % 792 == 0 ? 792 : M, B = M / n_tok;
