@@ -72,7 +72,7 @@ int Engine::free_workspace() {
 int Engine::make_linear(LinearW& L, int N, int K, bool bias) {
     L.N = N;
     L.K = K;
-    L.Npad = round_up(N, 128);
+    L.Npad = round_up(N, 256);
     L.Kpad = round_up(K, 64);
     L.plane = (int64_t)L.Npad * L.Kpad;
     void* p;

@@ -17,9 +17,9 @@
 //   tile rows are full cache lines in both modes (64-byte half-line DMA requests filled LDS ~1.5x slower)
 // * XCD-aware, grouped tile order so that co-resident tiles of one XCD share A panels / W tiles in L2
 // * accumulators are kept TRANSPOSED (D^T = W_frag . A_frag^T): a lane then owns 4 consecutive output
-//   columns of one row, so every epilogue access is a 16-byte (fp32) / 8-byte (bf16) vector; the V third
-//   of the QKV projection uses the plain orientation instead (4 consecutive tokens per lane) because it
-//   is stored transposed ([head][d][token]) for the attention kernel
+//   columns of one row, so epilogue accesses are 16-byte (fp32) / 8-byte (bf16) vectors (the V third of
+//   the QKV projection, stored transposed [head][d][token] for the attention kernel, uses 2-byte stores
+//   that form 32-byte runs across the 16 lanes of a group)
 // * fused epilogues: bias, residual(+row map), exact-erf GELU, bf16 hi/lo split, QKV head scatter
 #include "common.h"
 #include "kernels.h"
@@ -83,17 +83,17 @@ __device__ __forceinline__ RowMap map_row(const GemmParams& p, int m) {
 }
 
 // Transposed accumulators: acc[i][j][r] = C[m0 + wr*64 + i*16 + (lane&15)][n0 + wc*64 + j*16 + (lane>>4)*4 + r]
-template <int PLANES>
-__device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int wr, int wc, int lane) {
+template <int PLANES, int FM, int FN>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (&acc)[FM][FN], int m0, int n0, int wr, int wc, int lane) {
     const int ncol = (lane >> 4) * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wr * (16 * FM) + i * 16 + (lane & 15);
         if (m >= p.M) continue;
         const RowMap rm = map_row(p, m);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nb = n0 + wc * 64 + j * 16;  // fragment's first column (wave-uniform)
+        for (int j = 0; j < FN; ++j) {
+            const int nb = n0 + wc * (16 * FN) + j * 16;  // fragment's first column (wave-uniform)
             if (nb >= p.N) continue;
             const int n = nb + ncol;
             f32x4 v = acc[i][j];
@@ -106,9 +106,21 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
                 int64_t plane;
                 if (p.epi == EPI_QKV) {
                     const int D = p.qkv_dim;
-                    const int which = nb / D;  // 0 q, 1 k (v tiles take epilogue_cols)
+                    const int which = nb / D;  // 0 q, 1 k, 2 v (uniform per 16-column fragment)
                     const int c = n - which * D;
                     const int h = c / p.head_dim, d = c - h * p.head_dim;
+                    if (which == 2) {
+                        // V is stored transposed for the attention kernel: V^T[(b,h)][d][token].  The lane's 4 values are
+                        // 4 consecutive d of one token; the 16 lanes of a group cover 16 consecutive tokens (32-byte runs).
+                        bf16* vd = p.vt_out + ((size_t)(rm.b * p.heads + h) * p.head_dim + d) * p.n_pad + rm.tok;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bf16 hi = (bf16)v[r];
+                            vd[(size_t)r * p.n_pad] = hi;
+                            if constexpr (PLANES == 2) vd[(size_t)r * p.n_pad + p.vt_plane] = (bf16)(v[r] - (float)hi);
+                        }
+                        continue;
+                    }
                     if (which == 0) v *= p.q_scale;
                     dst = (which == 0 ? p.q_out : p.k_out) + ((size_t)(rm.b * p.heads + h) * p.n_tok + rm.tok) * p.head_dim + d;
                     plane = p.qk_plane;
@@ -134,74 +146,37 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
     }
 }
 
-// Plain accumulators (V tiles of the QKV projection):
-// acc[i][j][r] = C[m0 + wr*64 + i*16 + (lane>>4)*4 + r][n0 + wc*64 + j*16 + (lane&15)]  -> V^T[(b,h)][d][token]
-template <int PLANES>
-__device__ __forceinline__ void epilogue_cols_vt(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int wr, int wc, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int mbase = m0 + wr * 64 + i * 16 + (lane >> 4) * 4;
-        if (mbase >= p.M) continue;
-        const int b0 = mbase / p.n_tok, tok0 = mbase - b0 * p.n_tok;
-        const bool vec = (mbase + 3 < p.M) && (tok0 + 3 < p.n_tok) && ((tok0 & 3) == 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nb = n0 + wc * 64 + j * 16;
-            if (nb >= p.N) continue;
-            const int n = nb + (lane & 15);
-            const float bias = p.bias ? p.bias[n] : 0.f;
-            const int c = n - 2 * p.qkv_dim;
-            const int h = c / p.head_dim, d = c - h * p.head_dim;
-            bf16x4 hv, lv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = acc[i][j][r] + bias;
-                const bf16 hi = (bf16)v;
-                hv[r] = hi;
-                lv[r] = (bf16)(v - (float)hi);
-            }
-            if (vec) {
-                bf16* dst = p.vt_out + ((size_t)(b0 * p.heads + h) * p.head_dim + d) * p.n_pad + tok0;
-                *reinterpret_cast<bf16x4*>(dst) = hv;
-                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + p.vt_plane) = lv;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = mbase + r;
-                    if (m < p.M) {
-                        const int b = m / p.n_tok, tok = m - b * p.n_tok;
-                        bf16* dst = p.vt_out + ((size_t)(b * p.heads + h) * p.head_dim + d) * p.n_pad + tok;
-                        *dst = hv[r];
-                        if constexpr (PLANES == 2) dst[p.vt_plane] = lv[r];
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int PLANES>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
-    constexpr int BM = 128, BN = 128;
+// Tile configurations (BM x BN output tile, WM x WN waves, each wave FM x FN MFMA fragments of 16x16):
+//   128x128, 2x2 waves (64x64 per wave)  : 64 KiB LDS, two workgroups per CU         -- small / odd shapes
+//   256x128, 4x2 waves (64x64 per wave)  : 96 KiB LDS, one 512-thread workgroup / CU
+//   256x256, 2x4 waves (128x64 per wave) : 128 KiB LDS, one 512-thread workgroup / CU -- highest FLOP per staged byte
+// The LDS fill (LDS-DMA pieces of 8 rows x 128 B) is the scarce resource (~25 B/clk/CU measured), so bigger
+// tiles raise the MFMA ceiling: per K tile a workgroup stages (BM+BN)*128 B and runs BM*BN/256*{2|3} MFMAs.
+template <int PLANES, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void gemm_bf16_kernel(const GemmParams p) {
+    constexpr int NWAVES = WM * WN;
+    constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     // every K tile row is one 128-byte line in LDS and in memory: 64 k of the single plane (fast), or
     // 32 k as [32 hi | 32 lo] (parity, interleaved operand layout: common.h a_pos)
-    constexpr int BK = 64 / PLANES;    // logical k per tile
-    constexpr int NI = BM / 8 / 4;     // 1-KiB DMA pieces (8 rows each) per wave per operand
-    constexpr int TILE_BYTES = BM * 128;
-    constexpr int STAGE_BYTES = TILE_BYTES * 2;
+    constexpr int BK = 64 / PLANES;           // logical k per tile
+    constexpr int NIA = BM / 8 / NWAVES;      // 1-KiB DMA pieces (8 rows each) per wave, A operand
+    constexpr int NIB = BN / 8 / NWAVES;      // ... W operand
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static_assert(NIA >= 1 && NIB >= 1, "tile too small for the wave count");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
 
     // ---- tile selection: XCD chunking + GROUP_M-grouped order --------------------------------
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;
     const int id = xcd_remap(blockIdx.x, ntiles);
-    constexpr int GROUP_M = 8;
+    constexpr int GROUP_M = (BM == 128) ? 8 : 4;
     const int group_sz = GROUP_M * tiles_n;
     const int g = id / group_sz;
     const int first_m = g * GROUP_M;
@@ -211,105 +186,101 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     const int tile_n = in_g / gm;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- per-lane source pointers of this wave's DMA pieces (piece j covers tile rows RPI*j ...) ----
-    const bf16* a_src[NI];
-    const bf16* w_src[NI];
+    // ---- per-lane source pointers of this wave's DMA pieces (piece j covers tile rows 8j .. 8j+7) ----
+    // (32-bit element offsets from the uniform base pointers: one VGPR per piece instead of a 64-bit pointer)
+    unsigned a_src[NIA], w_src[NIB];
 #pragma unroll
-    for (int jj = 0; jj < NI; ++jj) {
-        const int row = (wave * NI + jj) * 8 + lane / 8;
+    for (int jj = 0; jj < NIA; ++jj) {
+        const int row = (wave * NIA + jj) * 8 + lane / 8;
         const int logical = (lane % 8) ^ lds_swizzle<64>(row);
-        a_src[jj] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda * PLANES + logical * 8;
-        w_src[jj] = p.W + (size_t)(n0 + row) * p.K * PLANES + logical * 8;
+        a_src[jj] = (unsigned)min(m0 + row, p.M - 1) * (unsigned)(p.lda * PLANES) + logical * 8;
+    }
+#pragma unroll
+    for (int jj = 0; jj < NIB; ++jj) {
+        const int row = (wave * NIB + jj) * 8 + lane / 8;
+        const int logical = (lane % 8) ^ lds_swizzle<64>(row);
+        w_src[jj] = (unsigned)(n0 + row) * (unsigned)(p.K * PLANES) + logical * 8;
     }
     auto issue_tile = [&](int stage, int k0) {
+        char* sb = smem + stage * STAGE_BYTES;
+        const bf16* ab = p.A + k0;
+        const bf16* wb = p.W + k0;
 #pragma unroll
-        for (int jj = 0; jj < NI; ++jj) {
-            const int j = wave * NI + jj;
-            char* da = smem + stage * STAGE_BYTES + j * 1024;
-            char* dw = smem + stage * STAGE_BYTES + TILE_BYTES + j * 1024;
-            __builtin_amdgcn_global_load_lds((gbl_void*)(a_src[jj] + k0), (lds_void*)da, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(w_src[jj] + k0), (lds_void*)dw, 16, 0, 0);
-        }
+        for (int jj = 0; jj < NIA; ++jj)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(ab + a_src[jj]), (lds_void*)(sb + (wave * NIA + jj) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int jj = 0; jj < NIB; ++jj)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wb + w_src[jj]), (lds_void*)(sb + A_BYTES + (wave * NIB + jj) * 1024), 16, 0, 0);
     };
 
-    // the V third of a QKV projection is accumulated in the plain orientation (block-uniform choice)
-    const bool plain = (p.epi == EPI_QKV) && (n0 >= 2 * p.qkv_dim);
-
-    f32x4 acc[4][4];
+    f32x4 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // fragment read offsets (row within tile, k-chunk within a 32-wide k-step)
     // 16-byte chunks of a 128-byte row: fast = [k 0..31 | k 32..63] -> two k-steps; parity = [hi | lo] of one k-step
+    // The XOR swizzle only involves (row >> 1) & 7 = (frow >> 1) & 7 for every fragment (fragment rows start at
+    // multiples of 16), so fragment i sits at a compile-time 2-KiB stride from fragment 0: two base registers per operand.
     const int frow = lane & 15, fq = lane >> 4;
-    int a_off[4][2], b_off[4][2];
+    int a_base[2], b_base[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            a_off[i][half] = lds_off<64>(wr * 64 + i * 16 + frow, half * 4 + fq);
-            b_off[i][half] = TILE_BYTES + lds_off<64>(wc * 64 + i * 16 + frow, half * 4 + fq);
-        }
+    for (int half = 0; half < 2; ++half) {
+        a_base[half] = lds_off<64>(wr * (16 * FM) + frow, half * 4 + fq);
+        b_base[half] = A_BYTES + lds_off<64>(wc * (16 * FN) + frow, half * 4 + fq);
+    }
 
     const int nk = p.K / BK;
     issue_tile(0, 0);
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         __syncthreads();  // hipcc drains vmcnt before the barrier: tile t has landed; stage cur^1 is free
-        if (t + 1 < nk && !(p.ablate & 1)) issue_tile(cur ^ 1, (t + 1) * 64);  // 64 elements = 128 bytes per tile row
+        if (t + 1 < nk) issue_tile(cur ^ 1, (t + 1) * 64);  // 64 elements = 128 bytes per tile row
         const char* base = smem + cur * STAGE_BYTES;
-        if (p.ablate & 4) continue;
+        // Software-pipelined fragment reads: a "unit" is one 16-row A fragment (hi[, lo]) against all FN column
+        // fragments = FN (fast) / 3 FN (parity) MFMAs.  The A fragments of unit u+DIST are requested before the
+        // MFMAs of unit u are issued, so LDS latency hides behind MFMA issue instead of stalling every group.
+        constexpr int KSTEPS = BK / 32, UNITS = KSTEPS * FM, DIST = (PLANES == 1) ? 3 : 2;
+        bf16x8 bfr[KSTEPS][PLANES][FN];
+        bf16x8 afu[UNITS][PLANES];
 #pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            bf16x8 af[PLANES][4], bfr[PLANES][4];
+        for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bfr[0][pl][j] = *reinterpret_cast<const bf16x8*>(base + b_base[pl] + j * 2048);
+#pragma unroll
+        for (int u = 0; u < DIST && u < UNITS; ++u)
 #pragma unroll
             for (int pl = 0; pl < PLANES; ++pl)
+                afu[u][pl] = *reinterpret_cast<const bf16x8*>(base + a_base[PLANES == 1 ? u / FM : pl] + (u % FM) * 2048);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    af[pl][i] = *reinterpret_cast<const bf16x8*>(base + a_off[i][PLANES == 1 ? kk : pl]);
-                    bfr[pl][i] = *reinterpret_cast<const bf16x8*>(base + b_off[i][PLANES == 1 ? kk : pl]);
-                }
-            if (p.ablate & 2) {
+        for (int u = 0; u < UNITS; ++u) {
+            const int kk = u / FM, i = u % FM;
+            if (u + DIST < UNITS) {
 #pragma unroll
                 for (int pl = 0; pl < PLANES; ++pl)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[pl][i]), "v"(bfr[pl][i]));
-                continue;
+                    afu[u + DIST][pl] =
+                        *reinterpret_cast<const bf16x8*>(base + a_base[PLANES == 1 ? (u + DIST) / FM : pl] + ((u + DIST) % FM) * 2048);
             }
-            if (!plain) {
+            if (PLANES == 1 && KSTEPS == 2 && u == FM - DIST) {  // next k-step's W fragments, ahead of its first unit
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if constexpr (PLANES == 2) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], af[1][i], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], af[0][i], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], af[0][i], acc[i][j], 0, 0, 0);
-                    }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if constexpr (PLANES == 2) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[1][j], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
-                    }
+                for (int j = 0; j < FN; ++j) bfr[KSTEPS - 1][0][j] = *reinterpret_cast<const bf16x8*>(base + b_base[1] + j * 2048);
             }
+            // transposed accumulation D^T = W_frag . A_frag^T: the lane owns 4 consecutive output columns of one row
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (PLANES == 2) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][0][j], afu[u][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][1][j], afu[u][0], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][0][j], afu[u][0], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (!plain)
-        epilogue_rows<PLANES>(p, acc, m0, n0, wr, wc, lane);
-    else
-        epilogue_cols_vt<PLANES>(p, acc, m0, n0, wr, wc, lane);
+    epilogue_rows<PLANES, FM, FN>(p, acc, m0, n0, wr, wc, lane);
 }
 
-int g_gemm_ablate = 0;
+int g_gemm_tile = 0;  // 0 = automatic choice per shape
 
 int launch_gemm(const GemmParams& p, int planes, hipStream_t stream) {
     CWM_REQUIRE(planes == 1 || planes == 2, "gemm: planes must be 1 or 2");
@@ -321,24 +292,36 @@ int launch_gemm(const GemmParams& p, int planes, hipStream_t stream) {
         CWM_REQUIRE(p.ldc % 4 == 0 && (!p.resid || p.ldr % 4 == 0), "gemm: ldc/ldr must be multiples of 4");
     } else if (p.epi == EPI_QKV) {
         CWM_REQUIRE(p.rows_in == p.n_tok && p.N == 3 * p.qkv_dim && p.head_dim % 4 == 0, "gemm: bad QKV epilogue setup");
-        CWM_REQUIRE(p.qkv_dim % 128 == 0, "gemm: QKV epilogue needs the model width (%d) to be a multiple of the 128-column tile", p.qkv_dim);
+        CWM_REQUIRE(p.qkv_dim % 16 == 0, "gemm: QKV epilogue needs the model width (%d) to be a multiple of 16", p.qkv_dim);
         CWM_REQUIRE(p.n_pad % 4 == 0, "gemm: n_pad must be a multiple of 4");
     } else {
         CWM_REQUIRE(p.ldo % 4 == 0, "gemm: ldo must be a multiple of 4");
     }
-    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-    const size_t smem = 65536;
-    typedef void (*kern_t)(const GemmParams);
-    static const kern_t kerns[2] = {gemm_bf16_kernel<1>, gemm_bf16_kernel<2>};
-    static bool attr_done[2] = {false, false};
-    kern_t k = kerns[planes - 1];
-    if (!attr_done[planes - 1]) {
-        CWM_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done[planes - 1] = true;
+    // ---- tile configuration: biggest tile whose grid still fills the chip reasonably ----
+    int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256
+    if (cfg == 0) {
+        // Measured on MI355X (tools/microbench.py, B/8 batch-32 shapes, both modes): wide outputs (N >= 1024: qkv, fc1)
+        // run best on the 256x256 tile; N <= 768 (proj, fc2, head, patch embed) on 128x128 with two workgroups per CU,
+        // whose epilogue overlaps the co-resident workgroup's main loop and whose grid quantises better.
+        cfg = (p.N >= 1024 && p.M >= 512) ? 3 : 1;
     }
-    GemmParams pp = p;
-    pp.ablate = g_gemm_ablate;
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, pp);
+    typedef void (*kern_t)(const GemmParams);
+    static const kern_t kerns[3][2] = {
+        {gemm_bf16_kernel<1, 128, 128, 2, 2>, gemm_bf16_kernel<2, 128, 128, 2, 2>},
+        {gemm_bf16_kernel<1, 256, 128, 4, 2>, gemm_bf16_kernel<2, 256, 128, 4, 2>},
+        {gemm_bf16_kernel<1, 256, 256, 2, 4>, gemm_bf16_kernel<2, 256, 256, 2, 4>},
+    };
+    static const int bms[3] = {128, 256, 256}, bns[3] = {128, 128, 256}, threads[3] = {256, 512, 512};
+    static bool attr_done[3][2] = {{false, false}, {false, false}, {false, false}};
+    const int ci = cfg - 1;
+    const size_t smem = (size_t)2 * (bms[ci] + bns[ci]) * 128;
+    const int tiles = ((p.M + bms[ci] - 1) / bms[ci]) * ((p.N + bns[ci] - 1) / bns[ci]);
+    kern_t k = kerns[ci][planes - 1];
+    if (!attr_done[ci][planes - 1]) {
+        CWM_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done[ci][planes - 1] = true;
+    }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(threads[ci]), smem, stream, p);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }

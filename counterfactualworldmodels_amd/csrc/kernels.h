@@ -40,11 +40,10 @@ struct GemmParams {
     int64_t qk_plane, vt_plane;
     int qkv_dim, heads, head_dim, n_tok, n_pad;
     float q_scale;
-    int ablate;  // debug: 1 skip tile loads, 2 skip MFMAs, 4 skip LDS reads + MFMAs (timing-only builds of the loop)
 };
 
 int launch_gemm(const GemmParams& p, int planes, hipStream_t stream);
-extern int g_gemm_ablate;  // debug: see GemmParams::ablate
+extern int g_gemm_tile;    // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256 output tile
 
 struct AttnParams {
     const bf16* q;   // [planes][B*H][N][64]   (q pre-scaled by hd^-0.5)

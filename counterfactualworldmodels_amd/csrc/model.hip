@@ -300,7 +300,7 @@ extern "C" int cwm_linear(const float* a_dev, const float* w_dev, const float* b
     CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_linear: bad mode");
     hipStream_t s = (hipStream_t)stream;
     const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
-    const int Kp = round_up(K, 64), Np = round_up(N, 128);
+    const int Kp = round_up(K, 64), Np = round_up(N, 256);
     Scratch sc;
     bf16* A = sc.get<bf16>((size_t)2 * M * Kp);
     bf16* W = sc.get<bf16>((size_t)2 * Np * Kp);
@@ -468,8 +468,8 @@ void fill_f32(float* d, int64_t n, unsigned seed, float scale) {
 
 extern "C" int cwm_debug_set(const char* key, int value) {
     CWM_REQUIRE(key, "cwm_debug_set: null key");
-    if (!strcmp(key, "gemm_ablate")) {
-        g_gemm_ablate = value;
+    if (!strcmp(key, "gemm_tile")) {
+        g_gemm_tile = value;
         return CWM_OK;
     }
     cwm_set_error("cwm_debug_set: unknown key %s", key);
@@ -480,7 +480,7 @@ extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters,
     CWM_REQUIRE(avg_us && M > 0 && N > 0 && K > 0 && iters > 0, "cwm_bench_gemm: bad argument");
     CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_bench_gemm: bad mode");
     const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
-    const int Kp = round_up(K, 64), Np = round_up(N, 128);
+    const int Kp = round_up(K, 64), Np = round_up(N, 256);
     Scratch sc;
     bf16* A = sc.get<bf16>((size_t)2 * M * Kp);
     bf16* W = sc.get<bf16>((size_t)2 * Np * Kp);

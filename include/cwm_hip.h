@@ -182,7 +182,7 @@ int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int
  * Runs `iters` back-to-back launches after 3 warm-up launches and returns the mean launch time. */
 int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters, double* avg_us);
 int cwm_bench_attention(int B, int H, int N, int mode, int iters, double* avg_us);
-/* development switches: "gemm_ablate" (bit 0 skip tile loads, bit 1 skip MFMAs, bit 2 skip LDS reads): timing only */
+/* development switches: "gemm_tile" (0 automatic per shape, 1: 128x128, 2: 256x128, 3: 256x256 output tile) */
 int cwm_debug_set(const char* key, int value);
 
 const char* cwm_last_error(void);

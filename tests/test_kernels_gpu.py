@@ -164,3 +164,24 @@ def test_unembed_bit_exact_golden(gu):
     n_vis = m.shape[1] - int(m[0].sum())
     _lib.check(lib.cwm_unembed(y.data_ptr(), x.data_ptr(), m.data_ptr(), B, T, Cc, H, W, 8, n_vis, out.data_ptr(), gu.stream()))
     assert np.array_equal(out.cpu().numpy(), g["unembed_video"])
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_gemm_tile_configurations_agree(gu, tile):
+    """All output-tile configurations of the GEMM (128x128, 256x128, 256x256) give the same result."""
+    lib = _lib.get_lib()
+    try:
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", tile))
+        for mode in ("parity", "fast"):
+            for (M, N, K) in [(300, 768, 192), (1000, 1152, 384), (77, 48, 512), (700, 256, 64), (513, 384, 1536)]:
+                a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+                out = gu.linear(a, w, b, mode=mode)
+                err = (out - F.linear(a, w, b)).abs().max().item()
+                assert err <= TOL[mode], (tile, mode, M, N, K, err)
+        g = torch.Generator().manual_seed(9)
+        a = torch.randint(-4, 5, (300, 128), generator=g).float()
+        w = torch.randint(-4, 5, (272, 128), generator=g).float()
+        assert torch.equal(gu.linear(a, w, None, mode="parity"), a @ w.t())
+        assert torch.equal(gu.linear(a, w, None, mode="fast"), a @ w.t())
+    finally:
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))

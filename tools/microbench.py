@@ -28,7 +28,7 @@ ATTN_SHAPES = [("b8.enc", 32, 12, 792), ("b8.dec", 32, 6, 1568), ("l4.enc", 8, 1
 
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-    variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
+    variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3").split(",")]
     torch.cuda.init()
     lib = _lib.get_lib()
     us = C.c_double()
@@ -37,11 +37,12 @@ def main():
             for mode in ("fast", "parity"):
                 row = []
                 for v in variants:
+                    _lib.check(lib.cwm_debug_set(b"gemm_tile", v))
                     best = 1e30
                     for _ in range(3):
                         _lib.check(lib.cwm_bench_gemm(M, N, K, _lib.mode_id(mode), epi, 20, C.byref(us)))
                         best = min(best, us.value)
-                    row.append("v%d %8.1f us %7.1f TF" % (v, best, 2.0 * M * N * K / best / 1e6))
+                    row.append("t%d %7.1f us %6.1f TF" % (v, best, 2.0 * M * N * K / best / 1e6))
                 print("%-12s %-6s M=%d N=%d K=%d  %s" % (name, mode, M, N, K, " | ".join(row)), flush=True)
     else:
         for name, B, H, N in ATTN_SHAPES:
