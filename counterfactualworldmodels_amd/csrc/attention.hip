@@ -11,8 +11,7 @@
 //      converted to bf16 in place (accumulator-as-operand; k order permuted, matched on the V^T reads)
 //   -> the running rescale factor alpha[q] is lane-local as well.
 // K and V^T tiles (64 keys) are double-buffered in LDS with register-staged prefetch of tile t+1
-// issued before the MFMAs of tile t.  LDS images are XOR-swizzled for conflict-free ds_read_b128 /
-// ds_read_b64.  PLANES==2 is the split-bf16 "parity" mode (hi*hi + hi*lo + lo*hi for both products).
+// issued before the MFMAs of tile t.  LDS images are XOR-swizzled for conflict-free ds_read_b128.  PLANES==2 is the split-bf16 "parity" mode (hi*hi + hi*lo + lo*hi for both products).
 #include "common.h"
 #include "kernels.h"
 
@@ -51,14 +50,19 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     }
 
     // ---- staging bookkeeping: 512 16-byte chunks per tile, 2 per thread --------------------------
-    int st_row[2], st_chunk[2], st_koff[2], st_voff[2];
+    // V^T tile image: within every 16-key group the 8-byte quarters are stored as [k0-3 | k8-11 | k4-7 | k12-15], so the
+    // PV A-operand of lane half hh (keys 16 ks + 4 hh + {0..3} and 16 ks + 8 + 4 hh + {0..3}, the k order of the
+    // accumulator-as-operand trick) is ONE aligned 16-byte chunk (2 ks + hh): a conflict-free ds_read_b128 like K.
+    // A staged global chunk g (keys 8g..8g+7) therefore lands as two 8-byte halves in chunks (g & ~1) and (g & ~1) + 1.
+    int st_row[2], st_chunk[2], st_koff[2], st_voff0[2], st_voff1[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + i * 256;
         st_row[i] = idx >> 3;
         st_chunk[i] = idx & 7;
         st_koff[i] = lds_off128(st_row[i], st_chunk[i]);
-        st_voff[i] = lds_off128(st_row[i], st_chunk[i]);
+        st_voff0[i] = lds_off128(st_row[i], st_chunk[i] & ~1) + (st_chunk[i] & 1) * 8;
+        st_voff1[i] = lds_off128(st_row[i], (st_chunk[i] & ~1) + 1) + (st_chunk[i] & 1) * 8;
     }
     u32x4 rk[PLANES][2], rv[PLANES][2];
     auto load_tiles = [&](int kt) {
@@ -86,9 +90,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
 #pragma unroll
             for (int pl = 0; pl < PLANES; ++pl) {
                 *reinterpret_cast<u32x4*>(base + pl * TILE_BYTES + st_koff[i]) = rk[pl][i];
-                u32x4 v = rv[pl][i];
-                if (st_row[i] & 16) v = __builtin_shufflevector(v, v, 2, 3, 0, 1);  // swap the 8-byte halves (bank spread)
-                *reinterpret_cast<u32x4*>(base + (PLANES + pl) * TILE_BYTES + st_voff[i]) = v;
+                const u32x4 v = rv[pl][i];
+                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                *reinterpret_cast<u32x2*>(base + (PLANES + pl) * TILE_BYTES + st_voff0[i]) = u32x2{v[0], v[1]};
+                *reinterpret_cast<u32x2*>(base + (PLANES + pl) * TILE_BYTES + st_voff1[i]) = u32x2{v[2], v[3]};
             }
     };
 
@@ -99,18 +104,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int s = 0; s < 4; ++s) k_off[kb][s] = lds_off128(kb * 32 + qcol, 2 * s + hh);
-    // V^T (A operand of O^T): row = d = db*32 + qcol; k-step ks needs keys 16 ks + 4 hh + {0..3}
-    // (chunk 2 ks, half hh) and 16 ks + 8 + 4 hh + {0..3} (chunk 2 ks + 1, half hh)
-    int v_off[2][4][2];
+    // V^T (A operand of O^T): row = d = db*32 + qcol, 16-byte chunk 2 ks + hh (see the tile image above)
+    int v_off[2][4];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int d = db * 32 + qcol;
-                v_off[db][ks][c] = lds_off128(d, 2 * ks + c) + ((hh ^ ((d >> 4) & 1)) << 3);
-            }
+        for (int ks = 0; ks < 4; ++ks) v_off[db][ks] = lds_off128(db * 32 + qcol, 2 * ks + hh);
 
     f32x16 oacc[2];
 #pragma unroll
@@ -165,7 +164,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+        // the running maximum rarely moves after the first tiles: skip the rescale of O and l (alpha would be exactly 1)
+        const bool grew = __any(m_new > m_run);
+        const float alpha = grew ? __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e) : 1.0f;
         m_run = m_new;
         const float mc = m_new * kLog2e;
         float rowsum = 0.f;
@@ -178,10 +179,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
                 rowsum += pv;
             }
         l_run = l_run * alpha + rowsum;
+        if (grew) {
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        }
 
         // ---- O^T += V^T P^T  (P^T fragment of k-step ks = kb*2+s is sacc[kb][8s .. 8s+7]) --------
 #pragma unroll
@@ -198,13 +201,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const char* vb = base + PLANES * TILE_BYTES;
-                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vb + v_off[db][ks][0]);
-                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vb + v_off[db][ks][1]);
-                const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + v_off[db][ks]);
                 if constexpr (PLANES == 2) {
-                    const bf16x4 l0 = *reinterpret_cast<const bf16x4*>(vb + TILE_BYTES + v_off[db][ks][0]);
-                    const bf16x4 l1 = *reinterpret_cast<const bf16x4*>(vb + TILE_BYTES + v_off[db][ks][1]);
-                    const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vb + TILE_BYTES + v_off[db][ks]);
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc[db], 0, 0, 0);
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, plo, oacc[db], 0, 0, 0);
                 }
