@@ -7,17 +7,32 @@
 //   S^T[key][q] = K[key][:] . Q[q][:]       mfma_f32_32x32x16_bf16, A = K tile (LDS), B = Q (registers)
 //   -> every lane holds 16 keys of ONE query column, so the online-softmax row max / row sum are
 //      in-register reductions plus a single lane^32 exchange (wave shuffle)
-//   O^T[d][q]  += V^T[d][key] . P^T[key][q]  A = V^T tile (LDS), B = the S^T accumulator itself,
-//      converted to bf16 in place (accumulator-as-operand; k order permuted, matched on the V^T reads)
+//   O^T[d][q]  += V^T[d][key] . P^T[key][q]  A = V^T fragments, B = the S^T accumulator itself,
+//      converted to bf16 in place (accumulator-as-operand; k order permuted, matched on the V reads)
 //   -> the running rescale factor alpha[q] is lane-local as well.
-// K and V^T tiles (64 keys) are double-buffered in LDS with register-staged prefetch of tile t+1
-// issued before the MFMAs of tile t.  LDS images are XOR-swizzled for conflict-free ds_read_b128.  PLANES==2 is the split-bf16 "parity" mode (hi*hi + hi*lo + lo*hi for both products).
+// V is ROW-major in memory and in LDS ([key][d], like K -- the QKV projection writes Q, K and V with one
+// epilogue); the V^T fragments come from the hardware transpose read ds_read_b64_tr_b16: per 16-lane group a
+// block of 4 keys x 16 d is delivered column-major, i.e. a lane gets 4 consecutive keys of ONE d -- exactly one
+// half of the permuted k order {4 hh + 0..3, 8 + 4 hh + 0..3} the accumulator-as-operand trick asks for.
+// K and V tiles (64 keys) are double-buffered in LDS with register-staged prefetch of tile t+1
+// issued before the MFMAs of tile t.  LDS images are XOR-swizzled (K: conflict-free ds_read_b128; V: the four
+// key rows of a transposed read land on the four 64-byte quarters of the 256-byte bank row).
+// PLANES==2 is the split-bf16 "parity" mode (hi*hi + hi*lo + lo*hi for both products).
 #include "common.h"
 #include "kernels.h"
 
 namespace cwm {
 
 __device__ __forceinline__ int lds_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// V tile image: key row of 128 bytes, 16-byte chunk c (8 d) stored at c ^ 4 on key rows with bit 1 set
+__device__ __forceinline__ int lds_off_v(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x4 lds_read_tr16(const char* ptr) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr);
+    return __builtin_bit_cast(bf16x4, v);
+}
 
 template <int PLANES>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
@@ -36,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
 
     const bf16* Qb = p.q + (size_t)bh * N * 64;
     const bf16* Kb = p.k + (size_t)bh * N * 64;
-    const bf16* Vb = p.vt + (size_t)bh * 64 * p.n_pad;
+    const bf16* Vb = p.v + (size_t)bh * N * 64;
 
     // ---- Q fragments (B operand): lane (q = qcol, half hh) holds Q[q][16 s + 8 hh + 0..7] --------
     bf16x8 qf[PLANES][4];
@@ -49,37 +64,26 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
                 qf[pl][s] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)pl * p.qk_plane + (size_t)qrow * 64 + s * 16 + hh * 8);
     }
 
-    // ---- staging bookkeeping: 512 16-byte chunks per tile, 2 per thread --------------------------
-    // V^T tile image: within every 16-key group the 8-byte quarters are stored as [k0-3 | k8-11 | k4-7 | k12-15], so the
-    // PV A-operand of lane half hh (keys 16 ks + 4 hh + {0..3} and 16 ks + 8 + 4 hh + {0..3}, the k order of the
-    // accumulator-as-operand trick) is ONE aligned 16-byte chunk (2 ks + hh): a conflict-free ds_read_b128 like K.
-    // A staged global chunk g (keys 8g..8g+7) therefore lands as two 8-byte halves in chunks (g & ~1) and (g & ~1) + 1.
-    int st_row[2], st_chunk[2], st_koff[2], st_voff0[2], st_voff1[2];
+    // ---- staging bookkeeping: 512 16-byte chunks per tile (row = key, 8 chunks of 8 d), 2 per thread ----
+    int st_row[2], st_chunk[2], st_koff[2], st_voff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + i * 256;
         st_row[i] = idx >> 3;
         st_chunk[i] = idx & 7;
         st_koff[i] = lds_off128(st_row[i], st_chunk[i]);
-        st_voff0[i] = lds_off128(st_row[i], st_chunk[i] & ~1) + (st_chunk[i] & 1) * 8;
-        st_voff1[i] = lds_off128(st_row[i], (st_chunk[i] & ~1) + 1) + (st_chunk[i] & 1) * 8;
+        st_voff[i] = lds_off_v(st_row[i], st_chunk[i]);
     }
     u32x4 rk[PLANES][2], rv[PLANES][2];
     auto load_tiles = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int krow = min(kt * 64 + st_row[i], N - 1);
-            const int key0 = kt * 64 + st_chunk[i] * 8;
+            // keys past the sequence end re-read the last row: finite values, and P is exactly 0 there
+            const size_t off = (size_t)min(kt * 64 + st_row[i], N - 1) * 64 + st_chunk[i] * 8;
 #pragma unroll
             for (int pl = 0; pl < PLANES; ++pl) {
-                rk[pl][i] = *reinterpret_cast<const u32x4*>(Kb + (size_t)pl * p.qk_plane + (size_t)krow * 64 + st_chunk[i] * 8);
-                u32x4 v = *reinterpret_cast<const u32x4*>(Vb + (size_t)pl * p.vt_plane + (size_t)st_row[i] * p.n_pad + key0);
-                if (key0 + 8 > N) {  // zero the keys past the sequence end (P is 0 there, 0 * garbage must stay 0)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (key0 + e >= N) v[e >> 1] &= (e & 1) ? 0x0000FFFFu : 0xFFFF0000u;
-                }
-                rv[pl][i] = v;
+                rk[pl][i] = *reinterpret_cast<const u32x4*>(Kb + (size_t)pl * p.qk_plane + off);
+                rv[pl][i] = *reinterpret_cast<const u32x4*>(Vb + (size_t)pl * p.qk_plane + off);
             }
         }
     };
@@ -90,10 +94,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
 #pragma unroll
             for (int pl = 0; pl < PLANES; ++pl) {
                 *reinterpret_cast<u32x4*>(base + pl * TILE_BYTES + st_koff[i]) = rk[pl][i];
-                const u32x4 v = rv[pl][i];
-                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-                *reinterpret_cast<u32x2*>(base + (PLANES + pl) * TILE_BYTES + st_voff0[i]) = u32x2{v[0], v[1]};
-                *reinterpret_cast<u32x2*>(base + (PLANES + pl) * TILE_BYTES + st_voff1[i]) = u32x2{v[2], v[3]};
+                *reinterpret_cast<u32x4*>(base + (PLANES + pl) * TILE_BYTES + st_voff[i]) = rv[pl][i];
             }
     };
 
@@ -104,12 +105,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int s = 0; s < 4; ++s) k_off[kb][s] = lds_off128(kb * 32 + qcol, 2 * s + hh);
-    // V^T (A operand of O^T): row = d = db*32 + qcol, 16-byte chunk 2 ks + hh (see the tile image above)
-    int v_off[2][4];
+    // V^T (A operand of O^T) by transposed reads.  16-lane group g = lane >> 4 reads the block {keys 4 (g >> 1) + 0..3
+    // (+ 16 ks, + 8 for the second half of the fragment)} x {d = 32 db + 16 (g & 1) + 0..15}: lane 4 q + pc of the group
+    // supplies the address of key row q, d columns 4 pc .. 4 pc + 3, and lane i receives d column i (= 32 db + lane % 32)
+    // with key q in element q.  Key offsets 16 ks + 8 half are multiples of 4, so the swizzle bit is (q >> 1) & 1 and
+    // they are plain immediates; the two db blocks differ by the swizzled chunk bit -> one base register each.
+    int v_base[2];
+    {
+        const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) v_off[db][ks] = lds_off128(db * 32 + qcol, 2 * ks + hh);
+        for (int db = 0; db < 2; ++db) v_base[db] = lds_off_v(4 * (g >> 1) + q, db * 4 + (g & 1) * 2 + (pc >> 1)) + (pc & 1) * 8;
+    }
 
     f32x16 oacc[2];
 #pragma unroll
@@ -200,10 +206,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
             }
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const char* vb = base + PLANES * TILE_BYTES;
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + v_off[db][ks]);
+                const char* vb = base + PLANES * TILE_BYTES + v_base[db] + ks * 2048;
+                const bf16x8 vf = __builtin_shufflevector(lds_read_tr16(vb), lds_read_tr16(vb + 1024), 0, 1, 2, 3, 4, 5, 6, 7);
                 if constexpr (PLANES == 2) {
-                    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vb + TILE_BYTES + v_off[db][ks]);
+                    const bf16x8 vl = __builtin_shufflevector(lds_read_tr16(vb + TILE_BYTES), lds_read_tr16(vb + TILE_BYTES + 1024), 0, 1, 2,
+                                                              3, 4, 5, 6, 7);
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc[db], 0, 0, 0);
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, plo, oacc[db], 0, 0, 0);
                 }
@@ -243,8 +250,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
 
 int launch_attention(const AttnParams& p, int planes, hipStream_t stream) {
     CWM_REQUIRE(planes == 1 || planes == 2, "attention: planes must be 1 or 2");
-    CWM_REQUIRE(p.n_tok > 0 && p.n_pad >= ((p.n_tok + 63) / 64) * 64 && p.n_pad % 8 == 0,
-                "attention: n_pad=%d must cover n_tok=%d rounded up to 64", p.n_pad, p.n_tok);
+    CWM_REQUIRE(p.n_tok > 0 && p.batch > 0 && p.heads > 0, "attention: empty problem");
     CWM_REQUIRE(p.ldo % 4 == 0, "attention: ldo must be a multiple of 4");
     const dim3 grid((p.n_tok + 127) / 128, p.batch * p.heads);
     const size_t smem = (size_t)2 * (64 * 64 * 2) * 2 * planes;

@@ -134,8 +134,7 @@ int stream_workspace(Engine& E, StreamW& S, int B, int vmax, int mlp_ratio, bool
         if ((rc = E.ws(&S.sb.qkv_f32, 3 * act))) return rc;
     } else {
         if ((rc = E.ws(&S.sb.qbuf, 2 * act)) || (rc = E.ws(&S.sb.kbuf, 2 * act))) return rc;
-        const size_t vt = std::max((size_t)B * S.enc_dim * round_up(vmax, 64), (size_t)B * S.dec_dim * round_up(next, 64));
-        if ((rc = E.ws(&S.sb.vtbuf, 2 * vt))) return rc;
+        if ((rc = E.ws(&S.sb.vbuf, 2 * act))) return rc;
     }
     return 0;
 }

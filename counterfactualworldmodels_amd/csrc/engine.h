@@ -58,7 +58,7 @@ struct KernelTimer {
 
 // Activation buffers of one token stream (bf16 planes are [2][rows][width], plane stride set per use).
 struct StreamBuffers {
-    bf16 *hbuf = nullptr, *gbuf = nullptr, *qbuf = nullptr, *kbuf = nullptr, *vtbuf = nullptr;
+    bf16 *hbuf = nullptr, *gbuf = nullptr, *qbuf = nullptr, *kbuf = nullptr, *vbuf = nullptr;
     float* qkv_f32 = nullptr;  // only for streams whose head_dim != 64 (small-sequence attention path)
 };
 

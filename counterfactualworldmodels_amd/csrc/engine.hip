@@ -318,7 +318,6 @@ int Engine::run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H,
     const int M = B * n_tok;
     const int64_t hplane = (int64_t)M * D;
     const int hidden = w.fc1.N;
-    const int n_pad = round_up(n_tok, 64);
     int rc;
     LayerNormParams ln;
     memset(&ln, 0, sizeof(ln));
@@ -329,16 +328,16 @@ int Engine::run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H,
     GemmParams g = gemm_base(sb.hbuf, D, w.qkv, M, planes);
     g.epi = EPI_QKV;
     g.rows_in = n_tok; g.rows_out = n_tok; g.map_stride = n_tok;
-    g.q_out = sb.qbuf; g.k_out = sb.kbuf; g.vt_out = sb.vtbuf;
-    g.qk_plane = hplane; g.vt_plane = (int64_t)B * D * n_pad;
-    g.qkv_dim = D; g.heads = H; g.head_dim = D / H; g.n_tok = n_tok; g.n_pad = n_pad;
+    g.q_out = sb.qbuf; g.k_out = sb.kbuf; g.v_out = sb.vbuf;
+    g.qk_plane = hplane;
+    g.qkv_dim = D; g.heads = H; g.head_dim = D / H; g.n_tok = n_tok;
     g.q_scale = 1.0f / sqrtf((float)(D / H));
     if ((rc = run_gemm(g, planes, s))) return rc;
 
     AttnParams a;
     memset(&a, 0, sizeof(a));
-    a.q = sb.qbuf; a.k = sb.kbuf; a.vt = sb.vtbuf; a.qk_plane = hplane; a.vt_plane = (int64_t)B * D * n_pad;
-    a.o = sb.hbuf; a.o_plane = hplane; a.ldo = D; a.n_tok = n_tok; a.n_pad = n_pad; a.heads = H; a.batch = B;
+    a.q = sb.qbuf; a.k = sb.kbuf; a.v = sb.vbuf; a.qk_plane = hplane;
+    a.o = sb.hbuf; a.o_plane = hplane; a.ldo = D; a.n_tok = n_tok; a.heads = H; a.batch = B;
     if ((rc = run_attention(a, planes, s))) return rc;
 
     g = gemm_base(sb.hbuf, D, w.proj, M, planes);

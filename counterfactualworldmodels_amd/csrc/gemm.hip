@@ -17,12 +17,11 @@
 //   tile rows are full cache lines in both modes (64-byte half-line DMA requests filled LDS ~1.5x slower)
 // * XCD-aware, grouped tile order so that co-resident tiles of one XCD share A panels / W tiles in L2
 // * accumulators are kept TRANSPOSED (D^T = W_frag . A_frag^T): a lane then owns 4 consecutive output
-//   columns of one row, so epilogue accesses are 16-byte (fp32) / 8-byte (bf16) vectors (the V third of
-//   the QKV projection, stored transposed [head][d][token] for the attention kernel, uses 2-byte stores
-//   that form 32-byte runs across the 16 lanes of a group)
+//   columns of one row, so epilogue accesses are 16-byte (fp32) / 8-byte (bf16) vectors
 // * fused epilogues: bias, residual(+row map), exact-erf GELU, bf16 hi/lo split, QKV head scatter
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace cwm {
 
@@ -82,6 +81,54 @@ __device__ __forceinline__ RowMap map_row(const GemmParams& p, int m) {
     return r;
 }
 
+// One transposed accumulator fragment: v[r] = C[m][nb + ncol + r] (nb = the fragment's first column, wave-uniform;
+// ncol = (lane >> 4) * 4), with rm = map_row(p, m).  Shared by every GEMM kernel of this file.
+template <int PLANES>
+__device__ __forceinline__ void epilogue_frag(const GemmParams& p, const RowMap& rm, int nb, int ncol, f32x4 v) {
+    const int n = nb + ncol;
+    if (p.debug & 2) {
+        asm volatile("" ::"v"(v));
+        return;
+    }
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.epi == EPI_F32) {
+        if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)rm.res_row * p.ldr + n);
+        *reinterpret_cast<f32x4*>(p.C + (size_t)rm.out_row * p.ldc + n) = v;
+        return;
+    }
+    bf16* dst;
+    int64_t plane;
+    if (p.epi == EPI_QKV) {
+        const int D = p.qkv_dim;
+        const int which = nb / D;  // 0 q, 1 k, 2 v (uniform per 16-column fragment)
+        const int c = n - which * D;
+        const int h = c / p.head_dim, d = c - h * p.head_dim;
+        if (which == 0) v *= p.q_scale;
+        dst = (which == 0 ? p.q_out : which == 1 ? p.k_out : p.v_out) + ((size_t)(rm.b * p.heads + h) * p.n_tok + rm.tok) * p.head_dim + d;
+        plane = p.qk_plane;
+    } else {
+        if (p.epi == EPI_BF16_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        }
+        dst = p.out_hi + a_pos<PLANES>(rm.out_row, p.ldo, n);  // A-operand layout of the next GEMM
+        plane = kLoOffset;
+    }
+    bf16x4 hv, lv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bf16 hi = (bf16)v[r];
+        hv[r] = hi;
+        lv[r] = (bf16)(v[r] - (float)hi);
+    }
+    if (p.debug & 1) {
+        asm volatile("" ::"v"(hv), "v"(lv), "v"(dst));
+        return;
+    }
+    *reinterpret_cast<bf16x4*>(dst) = hv;
+    if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + plane) = lv;
+}
+
 // Transposed accumulators: acc[i][j][r] = C[m0 + wr*64 + i*16 + (lane&15)][n0 + wc*64 + j*16 + (lane>>4)*4 + r]
 template <int PLANES, int FM, int FN>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (&acc)[FM][FN], int m0, int n0, int wr, int wc, int lane) {
@@ -95,53 +142,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
         for (int j = 0; j < FN; ++j) {
             const int nb = n0 + wc * (16 * FN) + j * 16;  // fragment's first column (wave-uniform)
             if (nb >= p.N) continue;
-            const int n = nb + ncol;
-            f32x4 v = acc[i][j];
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.epi == EPI_F32) {
-                if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)rm.res_row * p.ldr + n);
-                *reinterpret_cast<f32x4*>(p.C + (size_t)rm.out_row * p.ldc + n) = v;
-            } else {
-                bf16* dst;
-                int64_t plane;
-                if (p.epi == EPI_QKV) {
-                    const int D = p.qkv_dim;
-                    const int which = nb / D;  // 0 q, 1 k, 2 v (uniform per 16-column fragment)
-                    const int c = n - which * D;
-                    const int h = c / p.head_dim, d = c - h * p.head_dim;
-                    if (which == 2) {
-                        // V is stored transposed for the attention kernel: V^T[(b,h)][d][token].  The lane's 4 values are
-                        // 4 consecutive d of one token; the 16 lanes of a group cover 16 consecutive tokens (32-byte runs).
-                        bf16* vd = p.vt_out + ((size_t)(rm.b * p.heads + h) * p.head_dim + d) * p.n_pad + rm.tok;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const bf16 hi = (bf16)v[r];
-                            vd[(size_t)r * p.n_pad] = hi;
-                            if constexpr (PLANES == 2) vd[(size_t)r * p.n_pad + p.vt_plane] = (bf16)(v[r] - (float)hi);
-                        }
-                        continue;
-                    }
-                    if (which == 0) v *= p.q_scale;
-                    dst = (which == 0 ? p.q_out : p.k_out) + ((size_t)(rm.b * p.heads + h) * p.n_tok + rm.tok) * p.head_dim + d;
-                    plane = p.qk_plane;
-                } else {
-                    if (p.epi == EPI_BF16_GELU) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                    }
-                    dst = p.out_hi + a_pos<PLANES>(rm.out_row, p.ldo, n);  // A-operand layout of the next GEMM
-                    plane = kLoOffset;
-                }
-                bf16x4 hv, lv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bf16 hi = (bf16)v[r];
-                    hv[r] = hi;
-                    lv[r] = (bf16)(v[r] - (float)hi);
-                }
-                *reinterpret_cast<bf16x4*>(dst) = hv;
-                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + plane) = lv;
-            }
+            epilogue_frag<PLANES>(p, rm, nb, ncol, acc[i][j]);
         }
     }
 }
@@ -280,9 +281,209 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
     epilogue_rows<PLANES, FM, FN>(p, acc, m0, n0, wr, wc, lane);
 }
 
-int g_gemm_tile = 0;  // 0 = automatic choice per shape
+// ---------------------------------------------------------------------------------------------------
+// 256x256 "8-phase" kernel: the deep-pipelined structure for wide outputs (qkv, fc1).
+//
+// The kernel above waits vmcnt(0) at one workgroup barrier per K tile with all 8 waves in lockstep, so every
+// tile starts with a dead LDS-read burst and ends by draining its LDS-DMA: MFMA busy stalls near 40 %.  Here
+//  * the 256x256 tile is cut in four 128x128 quadrants; in every quadrant wave (wr, wc) owns a 64x32 piece,
+//    and a K tile is cut in four 16-KiB half-tiles (A rows 0-127 | A rows 128-255 | W rows 0-127 | W rows 128-255)
+//  * a K tile is 4 phases, one quadrant each: { ds_read the half-tile fragments the quadrant adds, issue the
+//    LDS-DMA of ONE half-tile (2 pieces per wave) -> s_barrier -> MFMA cluster -> s_barrier }
+//  * the two wave groups (wr = 0 / 1, one wave of each per SIMD) run one barrier apart, so on every SIMD one
+//    wave's MFMA cluster covers the other wave's load segment
+//  * LDS-DMA stays in flight ACROSS the barriers: raw s_barrier, and a counted s_waitcnt vmcnt(6) once per K
+//    tile (phase 4) that leaves the three youngest half-tiles in flight.
+// Half-tile schedule (t = K tile, buffer t & 1):   P1(t): A1(t+1)   P2(t): A0(t+2)   P3(t): W0(t+2)   P4(t): W1(t+2)
+// so the wait in P4(t) retires all of tile t+1, which is first read one barrier later, in P1(t+1).
+// Write-after-read: A half-tiles are staged by the group that reads them (waves 0-3 stage and read rows 0-63,
+// waves 4-7 rows 64-127), so one phase after the reads suffices; W half-tiles are read by both groups, and
+// the leading group re-stages them two phases after the read (W0 read in P1 -> staged in P3, W1 P2 -> P4).
+template <int PLANES>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
+    constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 128 B
+    constexpr int BUF_BYTES = 4 * HALF_BYTES;  // A0 | A1 | W0 | W1
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
-int launch_gemm(const GemmParams& p, int planes, hipStream_t stream) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int tiles_m = (p.M + 255) / 256;
+    const int tiles_n = (p.N + 255) / 256;
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    constexpr int GROUP_M = 4;
+    const int group_sz = GROUP_M * tiles_n;
+    const int g = id / group_sz;
+    const int first_m = g * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    const int in_g = id - g * group_sz;
+    const int m0 = (first_m + (in_g % gm)) * 256, n0 = (in_g / gm) * 256;
+
+    // ---- LDS-DMA sources: wave w stages pieces 2w, 2w+1 (rows 16w .. 16w+15) of every half-tile ----
+    unsigned src[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int row = wave * 16 + jj * 8 + lane / 8;
+            const int logical = (lane % 8) ^ lds_swizzle<64>(row);
+            src[h][jj] = (unsigned)min(m0 + h * 128 + row, p.M - 1) * (unsigned)(p.lda * PLANES) + logical * 8;
+            src[2 + h][jj] = (unsigned)(n0 + h * 128 + row) * (unsigned)(p.K * PLANES) + logical * 8;
+        }
+    auto stage = [&](auto half_c, int buf, int kt) {
+        constexpr int half = decltype(half_c)::value;
+        const bf16* gb = (half < 2 ? p.A : p.W) + (size_t)kt * 64;  // 64 elements = 128 bytes per tile row
+        char* sb = smem + buf * BUF_BYTES + half * HALF_BYTES + wave * 2048;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gb + src[half][jj]), (lds_void*)(sb + jj * 1024), 16, 0, 0);
+    };
+    using H_A0 = std::integral_constant<int, 0>;
+    using H_A1 = std::integral_constant<int, 1>;
+    using H_W0 = std::integral_constant<int, 2>;
+    using H_W1 = std::integral_constant<int, 3>;
+
+    // ---- fragment addresses (XOR swizzle only involves (frow >> 1) & 7: fragments sit at 2-KiB strides) ----
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_base[2], b_base[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        a_base[h] = lds_off<64>(wr * 64 + frow, h * 4 + fq);
+        b_base[h] = 2 * HALF_BYTES + lds_off<64>(wc * 32 + frow, h * 4 + fq);
+    }
+    bf16x8 af[2][4], bw0[2][2], bw1[2][2];  // [16-byte chunk set: k-step (fast) | hi, lo (parity)][fragment]
+    auto read_a = [&](const char* base, int qm) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[h][i] = *reinterpret_cast<const bf16x8*>(base + qm * HALF_BYTES + a_base[h] + i * 2048);
+    };
+    auto read_w = [&](const char* base, int qn, bf16x8 (&bw)[2][2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bw[h][j] = *reinterpret_cast<const bf16x8*>(base + qn * HALF_BYTES + b_base[h] + j * 2048);
+    };
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed accumulation D^T = W_frag . A_frag^T (the lane owns 4 consecutive output columns of one row)
+    auto mfma_quadrant = [&](f32x4 (&c)[4][2], const bf16x8 (&bw)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PLANES == 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[h][j], af[h][i], c[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][j], af[1][i], c[i][j], 0, 0, 0);
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[1][j], af[0][i], c[i][j], 0, 0, 0);
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][j], af[0][i], c[i][j], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define CWM_PHASE_BARRIER()                   \
+    do {                                      \
+        __builtin_amdgcn_sched_barrier(0);    \
+        __builtin_amdgcn_s_barrier();         \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+
+    const int nk = p.K / (64 / PLANES);
+    // ---- prologue: all of tile 0, then A0 / W0 / W1 of tile 1 ----
+    stage(H_A0{}, 0, 0);
+    stage(H_W0{}, 0, 0);
+    stage(H_W1{}, 0, 0);
+    stage(H_A1{}, 0, 0);
+    if (nk > 1) {
+        stage(H_A0{}, 1, 1);
+        stage(H_W0{}, 1, 1);
+        stage(H_W1{}, 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    CWM_PHASE_BARRIER();
+    if (wr == 1) CWM_PHASE_BARRIER();  // the second wave group runs one barrier behind the first
+
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        const char* base = smem + buf * BUF_BYTES;
+        // ---- P1: quadrant (0, 0) ----
+        read_w(base, 0, bw0);
+        read_a(base, 0);
+        if (t + 1 < nk) stage(H_A1{}, buf ^ 1, t + 1);
+        CWM_PHASE_BARRIER();
+        mfma_quadrant(acc[0][0], bw0);
+        CWM_PHASE_BARRIER();
+        // ---- P2: quadrant (0, 1) ----
+        read_w(base, 1, bw1);
+        if (t + 2 < nk) stage(H_A0{}, buf, t + 2);
+        CWM_PHASE_BARRIER();
+        mfma_quadrant(acc[0][1], bw1);
+        CWM_PHASE_BARRIER();
+        // ---- P3: quadrant (1, 1) ----
+        read_a(base, 1);
+        if (t + 2 < nk) stage(H_W0{}, buf, t + 2);
+        CWM_PHASE_BARRIER();
+        mfma_quadrant(acc[1][1], bw1);
+        CWM_PHASE_BARRIER();
+        // ---- P4: quadrant (1, 0); retire tile t+1 ----
+        if (t + 2 < nk) {
+            stage(H_W1{}, buf, t + 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        CWM_PHASE_BARRIER();
+        mfma_quadrant(acc[1][0], bw0);
+        CWM_PHASE_BARRIER();
+    }
+    if (wr == 0) CWM_PHASE_BARRIER();  // balance the stagger barrier
+#undef CWM_PHASE_BARRIER
+
+    const int ncol = (lane >> 4) * 4;
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + qm * 128 + wr * 64 + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+            const RowMap rm = map_row(p, m);
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int nb = n0 + qn * 128 + wc * 32 + j * 16;
+                    if (nb >= p.N) continue;
+                    epilogue_frag<PLANES>(p, rm, nb, ncol, acc[qm][qn][i][j]);
+                }
+        }
+}
+
+int g_gemm_tile = 0;  // 0 = automatic choice per shape
+int g_gemm_debug = 0;
+
+int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.debug = g_gemm_debug;
     CWM_REQUIRE(planes == 1 || planes == 2, "gemm: planes must be 1 or 2");
     CWM_REQUIRE(p.K % 64 == 0, "gemm: K=%d must be a multiple of 64", p.K);
     CWM_REQUIRE(p.lda % 8 == 0, "gemm: lda=%d must be a multiple of 8", p.lda);
@@ -293,12 +494,11 @@ int launch_gemm(const GemmParams& p, int planes, hipStream_t stream) {
     } else if (p.epi == EPI_QKV) {
         CWM_REQUIRE(p.rows_in == p.n_tok && p.N == 3 * p.qkv_dim && p.head_dim % 4 == 0, "gemm: bad QKV epilogue setup");
         CWM_REQUIRE(p.qkv_dim % 16 == 0, "gemm: QKV epilogue needs the model width (%d) to be a multiple of 16", p.qkv_dim);
-        CWM_REQUIRE(p.n_pad % 4 == 0, "gemm: n_pad must be a multiple of 4");
     } else {
         CWM_REQUIRE(p.ldo % 4 == 0, "gemm: ldo must be a multiple of 4");
     }
     // ---- tile configuration: biggest tile whose grid still fills the chip reasonably ----
-    int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256
+    int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase
     if (cfg == 0) {
         // Measured on MI355X (tools/microbench.py, B/8 batch-32 shapes, both modes): wide outputs (N >= 1024: qkv, fc1)
         // run best on the 256x256 tile; N <= 768 (proj, fc2, head, patch embed) on 128x128 with two workgroups per CU,
@@ -306,6 +506,20 @@ int launch_gemm(const GemmParams& p, int planes, hipStream_t stream) {
         cfg = (p.N >= 1024 && p.M >= 512) ? 3 : 1;
     }
     typedef void (*kern_t)(const GemmParams);
+    if (cfg == 4) {
+        static const kern_t k8[2] = {gemm8p_kernel<1>, gemm8p_kernel<2>};
+        static bool attr8[2] = {false, false};
+        const size_t smem8 = 2 * 4 * 128 * 128;
+        kern_t k = k8[planes - 1];
+        if (!attr8[planes - 1]) {
+            CWM_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
+            attr8[planes - 1] = true;
+        }
+        const int tiles8 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+        hipLaunchKernelGGL(k, dim3(tiles8), dim3(512), smem8, stream, p);
+        CWM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     static const kern_t kerns[3][2] = {
         {gemm_bf16_kernel<1, 128, 128, 2, 2>, gemm_bf16_kernel<2, 128, 128, 2, 2>},
         {gemm_bf16_kernel<1, 256, 128, 4, 2>, gemm_bf16_kernel<2, 256, 128, 4, 2>},

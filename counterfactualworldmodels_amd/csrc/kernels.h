@@ -8,7 +8,7 @@ enum GemmEpilogue : int {
     EPI_F32 = 0,        // C = acc + bias (+ resid[rowmap])            fp32 out
     EPI_BF16_GELU = 1,  // out = split_bf16(gelu_erf(acc + bias))      bf16 plane(s) out
     EPI_BF16 = 2,       // out = split_bf16(acc + bias)                bf16 plane(s) out
-    EPI_QKV = 3,        // per-head scatter: Q (scaled), K -> [B*H,N,hd]; V -> V^T [B*H,hd,Npad]
+    EPI_QKV = 3,        // per-head scatter: Q (scaled), K, V -> [B*H,N,hd]
 };
 
 struct GemmParams {
@@ -36,24 +36,26 @@ struct GemmParams {
     // EPI_QKV
     bf16* q_out;
     bf16* k_out;
-    bf16* vt_out;
-    int64_t qk_plane, vt_plane;
-    int qkv_dim, heads, head_dim, n_tok, n_pad;
+    bf16* v_out;
+    int64_t qk_plane;
+    int qkv_dim, heads, head_dim, n_tok;
     float q_scale;
+    int debug;  // development ablations (cwm_debug_set "gemm_debug"): bit 0 skip the epilogue's global stores, bit 1 skip the epilogue
 };
 
 int launch_gemm(const GemmParams& p, int planes, hipStream_t stream);
-extern int g_gemm_tile;    // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256 output tile
+extern int g_gemm_debug;
+extern int g_gemm_tile;    // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256 output tile, 4: 256x256 8-phase
 
 struct AttnParams {
     const bf16* q;   // [planes][B*H][N][64]   (q pre-scaled by hd^-0.5)
     const bf16* k;   // [planes][B*H][N][64]
-    const bf16* vt;  // [planes][B*H][64][n_pad]
-    int64_t qk_plane, vt_plane;
+    const bf16* v;   // [planes][B*H][N][64]  (row-major like K; transposed on the LDS read)
+    int64_t qk_plane;
     bf16* o;         // [planes][B*N][ldo]  (head h at columns h*64..)
     int64_t o_plane;
     int ldo;
-    int n_tok, n_pad, heads, batch;
+    int n_tok, heads, batch;
 };
 
 int launch_attention(const AttnParams& p, int planes, hipStream_t stream);

@@ -41,8 +41,7 @@ int ensure_workspace(cwm_model* m, int B, int n_vis) {
     if ((rc = E.ws(&m->sb.hbuf, 2 * act)) || (rc = E.ws(&m->sb.gbuf, 2 * act * c.mlp_ratio)) || (rc = E.ws(&m->sb.qbuf, 2 * act)) ||
         (rc = E.ws(&m->sb.kbuf, 2 * act)))
         return rc;
-    const size_t vt = std::max((size_t)Bc * c.enc_dim * round_up(Nv, 64), (size_t)Bc * c.dec_dim * round_up(Nt, 64));
-    if ((rc = E.ws(&m->sb.vtbuf, 2 * vt))) return rc;
+    if ((rc = E.ws(&m->sb.vbuf, 2 * act))) return rc;
     m->ws_batch = Bc;
     m->ws_nvis = Nv;
     return 0;
@@ -252,9 +251,8 @@ __global__ void pad_split_rows_kernel(const float* src, int rows, int K, bf16* o
     if constexpr (PLANES == 2) d[kLoOffset] = l;
 }
 
-// qkv [B,N,3,H,64] fp32 -> Q (scaled), K [B*H,N,64], V^T [B*H,64,n_pad]
-__global__ void qkv_scatter_kernel(const float* qkv, int B, int N, int H, int n_pad, float scale, bf16* q, bf16* k, bf16* vt,
-                                   int64_t qk_plane, int64_t vt_plane) {
+// qkv [B,N,3,H,64] fp32 -> Q (scaled), K, V [B*H,N,64]
+__global__ void qkv_scatter_kernel(const float* qkv, int B, int N, int H, float scale, bf16* q, bf16* k, bf16* v_out, int64_t qk_plane) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int D = H * 64;
     if (i >= (int64_t)B * N * 3 * D) return;
@@ -266,16 +264,10 @@ __global__ void qkv_scatter_kernel(const float* qkv, int B, int N, int H, int n_
     if (which == 0) v *= scale;
     bf16 hi, lo;
     split_bf16(v, hi, lo);
-    if (which < 2) {
-        bf16* dst = which == 0 ? q : k;
-        const size_t o = ((size_t)(b * H + h) * N + n) * 64 + d;
-        dst[o] = hi;
-        dst[o + qk_plane] = lo;
-    } else {
-        const size_t o = ((size_t)(b * H + h) * 64 + d) * n_pad + n;
-        vt[o] = hi;
-        vt[o + vt_plane] = lo;
-    }
+    bf16* dst = which == 0 ? q : which == 1 ? k : v_out;
+    const size_t o = ((size_t)(b * H + h) * N + n) * 64 + d;
+    dst[o] = hi;
+    dst[o + qk_plane] = lo;
 }
 
 // GEMM A-operand layout -> fp32 [rows][ld]
@@ -340,23 +332,20 @@ extern "C" int cwm_attention(const float* qkv_dev, float* o_dev, int B, int N, i
     CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_attention: bad mode");
     hipStream_t s = (hipStream_t)stream;
     const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
-    const int D = H * 64, n_pad = round_up(N, 64);
-    const int64_t qk_plane = (int64_t)B * N * D, vt_plane = (int64_t)B * D * n_pad;
+    const int D = H * 64;
+    const int64_t qk_plane = (int64_t)B * N * D;
     Scratch sc;
     bf16* q = sc.get<bf16>(2 * qk_plane);
     bf16* k = sc.get<bf16>(2 * qk_plane);
-    bf16* vt = sc.get<bf16>(2 * vt_plane);
+    bf16* v = sc.get<bf16>(2 * qk_plane);
     bf16* o = sc.get<bf16>(2 * qk_plane);
-    CWM_REQUIRE(q && k && vt && o, "cwm_attention: out of device memory");
-    // poison V^T padding with NaN bit patterns: the kernel must not let it leak
-    CWM_HIP_CHECK(hipMemsetAsync(vt, 0xFF, (size_t)2 * vt_plane * sizeof(bf16), s));
+    CWM_REQUIRE(q && k && v && o, "cwm_attention: out of device memory");
     const int64_t total = (int64_t)B * N * 3 * D;
-    hipLaunchKernelGGL(qkv_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv_dev, B, N, H, n_pad, 0.125f, q, k,
-                       vt, qk_plane, vt_plane);
+    hipLaunchKernelGGL(qkv_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv_dev, B, N, H, 0.125f, q, k, v, qk_plane);
     AttnParams a;
     memset(&a, 0, sizeof(a));
-    a.q = q; a.k = k; a.vt = vt; a.qk_plane = qk_plane; a.vt_plane = vt_plane; a.o = o; a.o_plane = qk_plane; a.ldo = D;
-    a.n_tok = N; a.n_pad = n_pad; a.heads = H; a.batch = B;
+    a.q = q; a.k = k; a.v = v; a.qk_plane = qk_plane; a.o = o; a.o_plane = qk_plane; a.ldo = D;
+    a.n_tok = N; a.heads = H; a.batch = B;
     if (int rc = launch_attention(a, planes, s)) return rc;
     if (planes == 2)
         hipLaunchKernelGGL(merge_planes_kernel<2>, dim3((unsigned)((qk_plane + 255) / 256)), dim3(256), 0, s, o, o_dev, B * N, D);
@@ -472,6 +461,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
         g_gemm_tile = value;
         return CWM_OK;
     }
+    if (!strcmp(key, "gemm_debug")) {
+        g_gemm_debug = value;
+        return CWM_OK;
+    }
     cwm_set_error("cwm_debug_set: unknown key %s", key);
     return CWM_ERR_INVALID;
 }
@@ -503,11 +496,9 @@ extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters,
     } else if (epi == 3) {
         CWM_REQUIRE(N % 192 == 0, "cwm_bench_gemm: QKV epilogue needs N = 3*64*heads");
         const int D = N / 3, H = D / 64, n_tok = 792 <= M && M % 792 == 0 ? 792 : M, B = M / n_tok;
-        const int n_pad = round_up(n_tok, 64);
         p.epi = EPI_QKV; p.rows_in = n_tok; p.rows_out = n_tok; p.map_stride = n_tok;
-        p.q_out = G; p.k_out = G2; p.vt_out = G3; p.qk_plane = (int64_t)M * D; p.vt_plane = (int64_t)B * D * n_pad;
-        CWM_REQUIRE(p.vt_plane * 2 <= (int64_t)2 * M * N + 64 * 1024 * 64, "cwm_bench_gemm: V^T scratch too small");
-        p.qkv_dim = D; p.heads = H; p.head_dim = 64; p.n_tok = n_tok; p.n_pad = n_pad; p.q_scale = 0.125f;
+        p.q_out = G; p.k_out = G2; p.v_out = G3; p.qk_plane = (int64_t)M * D;
+        p.qkv_dim = D; p.heads = H; p.head_dim = 64; p.n_tok = n_tok; p.q_scale = 0.125f;
     } else {
         p.epi = EPI_F32; p.C = Cm; p.ldc = N; p.resid = Cm; p.ldr = N;
     }
@@ -533,21 +524,21 @@ extern "C" int cwm_bench_attention(int B, int H, int N, int mode, int iters, dou
     CWM_REQUIRE(avg_us && B > 0 && H > 0 && N > 0 && iters > 0, "cwm_bench_attention: bad argument");
     CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_bench_attention: bad mode");
     const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
-    const int D = H * 64, n_pad = round_up(N, 64);
-    const int64_t qk_plane = (int64_t)B * N * D, vt_plane = (int64_t)B * D * n_pad;
+    const int D = H * 64;
+    const int64_t qk_plane = (int64_t)B * N * D;
     Scratch sc;
     bf16* q = sc.get<bf16>(2 * qk_plane);
     bf16* k = sc.get<bf16>(2 * qk_plane);
-    bf16* vt = sc.get<bf16>(2 * vt_plane);
+    bf16* v = sc.get<bf16>(2 * qk_plane);
     bf16* o = sc.get<bf16>(2 * qk_plane);
-    CWM_REQUIRE(q && k && vt && o, "cwm_bench_attention: out of device memory");
+    CWM_REQUIRE(q && k && v && o, "cwm_bench_attention: out of device memory");
     fill_bf16(q, 2 * qk_plane, 5, 0.5f);
     fill_bf16(k, 2 * qk_plane, 6, 1.0f);
-    fill_bf16(vt, 2 * vt_plane, 7, 1.0f);
+    fill_bf16(v, 2 * qk_plane, 7, 1.0f);
     AttnParams a;
     memset(&a, 0, sizeof(a));
-    a.q = q; a.k = k; a.vt = vt; a.qk_plane = qk_plane; a.vt_plane = vt_plane; a.o = o; a.o_plane = qk_plane; a.ldo = D;
-    a.n_tok = N; a.n_pad = n_pad; a.heads = H; a.batch = B;
+    a.q = q; a.k = k; a.v = v; a.qk_plane = qk_plane; a.o = o; a.o_plane = qk_plane; a.ldo = D;
+    a.n_tok = N; a.heads = H; a.batch = B;
     hipEvent_t e0, e1;
     CWM_HIP_CHECK(hipEventCreate(&e0));
     CWM_HIP_CHECK(hipEventCreate(&e1));

@@ -166,9 +166,9 @@ def test_unembed_bit_exact_golden(gu):
     assert np.array_equal(out.cpu().numpy(), g["unembed_video"])
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 def test_gemm_tile_configurations_agree(gu, tile):
-    """All output-tile configurations of the GEMM (128x128, 256x128, 256x256) give the same result."""
+    """All output-tile configurations of the GEMM (128x128, 256x128, 256x256, 256x256 8-phase) give the same result."""
     lib = _lib.get_lib()
     try:
         _lib.check(lib.cwm_debug_set(b"gemm_tile", tile))
@@ -183,5 +183,26 @@ def test_gemm_tile_configurations_agree(gu, tile):
         w = torch.randint(-4, 5, (272, 128), generator=g).float()
         assert torch.equal(gu.linear(a, w, None, mode="parity"), a @ w.t())
         assert torch.equal(gu.linear(a, w, None, mode="fast"), a @ w.t())
+    finally:
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
+
+
+def test_gemm_8phase_is_bitwise_equal_to_simple_kernel_under_repetition(gu):
+    """Race screen for the 8-phase GEMM (LDS-DMA in flight across raw barriers, counted vmcnt): every accumulator
+    sees the same product sequence as in the one-barrier-per-tile kernel, so the outputs must be bit-identical --
+    for 1, 2, 3 and many K tiles, ragged M / N, repeated launches (a half-tile read before it landed, or re-staged
+    before it was read, shows up as a mismatch)."""
+    lib = _lib.get_lib()
+    shapes = [(256, 256, 64), (300, 272, 128), (1000, 1152, 192), (513, 512, 384), (2049, 768, 768), (4096, 1024, 3072)]
+    try:
+        for mode in ("parity", "fast"):
+            for (M, N, K) in shapes:
+                a, w, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13)
+                _lib.check(lib.cwm_debug_set(b"gemm_tile", 1))
+                ref = gu.linear(a, w, b, mode=mode)
+                _lib.check(lib.cwm_debug_set(b"gemm_tile", 4))
+                for rep in range(8):
+                    out = gu.linear(a, w, b, mode=mode)
+                    assert torch.equal(out, ref), (mode, M, N, K, rep, (out - ref).abs().max().item())
     finally:
         _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))

@@ -28,7 +28,7 @@ ATTN_SHAPES = [("b8.enc", 32, 12, 792), ("b8.dec", 32, 6, 1568), ("l4.enc", 8, 1
 
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-    variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3").split(",")]
+    variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,3,4").split(",")]
     torch.cuda.init()
     lib = _lib.get_lib()
     us = C.c_double()
