@@ -81,6 +81,14 @@ __device__ __forceinline__ RowMap map_row(const GemmParams& p, int m) {
     return r;
 }
 
+// Q / K / V output base.  (Written as a select of three loaded VALUES: hipcc turns `which == 0 ? p.q_out : ...` over the
+// three adjacent pointer fields into a dynamic index into the kernel-argument struct, which then lives in scratch.)
+__device__ __forceinline__ bf16* qkv_out_base(const GemmParams& p, int which) {
+    bf16 *qo = p.q_out, *ko = p.k_out, *vo = p.v_out;
+    asm volatile("" : "+s"(qo), "+s"(ko), "+s"(vo));
+    return which == 0 ? qo : which == 1 ? ko : vo;
+}
+
 // One transposed accumulator fragment: v[r] = C[m][nb + ncol + r] (nb = the fragment's first column, wave-uniform;
 // ncol = (lane >> 4) * 4), with rm = map_row(p, m).  Shared by every GEMM kernel of this file.
 template <int PLANES>
@@ -104,7 +112,7 @@ __device__ __forceinline__ void epilogue_frag(const GemmParams& p, const RowMap&
         const int c = n - which * D;
         const int h = c / p.head_dim, d = c - h * p.head_dim;
         if (which == 0) v *= p.q_scale;
-        dst = (which == 0 ? p.q_out : which == 1 ? p.k_out : p.v_out) + ((size_t)(rm.b * p.heads + h) * p.n_tok + rm.tok) * p.head_dim + d;
+        dst = qkv_out_base(p, which) + ((size_t)(rm.b * p.heads + h) * p.n_tok + rm.tok) * p.head_dim + d;
         plane = p.qk_plane;
     } else {
         if (p.epi == EPI_BF16_GELU) {
@@ -145,6 +153,133 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
             epilogue_frag<PLANES>(p, rm, nb, ncol, acc[i][j]);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-staged epilogue (p.staged): the accumulator layout (16 rows x 4 lane groups of 4 columns) gives 32- / 64-byte
+// runs per row and makes every lane redo the row -> (batch, token) division for each of its rows; measured, that
+// epilogue was 30 % (parity) to 47 % (fast) of a K = 768 GEMM.  Here the workgroup first writes a row table
+// (one division per tile row) to LDS; then every wave pushes its tile through a private 8-KiB LDS buffer one
+// 64-row x 32-column piece at a time and reads it back row-major, so that every global access of the epilogue is a
+// 16-byte lane access forming full 128-byte (64-byte: fast-mode bf16, Q/K/V) row segments.
+//   piece buffer: [64 rows][128 B], 16-byte chunk c of row r at c ^ (r & 7)
+//     fp32: chunk = 4 columns;  bf16: chunks 0-3 = hi of 8 columns each, chunks 4-7 = lo (parity only)
+//   row table: out_row / residual row (EPI_F32, EPI_BF16*), b * heads * n_tok + token / - (EPI_QKV); -1 = row >= M
+__device__ __forceinline__ void epilogue_row_table(const GemmParams& p, int2* tab, int m0, int bm, int tid) {
+    if (tid < bm) {
+        const int m = m0 + tid;
+        int2 e = make_int2(-1, 0);
+        if (m < p.M) {
+            const RowMap rm = map_row(p, m);
+            e = (p.epi == EPI_QKV) ? make_int2(rm.b * p.heads * p.n_tok + rm.tok, 0) : make_int2(rm.out_row, rm.res_row);
+        }
+        tab[tid] = e;
+    }
+}
+
+// frag(i, j): the piece's fragment of rows 16 i .. 16 i + 15, columns 16 j .. 16 j + 15 (i < 4, j < 2)
+template <int PLANES, class Frag>
+__device__ __forceinline__ void epilogue_piece(const GemmParams& p, Frag frag, char* wlds, const int2* tab, int row0, int nb, int lane) {
+    if (nb >= p.N) return;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool f32_out = p.epi == EPI_F32;
+    int which = 0;
+    bf16* qkv_base = nullptr;
+    if (p.epi == EPI_QKV) {
+        which = nb / p.qkv_dim;
+        qkv_base = qkv_out_base(p, which);
+    }
+    // ---- accumulators (+ bias, activation, split) -> piece buffer ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (nb + j * 16 >= p.N) continue;
+        f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16 + fq * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 16 + fr;
+            f32x4 v = frag(i, j) + bias;
+            if (f32_out) {
+                *reinterpret_cast<f32x4*>(wlds + r * 128 + (((j * 4 + fq) ^ (r & 7)) << 4)) = v;
+            } else {
+                if (p.epi == EPI_BF16_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                } else if (which == 0 && p.epi == EPI_QKV) {
+                    v *= p.q_scale;
+                }
+                bf16x4 hv, lv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bf16 hi = (bf16)v[e];
+                    hv[e] = hi;
+                    lv[e] = (bf16)(v[e] - (float)hi);
+                }
+                const int ch = j * 2 + (fq >> 1), sub = (fq & 1) * 8;
+                *reinterpret_cast<bf16x4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4) + sub) = hv;
+                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(wlds + r * 128 + (((ch + 4) ^ (r & 7)) << 4) + sub) = lv;
+            }
+        }
+    }
+    if (p.debug & 1) return;
+    // ---- piece buffer -> global, row-major ----
+    if (f32_out || PLANES == 2) {
+        const int c = lane & 7;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int r = s * 8 + (lane >> 3);
+            const int2 info = tab[row0 + r];
+            f32x4 v = *reinterpret_cast<const f32x4*>(wlds + r * 128 + ((c ^ (r & 7)) << 4));
+            if (info.x < 0) continue;
+            if (f32_out) {
+                const int n = nb + c * 4;
+                if (n >= p.N) continue;
+                if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)info.y * p.ldr + n);
+                *reinterpret_cast<f32x4*>(p.C + (size_t)info.x * p.ldc + n) = v;
+            } else {
+                const int n = nb + (c & 3) * 8, lo = c >> 2;
+                if (n >= p.N) continue;
+                bf16* dst;
+                if (p.epi == EPI_QKV) {
+                    const int cD = n - which * p.qkv_dim, h = cD / p.head_dim, d = cD - h * p.head_dim;
+                    dst = qkv_base + (size_t)lo * p.qk_plane + ((size_t)(info.x + h * p.n_tok)) * p.head_dim + d;
+                } else {
+                    dst = p.out_hi + a_pos<2>(info.x, p.ldo, n) + lo * kLoOffset;
+                }
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+    } else {
+        const int c = lane & 3;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = s * 16 + (lane >> 2);
+            const int2 info = tab[row0 + r];
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wlds + r * 128 + ((c ^ (r & 7)) << 4));
+            const int n = nb + c * 8;
+            if (info.x < 0 || n >= p.N) continue;
+            bf16* dst;
+            if (p.epi == EPI_QKV) {
+                const int cD = n - which * p.qkv_dim, h = cD / p.head_dim, d = cD - h * p.head_dim;
+                dst = qkv_base + ((size_t)(info.x + h * p.n_tok)) * p.head_dim + d;
+            } else {
+                dst = p.out_hi + (size_t)info.x * p.ldo + n;
+            }
+            *reinterpret_cast<f32x4*>(dst) = v;
+        }
+    }
+}
+
+// Whole wave tile (FM x FN fragments at tile rows wrow0.., columns ncol0..) through the staged epilogue.
+template <int PLANES, int FM, int FN>
+__device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4 (&acc)[FM][FN], char* wlds, const int2* tab, int wrow0,
+                                                int ncol0, int lane) {
+    static_assert(FM % 4 == 0 && FN % 2 == 0, "wave tile must be a multiple of the 64x32 piece");
+#pragma unroll
+    for (int pi = 0; pi < FM / 4; ++pi)
+#pragma unroll
+        for (int pj = 0; pj < FN / 2; ++pj)
+            epilogue_piece<PLANES>(p, [&](int i, int j) { return acc[pi * 4 + i][pj * 2 + j]; }, wlds, tab, wrow0 + pi * 64, ncol0 + pj * 32, lane);
 }
 
 // Tile configurations (BM x BN output tile, WM x WN waves, each wave FM x FN MFMA fragments of 16x16):
@@ -278,7 +413,22 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    epilogue_rows<PLANES, FM, FN>(p, acc, m0, n0, wr, wc, lane);
+    if (p.debug & 2) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    if (p.staged) {
+        __syncthreads();  // every wave is done with the operand tiles: LDS becomes the epilogue's staging space
+        int2* tab = reinterpret_cast<int2*>(smem + NWAVES * 8192);
+        epilogue_row_table(p, tab, m0, BM, tid);
+        __syncthreads();
+        epilogue_staged<PLANES, FM, FN>(p, acc, smem + wave * 8192, tab, wr * (16 * FM), n0 + wc * (16 * FN), lane);
+    } else {
+        epilogue_rows<PLANES, FM, FN>(p, acc, m0, n0, wr, wc, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -459,6 +609,30 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
     if (wr == 0) CWM_PHASE_BARRIER();  // balance the stagger barrier
 #undef CWM_PHASE_BARRIER
 
+    if (p.debug & 2) {
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[qm][qn][i][j]));
+        return;
+    }
+    if (p.staged) {
+        // (the balancing barrier above is also the point where every wave is done reading the operand tiles)
+        int2* tab = reinterpret_cast<int2*>(smem + 8 * 8192);
+        epilogue_row_table(p, tab, m0, 256, tid);
+        __syncthreads();
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn)
+                epilogue_piece<PLANES>(p, [&](int i, int j) { return acc[qm][qn][i][j]; }, smem + wave * 8192, tab, qm * 128 + wr * 64,
+                                       n0 + qn * 128 + wc * 32, lane);
+        return;
+    }
     const int ncol = (lane >> 4) * 4;
 #pragma unroll
     for (int qm = 0; qm < 2; ++qm)
@@ -480,6 +654,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
 
 int g_gemm_tile = 0;  // 0 = automatic choice per shape
 int g_gemm_debug = 0;
+int g_gemm_staged = 1;  // 0: force the direct (per-fragment) epilogue
 
 int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) {
     GemmParams p = p_in;
@@ -496,6 +671,14 @@ int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) {
         CWM_REQUIRE(p.qkv_dim % 16 == 0, "gemm: QKV epilogue needs the model width (%d) to be a multiple of 16", p.qkv_dim);
     } else {
         CWM_REQUIRE(p.ldo % 4 == 0, "gemm: ldo must be a multiple of 4");
+        CWM_REQUIRE(planes == 1 || p.ldo % 32 == 0, "gemm: split-bf16 output rows are whole [32 hi | 32 lo] blocks: ldo=%d must be a multiple of 32", p.ldo);
+    }
+    // ---- LDS-staged epilogue whenever its 16-byte row segments are aligned (always, for the predictor's widths) ----
+    p.staged = 0;
+    if (g_gemm_staged) {
+        if (p.epi == EPI_F32) p.staged = 1;
+        else if (p.epi == EPI_QKV) p.staged = (p.qkv_dim % 32 == 0 && p.head_dim % 32 == 0);
+        else p.staged = (p.ldo % 8 == 0);
     }
     // ---- tile configuration: biggest tile whose grid still fills the chip reasonably ----
     int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase

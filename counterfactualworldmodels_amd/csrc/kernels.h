@@ -40,11 +40,13 @@ struct GemmParams {
     int64_t qk_plane;
     int qkv_dim, heads, head_dim, n_tok;
     float q_scale;
+    int staged;  // set by launch_gemm: epilogue through LDS with full-line global accesses (gemm.hip)
     int debug;  // development ablations (cwm_debug_set "gemm_debug"): bit 0 skip the epilogue's global stores, bit 1 skip the epilogue
 };
 
 int launch_gemm(const GemmParams& p, int planes, hipStream_t stream);
 extern int g_gemm_debug;
+extern int g_gemm_staged;
 extern int g_gemm_tile;    // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256 output tile, 4: 256x256 8-phase
 
 struct AttnParams {

@@ -270,13 +270,13 @@ __global__ void qkv_scatter_kernel(const float* qkv, int B, int N, int H, float 
     dst[o + qk_plane] = lo;
 }
 
-// GEMM A-operand layout -> fp32 [rows][ld]
+// GEMM A-operand layout (row length ld_in, a multiple of 32) -> fp32 [rows][ld]
 template <int PLANES>
-__global__ void merge_planes_kernel(const bf16* in, float* out, int rows, int ld) {
+__global__ void merge_planes_kernel(const bf16* in, float* out, int rows, int ld, int ld_in) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)rows * ld) return;
     const int r = (int)(i / ld), c = (int)(i - (int64_t)r * ld);
-    const bf16* s = in + a_pos<PLANES>(r, ld, c);
+    const bf16* s = in + a_pos<PLANES>(r, ld_in, c);
     out[i] = (float)s[0] + (PLANES == 2 ? (float)s[kLoOffset] : 0.f);
 }
 }  // namespace
@@ -297,7 +297,8 @@ extern "C" int cwm_linear(const float* a_dev, const float* w_dev, const float* b
     bf16* A = sc.get<bf16>((size_t)2 * M * Kp);
     bf16* W = sc.get<bf16>((size_t)2 * Np * Kp);
     float* bias = sc.get<float>(Np, true);
-    bf16* G = gelu ? sc.get<bf16>((size_t)2 * M * N) : nullptr;
+    const int ldg = round_up(N, 32);  // operand-layout rows are whole [32 hi | 32 lo] blocks
+    bf16* G = gelu ? sc.get<bf16>((size_t)2 * M * ldg) : nullptr;
     CWM_REQUIRE(A && W && bias && (!gelu || G), "cwm_linear: out of device memory");
     const unsigned gridA = (unsigned)(((int64_t)M * Kp + 255) / 256);
     if (planes == 2)
@@ -311,7 +312,7 @@ extern "C" int cwm_linear(const float* a_dev, const float* w_dev, const float* b
     p.A = A; p.lda = Kp; p.W = W;
     p.M = M; p.N = N; p.K = Kp; p.bias = bias;
     if (gelu) {
-        p.epi = EPI_BF16_GELU; p.out_hi = G; p.ldo = N;
+        p.epi = EPI_BF16_GELU; p.out_hi = G; p.ldo = ldg;
     } else {
         p.epi = EPI_F32; p.C = c_dev; p.ldc = N; p.resid = resid_dev; p.ldr = N;
     }
@@ -319,9 +320,9 @@ extern "C" int cwm_linear(const float* a_dev, const float* w_dev, const float* b
     if (gelu) {
         const unsigned gridG = (unsigned)(((int64_t)M * N + 255) / 256);
         if (planes == 2)
-            hipLaunchKernelGGL(merge_planes_kernel<2>, dim3(gridG), dim3(256), 0, s, G, c_dev, M, N);
+            hipLaunchKernelGGL(merge_planes_kernel<2>, dim3(gridG), dim3(256), 0, s, G, c_dev, M, N, ldg);
         else
-            hipLaunchKernelGGL(merge_planes_kernel<1>, dim3(gridG), dim3(256), 0, s, G, c_dev, M, N);
+            hipLaunchKernelGGL(merge_planes_kernel<1>, dim3(gridG), dim3(256), 0, s, G, c_dev, M, N, ldg);
     }
     CWM_HIP_CHECK(hipStreamSynchronize(s));
     return CWM_OK;
@@ -348,9 +349,9 @@ extern "C" int cwm_attention(const float* qkv_dev, float* o_dev, int B, int N, i
     a.n_tok = N; a.heads = H; a.batch = B;
     if (int rc = launch_attention(a, planes, s)) return rc;
     if (planes == 2)
-        hipLaunchKernelGGL(merge_planes_kernel<2>, dim3((unsigned)((qk_plane + 255) / 256)), dim3(256), 0, s, o, o_dev, B * N, D);
+        hipLaunchKernelGGL(merge_planes_kernel<2>, dim3((unsigned)((qk_plane + 255) / 256)), dim3(256), 0, s, o, o_dev, B * N, D, D);
     else
-        hipLaunchKernelGGL(merge_planes_kernel<1>, dim3((unsigned)((qk_plane + 255) / 256)), dim3(256), 0, s, o, o_dev, B * N, D);
+        hipLaunchKernelGGL(merge_planes_kernel<1>, dim3((unsigned)((qk_plane + 255) / 256)), dim3(256), 0, s, o, o_dev, B * N, D, D);
     CWM_HIP_CHECK(hipStreamSynchronize(s));
     return CWM_OK;
 }
@@ -459,6 +460,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
     CWM_REQUIRE(key, "cwm_debug_set: null key");
     if (!strcmp(key, "gemm_tile")) {
         g_gemm_tile = value;
+        return CWM_OK;
+    }
+    if (!strcmp(key, "gemm_staged")) {
+        g_gemm_staged = value;
         return CWM_OK;
     }
     if (!strcmp(key, "gemm_debug")) {

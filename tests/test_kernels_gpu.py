@@ -206,3 +206,28 @@ def test_gemm_8phase_is_bitwise_equal_to_simple_kernel_under_repetition(gu):
                     assert torch.equal(out, ref), (mode, M, N, K, rep, (out - ref).abs().max().item())
     finally:
         _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
+
+
+@pytest.mark.parametrize("tile", [1, 3, 4])
+def test_gemm_staged_epilogue_is_bitwise_equal_to_direct(gu, tile):
+    """The LDS-staged epilogue (row table + 64x32 pieces written back as full row segments) only re-routes the stores:
+    outputs must be bit-identical to the per-fragment epilogue, for fp32 (+bias, +residual), GELU and plain outputs,
+    ragged M / N and both modes."""
+    lib = _lib.get_lib()
+    cases = [(300, 272, 128), (1000, 1152, 192), (77, 48, 512), (513, 400, 384), (2049, 768, 768)]
+    try:
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", tile))
+        for mode in ("parity", "fast"):
+            for (M, N, K) in cases:
+                a, w, b, r = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23), rnd(M, N, seed=24)
+                outs = []
+                for staged in (0, 1):
+                    _lib.check(lib.cwm_debug_set(b"gemm_staged", staged))
+                    outs.append((gu.linear(a, w, b, mode=mode), gu.linear(a, w, b, resid=r, mode=mode), gu.linear(a, w, b, gelu=True, mode=mode),
+                                 gu.linear(a, w, None, mode=mode)))
+                for o0, o1 in zip(*outs):
+                    assert torch.equal(o0, o1), (tile, mode, M, N, K)
+                assert (outs[1][1] - (F.linear(a, w, b) + r)).abs().max().item() <= TOL[mode]
+    finally:
+        _lib.check(lib.cwm_debug_set(b"gemm_staged", 1))
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))

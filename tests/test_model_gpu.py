@@ -153,3 +153,29 @@ def test_weight_reload_is_picked_up():
         ref = O.vmae_forward(W, TINY_SPEC, xp.cpu(), mask.cpu())
     assert (y2.cpu() - ref).abs().max().item() <= 2e-4
     assert (y1 - y2).abs().max().item() > 1e-2
+
+
+def test_qkv_epilogue_variants_agree_end_to_end():
+    """Direct vs LDS-staged GEMM epilogues (QKV head scatter included) and every tile configuration: same forward output,
+    bit for bit (all of them apply the same product sequence to every accumulator)."""
+    g = np.load(os.path.join(GOLDEN, "tiny_8x8_k4.npz"))
+    seed, x, mask = case_inputs(g, TINY)
+    lib = _lib.get_lib()
+    outs = {}
+    try:
+        for mode in ("parity", "fast"):
+            m = build(TINY, seed, mode=mode)
+            G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+            for staged in (1, 0):
+                for tile in (0, 1, 3, 4):
+                    _lib.check(lib.cwm_debug_set(b"gemm_staged", staged))
+                    _lib.check(lib.cwm_debug_set(b"gemm_tile", tile))
+                    outs[(mode, staged, tile)] = m(G._preprocess(x.cuda()), mask.cuda()).cpu()
+            ref = outs[(mode, 1, 0)]
+            for key, y in outs.items():
+                if key[0] == mode:
+                    assert torch.equal(y, ref), key
+    finally:
+        _lib.check(lib.cwm_debug_set(b"gemm_staged", 1))
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
+    assert np.abs(outs[("parity", 1, 0)].numpy() - g["y_tokens"]).max() <= 2e-4
