@@ -1,0 +1,267 @@
+// Device-side building blocks shared by the GEMM kernels (gemm.hip, gemm_sk.hip): LDS tile addressing, exact-erf GELU,
+// row maps and the fused epilogues.  Not part of the C ABI.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+#include <type_traits>
+
+namespace cwm {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+template <int BK>
+__device__ __forceinline__ int lds_swizzle(int row) {
+    if constexpr (BK == 64) {
+        return (row >> 1) & 7;
+    } else {
+        // 64-byte rows: 4 rows share one 256-byte bank row; permute so each ds_read_b128 lane group
+        // (rows {0-3,12-15} at chunk c, rows {4-11} at chunk c^1) covers 16 distinct 16-byte slots.
+        return (0x78 >> (2 * ((row >> 2) & 3))) & 3;  // {0,2,3,1}
+    }
+}
+
+template <int BK>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * (BK * 2) + ((chunk ^ lds_swizzle<BK>(row)) << 4);
+}
+
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU default, VideoMAE/utils.py:38,49).  erf by Abramowitz & Stegun
+// 7.1.26 with v_rcp / v_exp: |gelu error| <= 4e-7 over [-8, 8] in fp32 (checked against scipy), i.e. at
+// the level of fp32 rounding of the exact form, at a third of the VALU cost of ocml erff (no branches).
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(t, poly, 1.421413741f);
+    poly = fmaf(t, poly, -0.284496736f);
+    poly = fmaf(t, poly, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
+    const float erf_abs = fmaf(-poly, e, 1.0f);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, z));
+}
+
+struct RowMap {
+    int out_row, res_row, b, tok;
+};
+
+__device__ __forceinline__ RowMap map_row(const GemmParams& p, int m) {
+    RowMap r;
+    if (p.rows_in > 0) {
+        r.b = m / p.rows_in;
+        r.tok = m - r.b * p.rows_in;
+        r.out_row = r.b * p.rows_out + r.tok;
+        r.res_row = p.resid_rowmap ? p.resid_rowmap[r.b * p.map_stride + r.tok] : r.out_row;
+    } else {
+        r.b = 0;
+        r.tok = m;
+        r.out_row = m;
+        r.res_row = m;
+    }
+    return r;
+}
+
+// Q / K / V output base.  (Written as a select of three loaded VALUES: hipcc turns `which == 0 ? p.q_out : ...` over the
+// three adjacent pointer fields into a dynamic index into the kernel-argument struct, which then lives in scratch.)
+__device__ __forceinline__ bf16* qkv_out_base(const GemmParams& p, int which) {
+    bf16 *qo = p.q_out, *ko = p.k_out, *vo = p.v_out;
+    asm volatile("" : "+s"(qo), "+s"(ko), "+s"(vo));
+    return which == 0 ? qo : which == 1 ? ko : vo;
+}
+
+// One transposed accumulator fragment: v[r] = C[m][nb + ncol + r] (nb = the fragment's first column, wave-uniform;
+// ncol = (lane >> 4) * 4), with rm = map_row(p, m).  Shared by every GEMM kernel of this file.
+template <int PLANES>
+__device__ __forceinline__ void epilogue_frag(const GemmParams& p, const RowMap& rm, int nb, int ncol, f32x4 v) {
+    const int n = nb + ncol;
+    if (p.debug & 2) {
+        asm volatile("" ::"v"(v));
+        return;
+    }
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.epi == EPI_F32) {
+        if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)rm.res_row * p.ldr + n);
+        *reinterpret_cast<f32x4*>(p.C + (size_t)rm.out_row * p.ldc + n) = v;
+        return;
+    }
+    bf16* dst;
+    int64_t plane;
+    if (p.epi == EPI_QKV) {
+        const int D = p.qkv_dim;
+        const int which = nb / D;  // 0 q, 1 k, 2 v (uniform per 16-column fragment)
+        const int c = n - which * D;
+        const int h = c / p.head_dim, d = c - h * p.head_dim;
+        if (which == 0) v *= p.q_scale;
+        dst = qkv_out_base(p, which) + ((size_t)(rm.b * p.heads + h) * p.n_tok + rm.tok) * p.head_dim + d;
+        plane = p.qk_plane;
+    } else {
+        if (p.epi == EPI_BF16_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        }
+        dst = p.out_hi + a_pos<PLANES>(rm.out_row, p.ldo, n);  // A-operand layout of the next GEMM
+        plane = kLoOffset;
+    }
+    bf16x4 hv, lv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bf16 hi = (bf16)v[r];
+        hv[r] = hi;
+        lv[r] = (bf16)(v[r] - (float)hi);
+    }
+    if (p.debug & 1) {
+        asm volatile("" ::"v"(hv), "v"(lv), "v"(dst));
+        return;
+    }
+    *reinterpret_cast<bf16x4*>(dst) = hv;
+    if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + plane) = lv;
+}
+
+// Transposed accumulators: acc[i][j][r] = C[m0 + wr*64 + i*16 + (lane&15)][n0 + wc*64 + j*16 + (lane>>4)*4 + r]
+template <int PLANES, int FM, int FN>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (&acc)[FM][FN], int m0, int n0, int wr, int wc, int lane) {
+    const int ncol = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wr * (16 * FM) + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const RowMap rm = map_row(p, m);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int nb = n0 + wc * (16 * FN) + j * 16;  // fragment's first column (wave-uniform)
+            if (nb >= p.N) continue;
+            epilogue_frag<PLANES>(p, rm, nb, ncol, acc[i][j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-staged epilogue (p.staged): the accumulator layout (16 rows x 4 lane groups of 4 columns) gives 32- / 64-byte
+// runs per row and makes every lane redo the row -> (batch, token) division for each of its rows; measured, that
+// epilogue was 30 % (parity) to 47 % (fast) of a K = 768 GEMM.  Here the workgroup first writes a row table
+// (one division per tile row) to LDS; then every wave pushes its tile through a private 8-KiB LDS buffer one
+// 64-row x 32-column piece at a time and reads it back row-major, so that every global access of the epilogue is a
+// 16-byte lane access forming full 128-byte (64-byte: fast-mode bf16, Q/K/V) row segments.
+//   piece buffer: [64 rows][128 B], 16-byte chunk c of row r at c ^ (r & 7)
+//     fp32: chunk = 4 columns;  bf16: chunks 0-3 = hi of 8 columns each, chunks 4-7 = lo (parity only)
+//   row table: out_row / residual row (EPI_F32, EPI_BF16*), b * heads * n_tok + token / - (EPI_QKV); -1 = row >= M
+__device__ __forceinline__ void epilogue_row_table(const GemmParams& p, int2* tab, int m0, int bm, int tid) {
+    if (tid < bm) {
+        const int m = m0 + tid;
+        int2 e = make_int2(-1, 0);
+        if (m < p.M) {
+            const RowMap rm = map_row(p, m);
+            e = (p.epi == EPI_QKV) ? make_int2(rm.b * p.heads * p.n_tok + rm.tok, 0) : make_int2(rm.out_row, rm.res_row);
+        }
+        tab[tid] = e;
+    }
+}
+
+// frag(i, j): the piece's fragment of rows 16 i .. 16 i + 15, columns 16 j .. 16 j + 15 (i < 4, j < 2)
+template <int PLANES, class Frag>
+__device__ __forceinline__ void epilogue_piece(const GemmParams& p, Frag frag, char* wlds, const int2* tab, int row0, int nb, int lane) {
+    if (nb >= p.N) return;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool f32_out = p.epi == EPI_F32;
+    int which = 0;
+    bf16* qkv_base = nullptr;
+    if (p.epi == EPI_QKV) {
+        which = nb / p.qkv_dim;
+        qkv_base = qkv_out_base(p, which);
+    }
+    // ---- accumulators (+ bias, activation, split) -> piece buffer ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (nb + j * 16 >= p.N) continue;
+        f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16 + fq * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 16 + fr;
+            f32x4 v = frag(i, j) + bias;
+            if (f32_out) {
+                *reinterpret_cast<f32x4*>(wlds + r * 128 + (((j * 4 + fq) ^ (r & 7)) << 4)) = v;
+            } else {
+                if (p.epi == EPI_BF16_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                } else if (which == 0 && p.epi == EPI_QKV) {
+                    v *= p.q_scale;
+                }
+                bf16x4 hv, lv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bf16 hi = (bf16)v[e];
+                    hv[e] = hi;
+                    lv[e] = (bf16)(v[e] - (float)hi);
+                }
+                const int ch = j * 2 + (fq >> 1), sub = (fq & 1) * 8;
+                *reinterpret_cast<bf16x4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4) + sub) = hv;
+                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(wlds + r * 128 + (((ch + 4) ^ (r & 7)) << 4) + sub) = lv;
+            }
+        }
+    }
+    if (p.debug & 1) return;
+    // ---- piece buffer -> global, row-major ----
+    if (f32_out || PLANES == 2) {
+        const int c = lane & 7;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int r = s * 8 + (lane >> 3);
+            const int2 info = tab[row0 + r];
+            f32x4 v = *reinterpret_cast<const f32x4*>(wlds + r * 128 + ((c ^ (r & 7)) << 4));
+            if (info.x < 0) continue;
+            if (f32_out) {
+                const int n = nb + c * 4;
+                if (n >= p.N) continue;
+                if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)info.y * p.ldr + n);
+                *reinterpret_cast<f32x4*>(p.C + (size_t)info.x * p.ldc + n) = v;
+            } else {
+                const int n = nb + (c & 3) * 8, lo = c >> 2;
+                if (n >= p.N) continue;
+                bf16* dst;
+                if (p.epi == EPI_QKV) {
+                    const int cD = n - which * p.qkv_dim, h = cD / p.head_dim, d = cD - h * p.head_dim;
+                    dst = qkv_base + (size_t)lo * p.qk_plane + ((size_t)(info.x + h * p.n_tok)) * p.head_dim + d;
+                } else {
+                    dst = p.out_hi + a_pos<2>(info.x, p.ldo, n) + lo * kLoOffset;
+                }
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+    } else {
+        const int c = lane & 3;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = s * 16 + (lane >> 2);
+            const int2 info = tab[row0 + r];
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wlds + r * 128 + ((c ^ (r & 7)) << 4));
+            const int n = nb + c * 8;
+            if (info.x < 0 || n >= p.N) continue;
+            bf16* dst;
+            if (p.epi == EPI_QKV) {
+                const int cD = n - which * p.qkv_dim, h = cD / p.head_dim, d = cD - h * p.head_dim;
+                dst = qkv_base + ((size_t)(info.x + h * p.n_tok)) * p.head_dim + d;
+            } else {
+                dst = p.out_hi + (size_t)info.x * p.ldo + n;
+            }
+            *reinterpret_cast<f32x4*>(dst) = v;
+        }
+    }
+}
+
+// Whole wave tile (FM x FN fragments at tile rows wrow0.., columns ncol0..) through the staged epilogue.
+template <int PLANES, int FM, int FN>
+__device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4 (&acc)[FM][FN], char* wlds, const int2* tab, int wrow0,
+                                                int ncol0, int lane) {
+    static_assert(FM % 4 == 0 && FN % 2 == 0, "wave tile must be a multiple of the 64x32 piece");
+#pragma unroll
+    for (int pi = 0; pi < FM / 4; ++pi)
+#pragma unroll
+        for (int pj = 0; pj < FN / 2; ++pj)
+            epilogue_piece<PLANES>(p, [&](int i, int j) { return acc[pi * 4 + i][pj * 2 + j]; }, wlds, tab, wrow0 + pi * 64, ncol0 + pj * 32, lane);
+}
+
+}  // namespace cwm

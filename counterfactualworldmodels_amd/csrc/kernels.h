@@ -40,14 +40,24 @@ struct GemmParams {
     int64_t qk_plane;
     int qkv_dim, heads, head_dim, n_tok;
     float q_scale;
+    // stream-K kernel (gemm_sk.hip); filled in by launch_gemm
+    float rows_in_inv;   // 1 / rows_in
+    float* sk_slabs;     // [grid][256*256] fp32 partial accumulators of split tiles
+    unsigned* sk_flags;  // [grid] slab published in launch `sk_epoch`
+    unsigned* sk_err;    // set to 1 if a hand-off wait timed out
+    unsigned sk_epoch;
     int staged;  // set by launch_gemm: epilogue through LDS with full-line global accesses (gemm.hip)
     int debug;  // development ablations (cwm_debug_set "gemm_debug"): bit 0 skip the epilogue's global stores, bit 1 skip the epilogue
 };
 
 int launch_gemm(const GemmParams& p, int planes, hipStream_t stream);
+int launch_gemm_sk(GemmParams& p, int planes, hipStream_t stream);  // persistent stream-K 8-phase kernel (gemm_sk.hip)
+bool sk_shape_ok(int M, int N, int K, int planes, int grid);
+int sk_grid_size();
+int sk_error_flag();
 extern int g_gemm_debug;
 extern int g_gemm_staged;
-extern int g_gemm_tile;    // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256 output tile, 4: 256x256 8-phase
+extern int g_gemm_tile;    // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256 output tile, 4: 256x256 8-phase, 5: persistent stream-K 8-phase
 
 struct AttnParams {
     const bf16* q;   // [planes][B*H][N][64]   (q pre-scaled by hd^-0.5)

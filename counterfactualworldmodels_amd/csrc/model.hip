@@ -462,6 +462,7 @@ extern "C" int cwm_debug_set(const char* key, int value) {
         g_gemm_tile = value;
         return CWM_OK;
     }
+    if (!strcmp(key, "sk_error")) return sk_error_flag() == 0 ? CWM_OK : CWM_ERR_INVALID;  // query: stream-K hand-off timeouts
     if (!strcmp(key, "gemm_staged")) {
         g_gemm_staged = value;
         return CWM_OK;
