@@ -42,12 +42,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qcol = lane & 31, hh = lane >> 5;
     const int N = p.n_tok;
     const int bh = blockIdx.y;
     const int b = bh / p.heads, h = bh - b * p.heads;
     const int q0 = blockIdx.x * 128 + wave * 32;
+    // a wave whose 32 query rows all lie past the sequence end (N = 792: three of the 28 wave slots per head) only helps to
+    // stage the K / V tiles: its MFMA / softmax work is skipped, leaving the matrix pipe to the co-resident workgroup
+    const bool active = q0 < p.n_tok;
 
     const bf16* Qb = p.q + (size_t)bh * N * 64;
     const bf16* Kb = p.k + (size_t)bh * N * 64;
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
         if (kt + 1 < nkt) load_tiles(kt + 1);
         const char* base = smem + cur * STAGE_BYTES;
 
+        if (active) {
         // ---- S^T = K Q^T ------------------------------------------------------------------------
         f32x16 sacc[2];
 #pragma unroll
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
                 oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, oacc[db], 0, 0, 0);
             }
         }
+        }  // active
 
         if (kt + 1 < nkt) store_tiles(cur ^ 1);
         __syncthreads();
