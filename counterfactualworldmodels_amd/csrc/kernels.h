@@ -71,6 +71,7 @@ struct AttnParams {
 };
 
 int launch_attention(const AttnParams& p, int planes, hipStream_t stream);
+extern int g_attn_kernel;  // 0 auto, 1: 4-wave kernel, 2: 8-wave staggered kernel
 
 struct LayerNormParams {
     const float* x;  // rows of length D, row stride ldx

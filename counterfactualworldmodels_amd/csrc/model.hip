@@ -463,6 +463,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
         return CWM_OK;
     }
     if (!strcmp(key, "sk_error")) return sk_error_flag() == 0 ? CWM_OK : CWM_ERR_INVALID;  // query: stream-K hand-off timeouts
+    if (!strcmp(key, "attn_kernel")) {
+        g_attn_kernel = value;
+        return CWM_OK;
+    }
     if (!strcmp(key, "gemm_staged")) {
         g_gemm_staged = value;
         return CWM_OK;

@@ -259,3 +259,25 @@ def test_gemm_stream_k_matches_simple_kernel(gu, mode):
             assert lib.cwm_debug_set(b"sk_error", 0) == 0, "a stream-K hand-off wait timed out"
     finally:
         _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
+
+
+def test_attention_8wave_kernel_is_bitwise_equal_to_4wave_kernel(gu):
+    """Race screen for the staggered 8-wave attention (LDS-DMA K/V rings, counted vmcnt, waves 4-7 one barrier behind waves
+    0-3): per-wave arithmetic is that of the 4-wave kernel, so outputs must be bit-identical -- one tile, ragged tails, odd
+    and even numbers of 128-query blocks, idle waves, the online-softmax rescale branch, repeated launches."""
+    lib = _lib.get_lib()
+    cases = [(2, 40, 1), (1, 64, 2), (3, 129, 2), (2, 300, 3), (2, 792, 12), (1, 1568, 6), (1, 1000, 2), (1, 3200, 1)]
+    try:
+        for mode in ("parity", "fast"):
+            for (B, N, H) in cases:
+                qkv = rnd(B, N, 3 * H * 64, seed=N + 1)
+                if N >= 300:
+                    qkv[0, N - 5, H * 64:H * 64 + 64] = qkv[0, 7, :64] * 6.0  # late spike: the running max jumps in the last tile
+                _lib.check(lib.cwm_debug_set(b"attn_kernel", 1))
+                ref = gu.attention(qkv, H, mode=mode)
+                _lib.check(lib.cwm_debug_set(b"attn_kernel", 2))
+                for rep in range(4):
+                    out = gu.attention(qkv, H, mode=mode)
+                    assert torch.equal(out, ref), (mode, B, N, H, rep, (out - ref).abs().max().item())
+    finally:
+        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))

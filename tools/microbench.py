@@ -47,11 +47,16 @@ def main():
     else:
         for name, B, H, N in ATTN_SHAPES:
             for mode in ("fast", "parity"):
-                best = 1e30
-                for _ in range(3):
-                    _lib.check(lib.cwm_bench_attention(B, H, N, _lib.mode_id(mode), 10, C.byref(us)))
-                    best = min(best, us.value)
-                print("%-8s %-6s B=%d H=%d N=%d  %8.1f us %7.1f TF" % (name, mode, B, H, N, best, 4.0 * B * H * N * N * 64 / best / 1e6), flush=True)
+                row = []
+                for kern in (1, 2):
+                    _lib.check(lib.cwm_debug_set(b"attn_kernel", kern))
+                    best = 1e30
+                    for _ in range(3):
+                        _lib.check(lib.cwm_bench_attention(B, H, N, _lib.mode_id(mode), 10, C.byref(us)))
+                        best = min(best, us.value)
+                    row.append("k%d %8.1f us %7.1f TF" % (kern, best, 4.0 * B * H * N * N * 64 / best / 1e6))
+                print("%-8s %-6s B=%d H=%d N=%d  %s" % (name, mode, B, H, N, " | ".join(row)), flush=True)
+        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))
 
 
 if __name__ == "__main__":
