@@ -147,6 +147,10 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p] * 6,
     ),
+    "cwm_flow_features": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
+    "cwm_flow_cov": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 4),
+    "cwm_flow_motion_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)] + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cwm_flow_map_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "cwm_bench_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cwm_bench_attention": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cwm_debug_set": (C.c_int, [C.c_char_p, C.c_int]),

@@ -102,3 +102,68 @@ def sharded_counterfactual_predictions(
         xs, ms = build_fn(xb, pb[:1])
         y_local = predict_fn(xs, ms)[:0]
     return all_gather_rows(y_local, S) if gather else y_local
+
+
+# ---- sample statistics over sharded samples -----------------------------------------------------------
+def all_gather_last_axis(x_local: torch.Tensor) -> torch.Tensor:
+    """Concatenate per-rank tensors along the LAST axis (rank order = sample order); sizes may differ (or be 0)."""
+    rank, world = _world()
+    if world == 1:
+        return x_local
+    n = torch.tensor([x_local.shape[-1]], dtype=torch.int64, device=x_local.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    width = max(max(counts), 1)
+    pad = torch.zeros(tuple(x_local.shape[:-1]) + (width,), dtype=x_local.dtype, device=x_local.device)
+    pad[..., : x_local.shape[-1]] = x_local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad.contiguous())
+    return torch.cat([p[..., :c] for p, c in zip(parts, counts)], -1)
+
+
+def sharded_flow_corrs(flow_samples_local: torch.Tensor, downsample: int = 1, use_covariance: bool = True, gather: bool = False,
+                       features_fn: Optional[Callable] = None, cov_rows_fn: Optional[Callable] = None) -> torch.Tensor:
+    """`FlowGenerator.compute_flow_corrs` (segmentation.py:479-547) when the S flow samples are spread over the ranks
+    (`flow_samples_local` [B,C,H,W,S_rank]).  One collective on small data: the pooled features [B,P,S_rank] are all-gathered
+    (P*S*4 bytes per frame pair: 12.8 MB at P = 12544, S = 256); then every rank computes rows `shard_range(P, rank, world)`
+    of the [P,P] matrix -- the 629-MB result stays sharded unless `gather`.  Returns [B,nrows,P] ([B,P,P] with gather).
+    `features_fn` / `cov_rows_fn` default to the HIP kernels (flowstats.py); the CPU tests inject the oracle."""
+    if features_fn is None or cov_rows_fn is None:
+        from . import flowstats
+
+        features_fn = features_fn or flowstats.flow_features
+        cov_rows_fn = cov_rows_fn or flowstats.feature_cov_rows
+    rank, world = _world()
+    B, _, H, W, S_local = flow_samples_local.shape
+    ds = int(downsample or 1)
+    if S_local > 0:
+        x_local = features_fn(flow_samples_local, ds)
+    else:  # a rank with an empty shard still joins the collective
+        x_local = torch.zeros((B, (H // ds) * (W // ds), 0), dtype=torch.float32, device=flow_samples_local.device)
+    x = all_gather_last_axis(x_local)
+    P = x.shape[1]
+    lo, hi = shard_range(P, rank, world)
+    slab = cov_rows_fn(x, lo, hi - lo, use_covariance)
+    if not gather or world == 1:
+        return slab
+    return all_gather_rows(slab.transpose(0, 1).contiguous(), P).transpose(0, 1).contiguous()
+
+
+def sharded_mean_motion_map(flows_local: torch.Tensor, normalize_per_sample: bool = False, normalize: bool = True, eps: float = 1e-2,
+                            sum_fn: Optional[Callable] = None, finish_fn: Optional[Callable] = None) -> torch.Tensor:
+    """`FlowGenerator.compute_mean_motion_map` (segmentation.py:257-276) over sharded samples: per-rank sums of the (per-sample
+    normalised) magnitudes, ONE all-reduce of [B,1,H,W] (+ the sample count), then the range normalisation on every rank."""
+    if sum_fn is None or finish_fn is None:
+        from . import flowstats
+
+        sum_fn = sum_fn or flowstats.motion_map_sum
+        finish_fn = finish_fn or flowstats.finish_motion_map
+    rank, world = _world()
+    B, _, H, W, S = flows_local.shape
+    total = sum_fn(flows_local, normalize_per_sample, eps) if S > 0 else torch.zeros((B, 1, H, W), dtype=torch.float32, device=flows_local.device)
+    n = torch.tensor([S], dtype=torch.int64, device=flows_local.device)
+    if world > 1:
+        dist.all_reduce(total)
+        dist.all_reduce(n)
+    return finish_fn(total, int(n.item()), normalize, eps)

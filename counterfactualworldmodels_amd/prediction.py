@@ -440,6 +440,23 @@ class PredictorBasedGenerator(nn.Module):
         return self.batch_predict_per_sample(
             x_mocos, masks=masks_mocos, frame=None, batch_size=(sample_batch_size or x_mocos.size(0)), sample_dim=0, **kwargs)
 
+    # ---- statistics over the flow samples (segmentation.py:250-276, 479-547): device kernels, see flowstats.py ----
+    def compute_flow_samples_magnitude(self, flows, normalize=True, dim=-4, eps=1e-2):
+        from . import flowstats
+
+        return flowstats.compute_flow_samples_magnitude(flows, normalize=normalize, dim=dim, eps=eps)
+
+    def compute_mean_motion_map(self, flows, normalize_per_sample=False, normalize=True, dim=-4, eps=1e-2):
+        from . import flowstats
+
+        return flowstats.compute_mean_motion_map(flows, normalize_per_sample=normalize_per_sample, normalize=normalize, dim=dim, eps=eps)
+
+    @staticmethod
+    def compute_flow_corrs(flow_samples, *args, **kwargs):
+        from . import flowstats
+
+        return flowstats.compute_flow_corrs(flow_samples, *args, **kwargs)
+
     def forward(self, x, mask=None, frame=None, *args, **kwargs):
         self.set_input(x, mask)
         if mask is None:

@@ -176,13 +176,40 @@ int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int
                       const uint8_t* active_dev, const uint8_t* masks_dev, const int32_t* shifts_dev, float* x_out_dev,
                       uint8_t* mask_out_dev, void* stream);
 
+/* ---- flow-sample statistics: the reductions over the S counterfactual flow samples -------------
+ * flows: fp32 device tensor addressed as flows[b*strides[0] + c*strides[1] + y*strides[2] + x*strides[3] + s*strides[4]]
+ * (elements), so both the reference's [B,C,H,W,S] view and the sample-major [(b s),C,H,W] batch the flow model emits work
+ * without a copy.  All asynchronous on `stream`.
+ *
+ * cwm_flow_features   x[B][P][S], P = (H/ds)(W/ds): ds x ds average pool per channel, then sqrt(mean_c(.^2))
+ *                     replaces: the `_ds` + `distance_func` (= ChannelMSE(dim=1) against zeros) prologue of
+ *                     FlowGenerator.compute_flow_corrs (segmentation.py:503-513; utils.py:510-513)
+ * cwm_flow_cov        out[B][nrows][P] = rows [row0, row0+nrows) of torch.cov(x[b]) (use_covariance) or torch.corrcoef(x[b])
+ *                     over the S samples, NaN -> 0.  replaces: segmentation.py:538-546.  Work buffers: xc [B][P][S], inv_std [B][P].
+ *                     Row slabs let ranks that all-gathered `x` each produce a part of the [P,P] matrix (dist.py).
+ * cwm_flow_motion_sum sum[B][H*W] = sum_s |flow| (magnitude over channels), each sample first range-normalised over (H,W)
+ *                     with max(range, eps) if normalize_per_sample (work buffer minmax [B][S][2]).
+ *                     replaces: compute_flow_samples_magnitude + the `.mean(-1)` numerator (segmentation.py:250-255, :264-268)
+ * cwm_flow_map_finish map = map*scale (scale = 1/S_total), then (map - min)/max(max - min, eps) per b if normalize.
+ *                     replaces: segmentation.py:273-275.  Split from the sum so that sample shards can be all-reduced in between. */
+int cwm_flow_features(const float* flows_dev, const int64_t* strides, int B, int C, int H, int W, int S, int downsample,
+                      float* x_dev, void* stream);
+int cwm_flow_cov(const float* x_dev, int B, int P, int S, int row0, int nrows, int use_covariance, float* xc_work_dev,
+                 float* inv_std_work_dev, float* out_dev, void* stream);
+int cwm_flow_motion_sum(const float* flows_dev, const int64_t* strides, int B, int C, int H, int W, int S,
+                        int normalize_per_sample, float eps, float* minmax_work_dev, float* sum_dev, void* stream);
+int cwm_flow_map_finish(float* map_dev, int B, int HW, float scale, int normalize, float eps, void* stream);
+
 /* ---- diagnostics: single-kernel micro-benchmarks on random operands (tools/microbench.py) ---------
  * epi: 0 = fp32 out + bias + in-place residual (proj/fc2 form), 1 = bias + GELU -> bf16 (fc1 form),
  *      3 = QKV head scatter (N must be 3*64*heads, M = batch*n_tok with n_tok = M / batch).
  * Runs `iters` back-to-back launches after 3 warm-up launches and returns the mean launch time. */
 int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters, double* avg_us);
 int cwm_bench_attention(int B, int H, int N, int mode, int iters, double* avg_us);
-/* development switches: "gemm_tile" (0 automatic per shape, 1: 128x128, 2: 256x128, 3: 256x256 output tile) */
+/* development switches: "gemm_tile" (0 automatic per shape, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase,
+ * 5: persistent stream-K 8-phase), "gemm_staged" (0: direct per-fragment epilogue), "gemm_debug" (epilogue ablations),
+ * "attn_kernel" (0 automatic, 1: 4-wave, 2: staggered 8-wave); query "sk_error" (non-zero return = a stream-K hand-off
+ * wait timed out) */
 int cwm_debug_set(const char* key, int value);
 
 const char* cwm_last_error(void);

@@ -310,6 +310,41 @@ def run_conj_cases(ns, skip_large=False):
     print(f"[golden] conj_imu400_b2.npz {tuple(y.shape)} std {y.std():.4f} ({time.time() - t0:.1f}s)")
 
 
+def flowstats_inputs(seed=0, shape=(2, 2, 16, 16, 12)):
+    """Seeded random flow samples [B,2,H,W,S] (one nearly-static sample, one constant sample)."""
+    g = torch.Generator().manual_seed(seed)
+    fl = torch.randn(*shape, generator=g) * 3
+    fl[..., 3] *= 0.01
+    fl[..., 5] = 0.25
+    return fl
+
+
+def run_flowstats_case(ns):
+    """`compute_flow_corrs` / `compute_mean_motion_map` / `compute_flow_samples_magnitude` of the reference
+    (cwm/models/segmentation.py:250-276, 479-547) on seeded random flows."""
+    FG = ns.segmentation.FlowGenerator
+
+    class _Self:  # the two map functions only use `self` to reach each other
+        pass
+
+    me = _Self()
+    me.compute_flow_samples_magnitude = lambda *a, **k: FG.compute_flow_samples_magnitude(me, *a, **k)
+    fl = flowstats_inputs()
+    out = {"seed": 0, "shape": np.array(fl.shape)}
+    for ds in (1, 2, 4):
+        rows = slice(0, 2) if ds == 1 else slice(None)  # ds = 1: the first two image rows of source positions only (file size)
+        out["cov_ds%d" % ds] = FG.compute_flow_corrs(fl, downsample=ds, use_covariance=True).numpy()[:, :, rows]
+        out["corr_ds%d" % ds] = FG.compute_flow_corrs(fl, downsample=ds, use_covariance=False).numpy()[:, :, rows]
+    for nps in (0, 1):
+        for nm in (0, 1):
+            out["map_nps%d_n%d" % (nps, nm)] = FG.compute_mean_motion_map(me, fl, normalize_per_sample=bool(nps), normalize=bool(nm)).numpy()
+    out["mag_norm"] = FG.compute_flow_samples_magnitude(me, fl, normalize=True).numpy()
+    out["map_4d"] = FG.compute_mean_motion_map(me, fl[..., 0].norm(dim=1, keepdim=True)).numpy()
+    out["cov_one_sample"] = FG.compute_flow_corrs(fl[..., :1], downsample=2, use_covariance=True).numpy()
+    np.savez_compressed(os.path.join(HERE, "flowstats.npz"), **out)
+    print("flowstats.npz written")
+
+
 def run_init_case(ns):
     """Reference constructor RNG parity: seed -> freshly initialised parameters (vmae.py:90,209,371)."""
     out = {}
@@ -345,7 +380,11 @@ def main():
     if args.only == "conj":
         run_conj_cases(ns, args.skip_large)
         return
+    if args.only == "flowstats":
+        run_flowstats_case(ns)
+        return
     run_init_case(ns)
+    run_flowstats_case(ns)
     run_shift_cases(ns)
     run_conj_cases(ns, args.skip_large)
     run_index_cases(ns)

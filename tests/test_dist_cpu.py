@@ -74,3 +74,62 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- sample statistics over sharded flow samples (dist.sharded_flow_corrs / sharded_mean_motion_map) ----------------------
+def _flow_cpu_hooks():
+    from oracle import flowstats_oracle as FO
+
+    def cov_rows(x, row0, nrows, use_cov):
+        out = []
+        for b in range(x.shape[0]):
+            c = torch.cov(x[b]) if use_cov else torch.corrcoef(x[b])
+            c[torch.isnan(c)] = 0
+            out.append(c[row0:row0 + nrows])
+        return torch.stack(out, 0)
+
+    def sum_fn(fl, nps, eps):
+        return FO.compute_flow_samples_magnitude(fl, normalize=nps, eps=eps).sum(-1)
+
+    def finish_fn(total, n, normalize, eps):
+        m = total / n
+        return FO.compute_mean_motion_map(m, eps=eps) if normalize else m
+
+    return FO.flow_features, cov_rows, sum_fn, finish_fn
+
+
+def _flow_inputs(S):
+    g = torch.Generator().manual_seed(5)
+    return torch.randn(2, 2, 8, 8, S, generator=g) * 2
+
+
+def _flow_worker(rank, world, port, S, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    feats, cov_rows, sum_fn, finish_fn = _flow_cpu_hooks()
+    lo, hi = cdist.shard_range(S, rank, world)
+    local = _flow_inputs(S)[..., lo:hi].contiguous()
+    cov = cdist.sharded_flow_corrs(local, downsample=2, use_covariance=True, gather=True, features_fn=feats, cov_rows_fn=cov_rows)
+    slab = cdist.sharded_flow_corrs(local, downsample=2, use_covariance=False, gather=False, features_fn=feats, cov_rows_fn=cov_rows)
+    mm = cdist.sharded_mean_motion_map(local, normalize_per_sample=True, normalize=True, sum_fn=sum_fn, finish_fn=finish_fn)
+    torch.save((cov, slab, mm), os.path.join(out_dir, "f%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S", [12, 7, 1])
+def test_sharded_flow_statistics_match_single_process(tmp_path, S):
+    from oracle import flowstats_oracle as FO
+
+    world = 2
+    mp.spawn(_flow_worker, args=(world, _free_port(), S, str(tmp_path)), nprocs=world, join=True)
+    fl = _flow_inputs(S)
+    cov = FO.compute_flow_corrs(fl, 2, True).reshape(2, 16, 16)
+    corr = FO.compute_flow_corrs(fl, 2, False).reshape(2, 16, 16)
+    mm = FO.compute_mean_motion_map(fl, normalize_per_sample=True, normalize=True)
+    for r in range(world):
+        c, slab, m = torch.load(os.path.join(str(tmp_path), "f%d.pt" % r))
+        lo, hi = cdist.shard_range(16, r, world)
+        assert torch.allclose(c, cov, atol=1e-6) and torch.allclose(slab, corr[:, lo:hi], atol=1e-6)
+        assert torch.allclose(m, mm, atol=1e-6)

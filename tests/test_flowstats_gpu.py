@@ -1,0 +1,103 @@
+"""Flow-sample statistics on a real MI355X, through the host mirror + C ABI: against the reference's own
+outputs (tests/golden/flowstats.npz), against the CPU oracle on other layouts, and size-independent properties at the full
+112 x 112 grid (a 12544 x 12544 matrix per frame pair)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from counterfactualworldmodels_amd import flowstats as FS
+from oracle import flowstats_oracle as FO
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLDEN)
+TOL = 1e-5  # fp32 statistics; the reference's torch.cov sums in a different order
+
+
+def _golden_inputs():
+    from make_golden import flowstats_inputs
+
+    return flowstats_inputs()
+
+
+def test_matches_reference_outputs():
+    g = np.load(os.path.join(GOLDEN, "flowstats.npz"))
+    fl = _golden_inputs().cuda()
+    for ds in (1, 2, 4):
+        rows = slice(0, 2) if ds == 1 else slice(None)
+        cov = FS.compute_flow_cov(fl, downsample=ds).cpu().numpy()[:, :, rows]
+        corr = FS.compute_flow_corrs(fl, downsample=ds).cpu().numpy()[:, :, rows]
+        assert cov.shape == g["cov_ds%d" % ds].shape
+        assert np.abs(cov - g["cov_ds%d" % ds]).max() <= TOL * max(1.0, np.abs(g["cov_ds%d" % ds]).max())
+        assert np.abs(corr - g["corr_ds%d" % ds]).max() <= 1e-5
+    for nps in (0, 1):
+        for nm in (0, 1):
+            m = FS.compute_mean_motion_map(fl, normalize_per_sample=bool(nps), normalize=bool(nm)).cpu().numpy()
+            ref = g["map_nps%d_n%d" % (nps, nm)]
+            assert m.shape == ref.shape and np.abs(m - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+    m4 = FS.compute_mean_motion_map(fl[..., 0].norm(dim=1, keepdim=True)).cpu().numpy()
+    assert np.abs(m4 - g["map_4d"]).max() <= TOL
+    assert np.abs(FS.compute_flow_samples_magnitude(fl).cpu().numpy() - g["mag_norm"]).max() <= TOL
+    one = FS.compute_flow_cov(fl[..., :1], downsample=2).cpu().numpy()
+    assert one.shape == g["cov_one_sample"].shape and not one.any()   # NaN -> 0 (segmentation.py:541)
+
+
+def test_sample_major_layout_and_ragged_sizes_match_oracle():
+    """The flow model emits [(b s),C,H,W]; the reference permutes it to [B,C,H,W,S] (segmentation.py:242-243): a strided view, read
+    in place.  Sizes that are not multiples of the 128 x 128 tile or of the 32-sample staging step."""
+    g = torch.Generator().manual_seed(3)
+    B, S, H, W = 2, 37, 24, 40
+    raw = torch.randn(B * S, 2, H, W, generator=g)
+    view = raw.view(B, S, 2, H, W).permute(0, 2, 3, 4, 1)   # [B,C,H,W,S], S stride = C*H*W
+    dev = raw.cuda().view(B, S, 2, H, W).permute(0, 2, 3, 4, 1)
+    assert not dev.is_contiguous()
+    for ds, cov in ((1, True), (2, False), (4, True)):
+        out = FS.compute_flow_corrs(dev, downsample=ds, use_covariance=cov).cpu()
+        ref = FO.compute_flow_corrs(view.contiguous(), ds, cov)
+        assert out.shape == ref.shape and (out - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item()), (ds, cov)
+    m = FS.compute_mean_motion_map(dev, normalize_per_sample=True).cpu()
+    assert (m - FO.compute_mean_motion_map(view.contiguous(), normalize_per_sample=True)).abs().max().item() <= TOL
+    # top-k samples and the "swap" concatenation (segmentation.py:500-511)
+    out = FS.compute_flow_corrs(dev, flow_samples_swap=dev.flip(-1), downsample=4, take_top_k=10, use_covariance=True).cpu()
+    x = torch.cat([FO.flow_features(view[..., :10].contiguous(), 4), FO.flow_features(view.flip(-1)[..., :10].contiguous(), 4)], -1)
+    ref = torch.stack([torch.cov(x[b]) for b in range(B)]).view(out.shape)
+    assert (out - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+
+
+def test_unsupported_options_fail_loudly():
+    fl = torch.zeros(1, 2, 8, 8, 4, device="cuda")
+    for kw in ({"do_spearman": True}, {"thresh": 0.1}, {"zscore": True}, {"normalize": True}, {"range_thresh": 0.5}):
+        with pytest.raises(NotImplementedError):
+            FS.compute_flow_corrs(fl, **kw)
+    with pytest.raises(RuntimeError):
+        FS.compute_flow_corrs(torch.zeros(1, 2, 8, 8, 4))   # CPU tensor: no fallback
+
+
+def test_full_grid_properties():
+    """224 x 224 flows, downsample 2 (the interface's setting): P = 12544, 629 MB of covariance.  Row slabs tile the matrix; it is
+    symmetric; its diagonal is the per-position sample variance; a constant sample set has zero covariance."""
+    g = torch.Generator().manual_seed(11)
+    S = 24
+    fl = (torch.randn(1, 2, 224, 224, S, generator=g) * 2).cuda()
+    x = FS.flow_features(fl, 2)
+    P = x.shape[1]
+    assert P == 12544
+    full = FS.feature_cov_rows(x, 0, P, True)[0]
+    assert (full - full.t()).abs().max().item() <= 1e-5
+    var = x[0].var(dim=1, unbiased=True)
+    assert (full.diagonal() - var).abs().max().item() <= 1e-5
+    for row0, nrows in ((0, 1), (3000, 1137), (P - 100, 100)):
+        slab = FS.feature_cov_rows(x, row0, nrows, True)[0]
+        assert torch.equal(slab, full[row0:row0 + nrows])
+    sub = torch.tensor([0, 17, 5000, P - 1], device="cuda")
+    ref = torch.cov(x[0][sub].double()).float()
+    assert (full[sub][:, sub] - ref).abs().max().item() <= 1e-5
+    corr = FS.feature_cov_rows(x, 100, 64, False)[0]
+    assert corr.abs().max().item() <= 1.0 and (corr[torch.arange(64), torch.arange(100, 164)] - 1).abs().max().item() <= 1e-5
+    const = torch.full((1, 2, 224, 224, 5), 0.5, device="cuda")
+    assert not FS.compute_flow_cov(const, downsample=2).any()
+    mm = FS.compute_mean_motion_map(fl)
+    assert mm.shape == (1, 1, 224, 224) and mm.min().item() == 0.0 and abs(mm.max().item() - 1.0) <= 1e-6
