@@ -58,6 +58,21 @@ def timed_steps(model, x, mask, n_vis, steps, distributed):
     return dt
 
 
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (separate FETCH_SIZE /
+    WRITE_SIZE runs, gfx950 corrections applied: tools/summarize_profiles.py -> profiles/pmc_summary_latest.json); None if the
+    summary is absent or was taken for another workload / mode.  (The counters cannot be read from inside this process.)"""
+    path = os.path.join(ROOT, "profiles", "pmc_summary_latest.json")
+    try:
+        with open(path) as f:
+            summ = json.load(f)
+        if summ.get("workload") != args.workload or summ.get("mode") != args.mode:
+            return None
+        return summ["hbm_bytes_per_launch"].get(kernel)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, k_vis, clump, seed, budget_s=20.0):
     """The oracle (CPU restatement of the reference, torch fp32 eager) on this box's host cores."""
     from oracle import vmae_oracle as O
@@ -245,7 +260,9 @@ def main():
 
     model.timing_enable(_lib.KCLASS_GEMM, True)
     dt = timed_steps(model, x, mask, n_vis, args.steps, distributed)
-    gemm = model.timing_collect(_lib.KCLASS_GEMM)
+    gemm = model.timing_collect(_lib.KCLASS_GEMM)                 # every GEMM launch ...
+    gemm_wide = model.timing_collect(_lib.KCLASS_GEMM_WIDE)       # ... split by the kernel that ran it
+    gemm_narrow = model.timing_collect(_lib.KCLASS_GEMM_NARROW)
     model.timing_enable(_lib.KCLASS_GEMM, False)
 
     value = B * n_gpus * args.steps / dt
@@ -266,13 +283,28 @@ def main():
         "model_tflops": flops_pair * value / 1e12,
         "model_frac_of_bf16_peak": flops_pair * value / 1e12 / (PEAK_BF16_TFLOPS * n_gpus),
     }
-    ach = gemm["total_flops"] / (gemm["total_ms"] * 1e-3) / 1e12 if gemm["total_ms"] > 0 else 0.0
+    planes = 2 if args.mode == "parity" else 1
+    kernels = {
+        "cwm::gemm8p_kernel<%d>" % planes: gemm_wide,                       # 256x256 8-phase: qkv, fc1
+        "cwm::gemm_bf16_kernel<%d, 128, 128, 2, 2>" % planes: gemm_narrow,  # proj, fc2, head, patch embed
+    }
+
+    def tflops(st):
+        return st["total_flops"] / (st["total_ms"] * 1e-3) / 1e12 if st["total_ms"] > 0 else 0.0
+
+    dom = max(kernels, key=lambda k: kernels[k]["total_ms"])  # dominant kernel = most device time in the timed region
+    st = kernels[dom]
+    ach = tflops(st)
     out["roofline"] = {
-        "bound": "mfma", "kernel": "cwm::gemm_bf16_kernel<%d>" % (2 if args.mode == "parity" else 1),
-        "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-        "launches": gemm["launches"], "avg_launch_us": 1e3 * gemm["total_ms"] / max(gemm["launches"], 1),
-        "note": "algorithmic 2*M*N*K of all GEMM launches in the timed region / summed HIP-event durations (rank 0)"
+        "bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+        "traffic": pmc_traffic(args, dom), "launches": st["launches"], "avg_launch_us": 1e3 * st["total_ms"] / max(st["launches"], 1),
+        "share_of_step": st["total_ms"] / (1e3 * dt) if dt > 0 else None,
+        "note": "algorithmic 2*M*N*K of this kernel's launches in the timed region / their summed HIP-event durations (rank 0)"
                 + ("; parity mode executes 3x these FLOPs on the MFMA pipe" if args.mode == "parity" else ""),
+        "all_gemm": {"achieved": tflops(gemm), "launches": gemm["launches"], "avg_launch_us": 1e3 * gemm["total_ms"] / max(gemm["launches"], 1),
+                     "share_of_step": gemm["total_ms"] / (1e3 * dt) if dt > 0 else None},
+        "other_kernel": {k: {"achieved": tflops(v), "launches": v["launches"], "avg_launch_us": 1e3 * v["total_ms"] / max(v["launches"], 1)}
+                         for k, v in kernels.items() if k != dom},
     }
 
     if not args.no_secondary:

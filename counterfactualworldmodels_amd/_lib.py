@@ -22,6 +22,8 @@ ERR_HIP = -2
 ERR_MASK = -3
 KCLASS_GEMM = 0
 KCLASS_ATTENTION = 1
+KCLASS_GEMM_WIDE = 2    # 256x256 8-phase kernel launches (booked together with KCLASS_GEMM)
+KCLASS_GEMM_NARROW = 3  # 128x128 kernel launches
 
 _MODES = {"fast": MODE_FAST, "parity": MODE_PARITY, MODE_FAST: MODE_FAST, MODE_PARITY: MODE_PARITY}
 

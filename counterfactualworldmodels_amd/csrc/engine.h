@@ -47,6 +47,7 @@ struct Slot {
 struct EventPair {
     hipEvent_t a, b;
     double flops;
+    int sub;  // kernel class the launch is also booked under (0: none)
 };
 
 struct KernelTimer {

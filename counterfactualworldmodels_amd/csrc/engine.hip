@@ -244,6 +244,7 @@ static int timer_begin(KernelTimer& t, double flops, hipStream_t s, EventPair** 
     }
     EventPair& e = t.pool[t.used++];
     e.flops = flops;
+    e.sub = 0;
     CWM_HIP_CHECK(hipEventRecord(e.a, s));
     *out = &e;
     return 0;
@@ -257,6 +258,7 @@ static int timer_end(EventPair* e, hipStream_t s) {
 int Engine::run_gemm(const GemmParams& p, int planes, hipStream_t s) {
     EventPair* e;
     if (int rc = timer_begin(timers[CWM_KCLASS_GEMM], 2.0 * p.M * (double)p.N * p.K, s, &e)) return rc;
+    if (e) e->sub = gemm_choose_tile(p, planes) >= 3 ? CWM_KCLASS_GEMM_WIDE : CWM_KCLASS_GEMM_NARROW;
     if (int rc = launch_gemm(p, planes, s)) return rc;
     return timer_end(e, s);
 }
@@ -278,6 +280,7 @@ int Engine::timing_enable(int kclass, int enable) {
         CWM_HIP_CHECK(hipEventCreate(&e.a));
         CWM_HIP_CHECK(hipEventCreate(&e.b));
         e.flops = 0;
+        e.sub = 0;
         t.pool.push_back(e);
     }
     return CWM_OK;
@@ -293,6 +296,12 @@ int Engine::timing_collect(int kclass, cwm_kernel_stats* out) {
         t.acc.launches += 1;
         t.acc.total_ms += ms;
         t.acc.total_flops += t.pool[i].flops;
+        if (t.pool[i].sub > 0 && t.pool[i].sub < CWM_KCLASS_COUNT) {  // per-kernel split of the GEMM class
+            cwm_kernel_stats& sa = timers[t.pool[i].sub].acc;
+            sa.launches += 1;
+            sa.total_ms += ms;
+            sa.total_flops += t.pool[i].flops;
+        }
     }
     t.used = 0;
     *out = t.acc;

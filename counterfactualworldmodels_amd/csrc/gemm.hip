@@ -397,6 +397,21 @@ int g_gemm_tile = 0;  // 0 = automatic choice per shape
 int g_gemm_debug = 0;
 int g_gemm_staged = 1;  // 0: force the direct (per-fragment) epilogue
 
+// Tile configuration for a launch: g_gemm_tile if set, else per shape.
+int gemm_choose_tile(const GemmParams& p, int planes) {
+    (void)planes;
+    int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase, 5: stream-K 8-phase
+    if (cfg == 0) {
+        // Measured on MI355X (tools/microbench.py, B/8 batch-32 and L/4 shapes, both modes): wide outputs (N >= 1024: qkv, fc1)
+        // run best on the 256x256 8-phase kernel (main loop at ~1.6 PFLOP/s of executed MFMA work); N <= 768 (proj, fc2,
+        // head, patch embed) on 128x128 with two workgroups per CU, whose epilogue overlaps the co-resident workgroup's
+        // main loop and whose grid quantises better (297 tiles of 256x256 are 1.16 rounds).  The persistent stream-K
+        // form (5) removes the quantisation but not the un-overlapped epilogue and is not selected automatically.
+        cfg = (p.N >= 1024 && p.M >= 512) ? 4 : 1;
+    }
+    return cfg;
+}
+
 int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) {
     GemmParams p = p_in;
     p.debug = g_gemm_debug;
@@ -421,16 +436,7 @@ int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) {
         else if (p.epi == EPI_QKV) p.staged = (p.qkv_dim % 32 == 0 && p.head_dim % 32 == 0);
         else p.staged = (p.ldo % 8 == 0);
     }
-    // ---- tile configuration: biggest tile whose grid still fills the chip reasonably ----
-    int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase, 5: stream-K 8-phase
-    if (cfg == 0) {
-        // Measured on MI355X (tools/microbench.py, B/8 batch-32 and L/4 shapes, both modes): wide outputs (N >= 1024: qkv, fc1)
-        // run best on the 256x256 8-phase kernel (main loop at ~1.6 PFLOP/s of executed MFMA work); N <= 768 (proj, fc2,
-        // head, patch embed) on 128x128 with two workgroups per CU, whose epilogue overlaps the co-resident workgroup's
-        // main loop and whose grid quantises better (297 tiles of 256x256 are 1.16 rounds).  The persistent stream-K
-        // form (5) removes the quantisation but not the un-overlapped epilogue and is not selected automatically.
-        cfg = (p.N >= 1024 && p.M >= 512) ? 4 : 1;
-    }
+    int cfg = gemm_choose_tile(p, planes);
     typedef void (*kern_t)(const GemmParams);
     if (cfg == 5) {
         if (sk_shape_ok(p.M, p.N, p.K, planes, sk_grid_size())) return launch_gemm_sk(p, planes, stream);

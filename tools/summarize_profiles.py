@@ -77,4 +77,8 @@ for mode in ("fast", "parity"):
                  algorithmic_TFLOPs=4.0 * 8 * 8 * 6272 * 6272 * 64 / ns / 1e3)
         out["attention_vit_l4_decoder_B8_H8_N6272_" + mode] = d
 json.dump(out, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
+# what bench.py reads for roofline.traffic (same command: base8 workload, parity mode)
+latest = {"tag": tag, "workload": "base8", "mode": "parity", "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag,
+          "hbm_bytes_per_launch": {k: t["hbm_bytes_per_launch_corrected"] for k, t in traffic.items()}}
+json.dump(latest, open(os.path.join(dst, "pmc_summary_latest.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
