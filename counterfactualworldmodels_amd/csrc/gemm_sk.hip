@@ -251,6 +251,11 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_kernel(const GemmParams p) {
         for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
             for (int ih = 0; ih < 2; ++ih) {
+                // (a fresh opaque copy of the lane id per row block: the row infos and addresses of the four row blocks must
+                // not be computed up front, where they would be spilled around the accumulators)
+                int lane_p = lane_e;
+                asm volatile("" : "+v"(lane_p));
+                const int lane = lane_p, frow = lane_p & 15, fq = lane_p >> 4;
                 const int rowbase = m0 + qm * 128 + wr * 64 + ih * 32;
                 constexpr int NROW = 4;  // read-back rows per lane (fast-mode bf16 outputs use the first 2)
                 int2 info[NROW];
@@ -480,8 +485,14 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_kernel(const GemmParams p) {
             if (cc.kend < nk) {
                 publish_head();  // the tail of this tile belongs to the next workgroup, which finishes it
             } else if (!(p.debug & 2)) {
-                if (cc.tile == ta && ka > 0) reduce_tail();  // the head came from the previous workgroup
-                epilogue_tile(m0c, n0c);
+                // (two copies of the epilogue rather than `if (tail) reduce; epilogue`: merging 128 conditionally updated
+                // accumulator registers at the join made hipcc copy and spill half of them)
+                if (cc.tile == ta && ka > 0) {
+                    reduce_tail();  // the head came from the previous workgroup
+                    epilogue_tile(m0c, n0c);
+                } else {
+                    epilogue_tile(m0c, n0c);
+                }
             } else {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
