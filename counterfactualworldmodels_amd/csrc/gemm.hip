@@ -366,12 +366,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
         int2* tab = reinterpret_cast<int2*>(smem + 8 * 8192);
         epilogue_row_table(p, tab, m0, 256, tid);
         __syncthreads();
-#pragma unroll
-        for (int qm = 0; qm < 2; ++qm)
-#pragma unroll
-            for (int qn = 0; qn < 2; ++qn)
-                epilogue_piece<PLANES>(p, [&](int i, int j) { return acc[qm][qn][i][j]; }, smem + wave * 8192, tab, qm * 128 + wr * 64,
-                                       n0 + qn * 128 + wc * 32, lane);
+        epilogue_piece_seq<PLANES, 4>(
+            p, [&](int pi, int i, int j) { return acc[pi >> 1][pi & 1][i][j]; }, [&](int pi) { return (pi >> 1) * 128 + wr * 64; },
+            [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, smem + wave * 8192, tab, lane);
         return;
     }
     const int ncol = (lane >> 4) * 4;
@@ -402,12 +399,25 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
     (void)planes;
     int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase, 5: stream-K 8-phase
     if (cfg == 0) {
-        // Measured on MI355X (tools/microbench.py, B/8 batch-32 and L/4 shapes, both modes): wide outputs (N >= 1024: qkv, fc1)
-        // run best on the 256x256 8-phase kernel (main loop at ~1.6 PFLOP/s of executed MFMA work); N <= 768 (proj, fc2,
-        // head, patch embed) on 128x128 with two workgroups per CU, whose epilogue overlaps the co-resident workgroup's
-        // main loop and whose grid quantises better (297 tiles of 256x256 are 1.16 rounds).  The persistent stream-K
-        // form (5) removes the quantisation but not the un-overlapped epilogue and is not selected automatically.
-        cfg = (p.N >= 1024 && p.M >= 512) ? 4 : 1;
+        // Measured on MI355X (tools/microbench.py gemm / gemm_l4: B/8 batch-32 and L/4 batch-8 shapes, both modes;
+        // gpurun_out/mb_gemm*_r1n.log):
+        //  * N >= 1024 (qkv, fc1, the L/4 proj / fc2): the 256x256 8-phase kernel, main loop at ~1.6 PFLOP/s of executed MFMA work
+        //  * N = 512 / 768: 256x256 tiles only if the grid quantises well (392 tiles = 1.53 rounds of 256 CUs: yes; 297 tiles =
+        //    1.16 rounds: no).  If not: 128x128 tiles with two workgroups per CU, whose epilogue overlaps the co-resident
+        //    workgroup's main loop.  (The persistent stream-K form (5) wins only the long-K case, fc2 of B/8: 305 vs 337 us in
+        //    parity mode = 1.8 % of the step; it is NOT selected automatically: its split tiles re-associate the fp32 sums, which
+        //    makes a sample's output depend on its position in the batch at the 3e-5 level, and a timed-out hand-off would only
+        //    show in an error word.)
+        //  * everything else (N = 384, head, patch embed, ragged N): 128x128
+        cfg = 1;
+        if (p.M >= 512 && p.N >= 1024) {
+            cfg = 4;
+        } else if (p.M >= 512 && p.N >= 512 && p.N % 256 == 0) {
+            const int64_t tiles = (int64_t)((p.M + 255) / 256) * (p.N / 256);
+            const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
+            const double fill = (double)tiles / (double)(((tiles + cus - 1) / cus) * cus);
+            if (fill >= 0.7) cfg = 4;
+        }
     }
     return cfg;
 }

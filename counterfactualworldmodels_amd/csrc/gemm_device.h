@@ -159,95 +159,148 @@ __device__ __forceinline__ void epilogue_row_table(const GemmParams& p, int2* ta
     }
 }
 
-// frag(i, j): the piece's fragment of rows 16 i .. 16 i + 15, columns 16 j .. 16 j + 15 (i < 4, j < 2)
-template <int PLANES, class Frag>
-__device__ __forceinline__ void epilogue_piece(const GemmParams& p, Frag frag, char* wlds, const int2* tab, int row0, int nb, int lane) {
-    if (nb >= p.N) return;
+// Where lanes with nothing to write (rows >= M, columns >= N) send their 16 bytes, and where they read a dummy residual.
+// Every global access of the staged epilogue is UNCONDITIONAL: exec-masked `if (valid) store` branches made hipcc lose count
+// of the vector-memory queue and wait `vmcnt(0)` before the next piece's first load result -- and since the counter retires in
+// order, each such wait also drained every store issued before it (measured: 40-60 us of a 100-us projection).
+static __device__ __attribute__((aligned(16))) float g_epilogue_trash[64 * 4];
+
+// A sequence of NPIECE 64-row x 32-column pieces of one wave through its 8-KiB LDS buffer.
+//   frag(pi, i, j): piece pi's fragment of rows 16 i .., columns 16 j .. (i < 4, j < 2); row0_of(pi): its first tile row;
+//   nb_of(pi): its first column (global, multiple of 32).
+// Order of the vector-memory operations: every bias load first; a piece is read back in two halves, and the residual rows of
+// the NEXT half are requested BEFORE the stores of this half are issued, so the (in-order) wait for them never waits for a store.
+template <int PLANES, int NPIECE, class Frag, class Row0, class Nb>
+__device__ __forceinline__ void epilogue_piece_seq(const GemmParams& p, Frag frag, Row0 row0_of, Nb nb_of, char* wlds, const int2* tab, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
     const bool f32_out = p.epi == EPI_F32;
-    int which = 0;
-    bf16* qkv_base = nullptr;
-    if (p.epi == EPI_QKV) {
-        which = nb / p.qkv_dim;
-        qkv_base = qkv_out_base(p, which);
-    }
-    // ---- accumulators (+ bias, activation, split) -> piece buffer ----
+    constexpr int NS = 8;  // read-back iterations of 8 rows (128-byte rows); fast-mode bf16 outputs: 4 iterations of 16 rows (64-byte rows)
+    const bool wide = f32_out || PLANES == 2;
+    // (explicitly GLOBAL pointers: a select between an output address and the trash buffer is otherwise a generic pointer
+    // and the accesses become flat_load / flat_store, which also count on lgkmcnt and complete out of order)
+    typedef __attribute__((address_space(1))) f32x4 gf32x4;
+    gf32x4* const trash = (gf32x4*)(g_epilogue_trash + lane * 4);
+
+    f32x4 bias[NPIECE][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (nb + j * 16 >= p.N) continue;
-        f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16 + fq * 4);
+    for (int pi = 0; pi < NPIECE; ++pi)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = i * 16 + fr;
-            f32x4 v = frag(i, j) + bias;
-            if (f32_out) {
-                *reinterpret_cast<f32x4*>(wlds + r * 128 + (((j * 4 + fq) ^ (r & 7)) << 4)) = v;
-            } else {
-                if (p.epi == EPI_BF16_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                } else if (which == 0 && p.epi == EPI_QKV) {
-                    v *= p.q_scale;
-                }
-                bf16x4 hv, lv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bf16 hi = (bf16)v[e];
-                    hv[e] = hi;
-                    lv[e] = (bf16)(v[e] - (float)hi);
-                }
-                const int ch = j * 2 + (fq >> 1), sub = (fq & 1) * 8;
-                *reinterpret_cast<bf16x4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4) + sub) = hv;
-                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(wlds + r * 128 + (((ch + 4) ^ (r & 7)) << 4) + sub) = lv;
-            }
+        for (int j = 0; j < 2; ++j) {
+            const int n = nb_of(pi) + j * 16;
+            bias[pi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) bias[pi][j] = *reinterpret_cast<const f32x4*>(p.bias + n + fq * 4);
         }
-    }
-    if (p.debug & 1) return;
-    // ---- piece buffer -> global, row-major ----
-    if (f32_out || PLANES == 2) {
-        const int c = lane & 7;
+
+    // residual rows of half a piece (unit u = 2 pi + half: read-back iterations 4 half .. 4 half + 3), EPI_F32 only
+    auto load_resid = [&](int u, f32x4 (&rv)[NS / 2]) {
+        const int pi = u >> 1, hf = u & 1;
+        const int n = nb_of(pi) + (lane & 7) * 4;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int r = s * 8 + (lane >> 3);
-            const int2 info = tab[row0 + r];
-            f32x4 v = *reinterpret_cast<const f32x4*>(wlds + r * 128 + ((c ^ (r & 7)) << 4));
-            if (info.x < 0) continue;
-            if (f32_out) {
-                const int n = nb + c * 4;
-                if (n >= p.N) continue;
-                if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)info.y * p.ldr + n);
-                *reinterpret_cast<f32x4*>(p.C + (size_t)info.x * p.ldc + n) = v;
-            } else {
-                const int n = nb + (c & 3) * 8, lo = c >> 2;
-                if (n >= p.N) continue;
-                bf16* dst;
-                if (p.epi == EPI_QKV) {
-                    const int cD = n - which * p.qkv_dim, h = cD / p.head_dim, d = cD - h * p.head_dim;
-                    dst = qkv_base + (size_t)lo * p.qk_plane + ((size_t)(info.x + h * p.n_tok)) * p.head_dim + d;
+        for (int s = 0; s < NS / 2; ++s) {
+            const int2 info = tab[row0_of(pi) + (hf * 4 + s) * 8 + (lane >> 3)];
+            const bool ok = p.resid && info.x >= 0 && n < p.N;
+            const gf32x4* src = ok ? (const gf32x4*)(p.resid + (size_t)info.y * p.ldr + n) : trash;
+            rv[s] = *src;  // raw: the "valid" select is applied where the value is used, so that nothing waits for the load here
+        }
+    };
+    f32x4 rv_next[NS / 2];
+    if (f32_out) load_resid(0, rv_next);
+
+#pragma unroll
+    for (int pi = 0; pi < NPIECE; ++pi) {
+        const int nb = nb_of(pi), row0 = row0_of(pi);
+        int which = 0;
+        bf16* qkv_base = nullptr;
+        int qh = 0, qd = 0;
+        if (p.epi == EPI_QKV) {
+            which = nb / p.qkv_dim;
+            qkv_base = qkv_out_base(p, which);
+            const int cD = nb - which * p.qkv_dim;
+            qh = cD / p.head_dim;
+            qd = cD - qh * p.head_dim;
+        }
+        // ---- accumulators (+ bias, activation, split) -> piece buffer ----
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = i * 16 + fr;
+                f32x4 v = frag(pi, i, j) + bias[pi][j];
+                if (f32_out) {
+                    *reinterpret_cast<f32x4*>(wlds + r * 128 + (((j * 4 + fq) ^ (r & 7)) << 4)) = v;
                 } else {
-                    dst = p.out_hi + a_pos<2>(info.x, p.ldo, n) + lo * kLoOffset;
+                    if (p.epi == EPI_BF16_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    } else if (which == 0 && p.epi == EPI_QKV) {
+                        v *= p.q_scale;
+                    }
+                    bf16x4 hv, lv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf16 hi = (bf16)v[e];
+                        hv[e] = hi;
+                        lv[e] = (bf16)(v[e] - (float)hi);
+                    }
+                    const int ch = j * 2 + (fq >> 1), sub = (fq & 1) * 8;
+                    *reinterpret_cast<bf16x4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4) + sub) = hv;
+                    if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(wlds + r * 128 + (((ch + 4) ^ (r & 7)) << 4) + sub) = lv;
                 }
-                *reinterpret_cast<f32x4*>(dst) = v;
             }
         }
-    } else {
-        const int c = lane & 3;
+        if (p.debug & 1) continue;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int r = s * 16 + (lane >> 2);
-            const int2 info = tab[row0 + r];
-            const f32x4 v = *reinterpret_cast<const f32x4*>(wlds + r * 128 + ((c ^ (r & 7)) << 4));
-            const int n = nb + c * 8;
-            if (info.x < 0 || n >= p.N) continue;
-            bf16* dst;
-            if (p.epi == EPI_QKV) {
-                const int cD = n - which * p.qkv_dim, h = cD / p.head_dim, d = cD - h * p.head_dim;
-                dst = qkv_base + ((size_t)(info.x + h * p.n_tok)) * p.head_dim + d;
+        for (int hf = 0; hf < 2; ++hf) {
+            // ---- half of the piece buffer -> registers (row-major 16-byte chunks), residual added ----
+            f32x4 v[NS / 2];
+            gf32x4* dst[NS / 2];
+            if (wide) {
+                const int c = lane & 7;
+#pragma unroll
+                for (int s = 0; s < NS / 2; ++s) {
+                    const int r = (hf * 4 + s) * 8 + (lane >> 3);
+                    const int2 info = tab[row0 + r];
+                    v[s] = *reinterpret_cast<const f32x4*>(wlds + r * 128 + ((c ^ (r & 7)) << 4));
+                    if (f32_out) {
+                        const int n = nb + c * 4;
+                        const bool ok = info.x >= 0 && n < p.N;
+                        if (ok && p.resid) v[s] += rv_next[s];
+                        dst[s] = ok ? (gf32x4*)(p.C + (size_t)info.x * p.ldc + n) : trash;
+                    } else {
+                        const int n = nb + (c & 3) * 8, lo = c >> 2;
+                        bf16* d;
+                        if (p.epi == EPI_QKV)
+                            d = qkv_base + (size_t)lo * p.qk_plane + ((size_t)(info.x + qh * p.n_tok)) * p.head_dim + qd + (c & 3) * 8;
+                        else
+                            d = p.out_hi + a_pos<2>(info.x, p.ldo, n) + lo * kLoOffset;
+                        dst[s] = (info.x >= 0 && n < p.N) ? (gf32x4*)d : trash;
+                    }
+                }
             } else {
-                dst = p.out_hi + (size_t)info.x * p.ldo + n;
+                const int c = lane & 3;
+#pragma unroll
+                for (int s = 0; s < NS / 4; ++s) {
+                    const int r = (hf * 2 + s) * 16 + (lane >> 2);
+                    const int2 info = tab[row0 + r];
+                    v[s] = *reinterpret_cast<const f32x4*>(wlds + r * 128 + ((c ^ (r & 7)) << 4));
+                    const int n = nb + c * 8;
+                    bf16* d;
+                    if (p.epi == EPI_QKV)
+                        d = qkv_base + ((size_t)(info.x + qh * p.n_tok)) * p.head_dim + qd + c * 8;
+                    else
+                        d = p.out_hi + (size_t)info.x * p.ldo + n;
+                    dst[s] = (info.x >= 0 && n < p.N) ? (gf32x4*)d : trash;
+                }
             }
-            *reinterpret_cast<f32x4*>(dst) = v;
+            // ---- the next half-piece's residual rows, then this half's stores ----
+            if (f32_out && 2 * pi + hf + 1 < 2 * NPIECE) load_resid(2 * pi + hf + 1, rv_next);
+            if (wide) {
+#pragma unroll
+                for (int s = 0; s < NS / 2; ++s) *dst[s] = v[s];
+            } else {
+#pragma unroll
+                for (int s = 0; s < NS / 4; ++s) *dst[s] = v[s];
+            }
         }
     }
 }
@@ -257,11 +310,10 @@ template <int PLANES, int FM, int FN>
 __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4 (&acc)[FM][FN], char* wlds, const int2* tab, int wrow0,
                                                 int ncol0, int lane) {
     static_assert(FM % 4 == 0 && FN % 2 == 0, "wave tile must be a multiple of the 64x32 piece");
-#pragma unroll
-    for (int pi = 0; pi < FM / 4; ++pi)
-#pragma unroll
-        for (int pj = 0; pj < FN / 2; ++pj)
-            epilogue_piece<PLANES>(p, [&](int i, int j) { return acc[pi * 4 + i][pj * 2 + j]; }, wlds, tab, wrow0 + pi * 64, ncol0 + pj * 32, lane);
+    constexpr int PJ = FN / 2, NPIECE = (FM / 4) * PJ;
+    epilogue_piece_seq<PLANES, NPIECE>(
+        p, [&](int pi, int i, int j) { return acc[(pi / PJ) * 4 + i][(pi % PJ) * 2 + j]; }, [&](int pi) { return wrow0 + (pi / PJ) * 64; },
+        [&](int pi) { return ncol0 + (pi % PJ) * 32; }, wlds, tab, lane);
 }
 
 }  // namespace cwm

@@ -213,7 +213,10 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_kernel(const GemmParams p) {
         else return make_int2(out_row, res_row);
     };
 
-    // ---- epilogue of one finished tile: 32-row x 32-column pieces through the wave's 4-KiB LDS buffer ----
+    // ---- epilogue of one finished tile: eight 32-row x 32-column pieces through the wave's 4-KiB LDS buffer ----
+    // Same access discipline as epilogue_piece_seq (gemm_device.h): unconditional GLOBAL loads / stores (lanes with nothing to
+    // write go to the trash buffer), every bias load first, the next piece's residual rows requested before this piece's
+    // stores are issued -- so the only vector-memory waits are counted ones for loads, never a drain of the stores.
     auto epilogue_tile = [&](int m0, int n0) {
         // (opaque copy of the lane id: keeps hipcc from hoisting the epilogue's address arithmetic out of the persistent
         // loop, where it would be spilled around the 224-register main loop)
@@ -223,6 +226,10 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_kernel(const GemmParams p) {
         const int lane = lane_e;
         char* wl = smem + RING_BYTES + wave * PIECE_BYTES;
         constexpr bool f32_out = EPI == EPI_F32;
+        constexpr bool wide = f32_out || PLANES == 2;  // 8 chunks (128 B) per row; else 4 chunks (64 B)
+        constexpr int NS = wide ? 4 : 2;               // read-back iterations per piece
+        typedef __attribute__((address_space(1))) f32x4 gf32x4;
+        gf32x4* const trash = (gf32x4*)(g_epilogue_trash + lane * 4);
         // per column block qn: QKV destination (which third, head, first d), uniform
         int which[2] = {0, 0}, qh[2] = {0, 0}, qd[2] = {0, 0};
         bf16* qbase[2] = {nullptr, nullptr};
@@ -237,7 +244,6 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_kernel(const GemmParams p) {
                 qbase[qn] = qkv_out_base(p, which[qn]);
             }
         }
-        // bias of the wave's 4 x 16 columns, once per tile (a load per piece would expose its latency 8 times)
         f32x4 bias4[2][2];
 #pragma unroll
         for (int qn = 0; qn < 2; ++qn)
@@ -247,110 +253,101 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_kernel(const GemmParams p) {
                 bias4[qn][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (p.bias && n < p.N) bias4[qn][j] = *reinterpret_cast<const f32x4*>(p.bias + n + fq * 4);
             }
+        // piece u = 2 blk + qn, row block blk = 2 qm + ih (32 rows of the wave's 128)
+        auto block_rows = [&](int blk, int2 (&info)[NS]) {
+            const int rowbase = m0 + (blk >> 1) * 128 + wr * 64 + (blk & 1) * 32;
 #pragma unroll
-        for (int qm = 0; qm < 2; ++qm)
+            for (int s = 0; s < NS; ++s) info[s] = row_info(rowbase + (wide ? s * 8 + (lane >> 3) : s * 16 + (lane >> 2)));
+        };
+        auto load_resid = [&](int qn, const int2 (&info)[NS], f32x4 (&rv)[NS]) {
+            const int n = n0 + qn * 128 + wc * 32 + (lane & 7) * 4;
 #pragma unroll
-            for (int ih = 0; ih < 2; ++ih) {
-                // (a fresh opaque copy of the lane id per row block: the row infos and addresses of the four row blocks must
-                // not be computed up front, where they would be spilled around the accumulators)
-                int lane_p = lane_e;
-                asm volatile("" : "+v"(lane_p));
-                const int lane = lane_p, frow = lane_p & 15, fq = lane_p >> 4;
-                const int rowbase = m0 + qm * 128 + wr * 64 + ih * 32;
-                constexpr int NROW = 4;  // read-back rows per lane (fast-mode bf16 outputs use the first 2)
-                int2 info[NROW];
-                constexpr bool wide = f32_out || PLANES == 2;  // 8 chunks (128 B) per row; else 4 chunks (64 B)
+            for (int s = 0; s < NS; ++s) {
+                const bool ok = p.resid && info[s].x >= 0 && n < p.N;
+                rv[s] = *(ok ? (const gf32x4*)(p.resid + (size_t)info[s].y * p.ldr + n) : trash);  // raw; selected at use
+            }
+        };
+        int2 info[NS];
+        f32x4 rv[NS];
+        block_rows(0, info);
+        if constexpr (f32_out) load_resid(0, info, rv);
 #pragma unroll
-                for (int s = 0; s < NROW; ++s) info[s] = row_info(rowbase + (wide ? s * 8 + (lane >> 3) : (s & 1) * 16 + (lane >> 2)));
+        for (int u = 0; u < 8; ++u) {
+            __builtin_amdgcn_sched_barrier(0);  // one piece at a time: keeps the epilogue's register footprint beside the accumulators small
+            const int blk = u >> 1, qn = u & 1, qm = blk >> 1, ih = blk & 1;
+            const int nb = n0 + qn * 128 + wc * 32;
+            // accumulators (+ bias, activation, split) -> piece buffer
 #pragma unroll
-                for (int qn = 0; qn < 2; ++qn) {
-                    __builtin_amdgcn_sched_barrier(0);  // one piece at a time: keeps the register footprint of the epilogue small
-                    const int nb = n0 + qn * 128 + wc * 32;
-                    if (nb >= p.N) continue;
-                    // residual rows of this piece, requested now: in flight during the write pass and the LDS round trip
-                    f32x4 rv[4];
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int il = 0; il < 2; ++il) {
+                    const int r = il * 16 + frow;
+                    f32x4 v = acc[qm][qn][ih * 2 + il][j] + bias4[qn][j];
                     if constexpr (f32_out) {
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            rv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            const int n = nb + (lane & 7) * 4;
-                            if (p.resid && info[s].x >= 0 && n < p.N) rv[s] = *reinterpret_cast<const f32x4*>(p.resid + (size_t)info[s].y * p.ldr + n);
-                        }
-                    }
-                    // accumulators (+ bias, activation, split) -> piece buffer
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if (nb + j * 16 >= p.N) continue;
-                        const f32x4 bias = bias4[qn][j];
-#pragma unroll
-                        for (int il = 0; il < 2; ++il) {
-                            const int r = il * 16 + frow;
-                            f32x4 v = acc[qm][qn][ih * 2 + il][j] + bias;
-                            if constexpr (f32_out) {
-                                *reinterpret_cast<f32x4*>(wl + r * 128 + (((j * 4 + fq) ^ (r & 7)) << 4)) = v;
-                            } else {
-                                if constexpr (EPI == EPI_BF16_GELU) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                                } else if constexpr (EPI == EPI_QKV) {
-                                    if (which[qn] == 0) v *= p.q_scale;
-                                }
-                                bf16x4 hv, lv;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const bf16 hi = (bf16)v[e];
-                                    hv[e] = hi;
-                                    lv[e] = (bf16)(v[e] - (float)hi);
-                                }
-                                const int ch = j * 2 + (fq >> 1), sub = (fq & 1) * 8;
-                                *reinterpret_cast<bf16x4*>(wl + r * 128 + ((ch ^ (r & 7)) << 4) + sub) = hv;
-                                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(wl + r * 128 + (((ch + 4) ^ (r & 7)) << 4) + sub) = lv;
-                            }
-                        }
-                    }
-                    if (p.debug & 1) continue;
-                    // piece buffer -> global, row-major 16-byte lane accesses
-                    if constexpr (wide) {
-                        const int c = lane & 7;
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            const int r = s * 8 + (lane >> 3);
-                            f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 128 + ((c ^ (r & 7)) << 4));
-                            if (info[s].x < 0) continue;
-                            if constexpr (f32_out) {
-                                const int n = nb + c * 4;
-                                if (n >= p.N) continue;
-                                v += rv[s];
-                                *reinterpret_cast<f32x4*>(p.C + (size_t)info[s].x * p.ldc + n) = v;
-                            } else {
-                                const int n = nb + (c & 3) * 8, lo = c >> 2;
-                                if (n >= p.N) continue;
-                                bf16* dst;
-                                if constexpr (EPI == EPI_QKV)
-                                    dst = qbase[qn] + (size_t)lo * p.qk_plane + ((size_t)(info[s].x + qh[qn] * p.n_tok)) * p.head_dim + qd[qn] + (c & 3) * 8;
-                                else
-                                    dst = p.out_hi + a_pos<2>(info[s].x, p.ldo, n) + lo * kLoOffset;
-                                *reinterpret_cast<f32x4*>(dst) = v;
-                            }
-                        }
+                        *reinterpret_cast<f32x4*>(wl + r * 128 + (((j * 4 + fq) ^ (r & 7)) << 4)) = v;
                     } else {
-                        const int c = lane & 3;
+                        if constexpr (EPI == EPI_BF16_GELU) {
 #pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const int r = s * 16 + (lane >> 2);
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 128 + ((c ^ (r & 7)) << 4));
-                            const int n = nb + c * 8;
-                            if (info[s].x < 0 || n >= p.N) continue;
-                            bf16* dst;
-                            if constexpr (EPI == EPI_QKV)
-                                dst = qbase[qn] + ((size_t)(info[s].x + qh[qn] * p.n_tok)) * p.head_dim + qd[qn] + c * 8;
-                            else
-                                dst = p.out_hi + (size_t)info[s].x * p.ldo + n;
-                            *reinterpret_cast<f32x4*>(dst) = v;
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        } else if constexpr (EPI == EPI_QKV) {
+                            if (which[qn] == 0) v *= p.q_scale;
                         }
+                        bf16x4 hv, lv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bf16 hi = (bf16)v[e];
+                            hv[e] = hi;
+                            lv[e] = (bf16)(v[e] - (float)hi);
+                        }
+                        const int ch = j * 2 + (fq >> 1), sub = (fq & 1) * 8;
+                        *reinterpret_cast<bf16x4*>(wl + r * 128 + ((ch ^ (r & 7)) << 4) + sub) = hv;
+                        if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(wl + r * 128 + (((ch + 4) ^ (r & 7)) << 4) + sub) = lv;
                     }
                 }
             }
+            if (p.debug & 1) continue;
+            // piece buffer -> registers (row-major 16-byte chunks), residual added; destinations
+            f32x4 v[NS];
+            gf32x4* dst[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if constexpr (wide) {
+                    const int c = lane & 7, r = s * 8 + (lane >> 3);
+                    v[s] = *reinterpret_cast<const f32x4*>(wl + r * 128 + ((c ^ (r & 7)) << 4));
+                    if constexpr (f32_out) {
+                        const int n = nb + c * 4;
+                        const bool ok = info[s].x >= 0 && n < p.N;
+                        if (ok && p.resid) v[s] += rv[s];
+                        dst[s] = ok ? (gf32x4*)(p.C + (size_t)info[s].x * p.ldc + n) : trash;
+                    } else {
+                        const int n = nb + (c & 3) * 8, lo = c >> 2;
+                        bf16* d;
+                        if constexpr (EPI == EPI_QKV)
+                            d = qbase[qn] + (size_t)lo * p.qk_plane + ((size_t)(info[s].x + qh[qn] * p.n_tok)) * p.head_dim + qd[qn] + (c & 3) * 8;
+                        else
+                            d = p.out_hi + a_pos<2>(info[s].x, p.ldo, n) + lo * kLoOffset;
+                        dst[s] = (info[s].x >= 0 && n < p.N) ? (gf32x4*)d : trash;
+                    }
+                } else {
+                    const int c = lane & 3, r = s * 16 + (lane >> 2);
+                    v[s] = *reinterpret_cast<const f32x4*>(wl + r * 128 + ((c ^ (r & 7)) << 4));
+                    const int n = nb + c * 8;
+                    bf16* d;
+                    if constexpr (EPI == EPI_QKV)
+                        d = qbase[qn] + ((size_t)(info[s].x + qh[qn] * p.n_tok)) * p.head_dim + qd[qn] + c * 8;
+                    else
+                        d = p.out_hi + (size_t)info[s].x * p.ldo + n;
+                    dst[s] = (info[s].x >= 0 && n < p.N) ? (gf32x4*)d : trash;
+                }
+            }
+            // next piece: its row block's infos and residual rows are requested before this piece's stores go out
+            if (u + 1 < 8) {
+                if (((u + 1) >> 1) != blk) block_rows((u + 1) >> 1, info);
+                if constexpr (f32_out) load_resid((u + 1) & 1, info, rv);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *dst[s] = v[s];
+        }
     };
 
     // ---- split tiles: fp32 slab of this workgroup's accumulators, [wave][fragment][lane] x 16 bytes ----

@@ -23,6 +23,16 @@ GEMM_SHAPES = [
     ("b8.dec.fc1", 50176, 1536, 384, 1),
     ("b8.dec.fc2", 50176, 384, 1536, 0),
 ]
+L4_SHAPES = [
+    ("l4.enc.qkv", 25344, 3072, 1024, 3),
+    ("l4.enc.proj", 25344, 1024, 1024, 0),
+    ("l4.enc.fc1", 25344, 4096, 1024, 1),
+    ("l4.enc.fc2", 25344, 1024, 4096, 0),
+    ("l4.dec.qkv", 50176, 1536, 512, 3),
+    ("l4.dec.proj", 50176, 512, 512, 0),
+    ("l4.dec.fc1", 50176, 2048, 512, 1),
+    ("l4.dec.fc2", 50176, 512, 2048, 0),
+]
 ATTN_SHAPES = [("b8.enc", 32, 12, 792), ("b8.dec", 32, 6, 1568), ("l4.enc", 8, 16, 3168), ("l4.dec", 8, 8, 6272)]
 
 
@@ -32,8 +42,8 @@ def main():
     torch.cuda.init()
     lib = _lib.get_lib()
     us = C.c_double()
-    if what == "gemm":
-        for name, M, N, K, epi in GEMM_SHAPES:
+    if what in ("gemm", "gemm_l4"):
+        for name, M, N, K, epi in (GEMM_SHAPES if what == "gemm" else L4_SHAPES):
             for mode in ("fast", "parity"):
                 row = []
                 for v in variants:
