@@ -165,11 +165,15 @@ class ConjoinedPaddedVisionTransformer(nn.Module):
                 _lib.get_lib().cwm_conj_destroy(self._handle)
             except Exception:
                 pass
-            self._handle = None
-            self._loaded = {}
+            # plain attributes: nn.Module.__setattr__ can already be half torn down when __del__ runs at interpreter exit
+            object.__setattr__(self, "_handle", None)
+            object.__setattr__(self, "_loaded", {})
 
     def __del__(self):
-        self._release()
+        try:
+            self._release()
+        except Exception:
+            pass
 
     def sync_weights(self, device: Optional[torch.device] = None) -> int:
         device = device or next(self.parameters()).device

@@ -125,7 +125,11 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     const cwm_config& c = m->cfg;
     const int B = a->batch, Nt = m->Nt, Nv = a->n_vis, Nm = Nt - Nv;
     CWM_REQUIRE(B > 0, "cwm_forward: batch must be positive");
-    CWM_REQUIRE(Nv > 0 && Nm > 0, "cwm_forward: need 0 < n_vis (%d) < num tokens (%d)", Nv, Nt);
+    CWM_REQUIRE(Nv > 0 && Nm >= 0, "cwm_forward: need 0 < n_vis (%d) <= num tokens (%d)", Nv, Nt);
+    // nothing masked: the reference decoder then returns head(norm(x)) for ALL tokens (vmae.py:250-253), and its wrapper cannot
+    // compose a video from that (prediction.py:252-254 would assign Nt rows to an empty selection)
+    CWM_REQUIRE(Nm > 0 || !a->y_video_dev, "cwm_forward: no token is masked, there is no predicted patch to un-embed");
+    const int Nret = Nm > 0 ? Nm : Nt;
     {
         char miss[256];
         const int nmiss = m->eng.missing_weights(miss, sizeof(miss));
@@ -168,17 +172,17 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     g.epi = EPI_F32; g.C = m->x_dec; g.ldc = c.dec_dim;
     g.resid = m->pos_dec; g.ldr = c.dec_dim; g.resid_rowmap = m->perm; g.rows_in = Nv; g.rows_out = Nt; g.map_stride = Nt;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
-    if ((rc = launch_fill_mask_tokens(m->x_dec, m->mask_token, m->pos_dec, m->perm, B, Nt, Nv, c.dec_dim, s))) return rc;
+    if (Nm > 0 && (rc = launch_fill_mask_tokens(m->x_dec, m->mask_token, m->pos_dec, m->perm, B, Nt, Nv, c.dec_dim, s))) return rc;
 
     // a9: decoder blocks over the full token set, norm + head on the last Nm tokens
     for (int i = 0; i < c.dec_depth; ++i)
         if ((rc = E.run_block(m->dec[i], m->x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, m->sb, s))) return rc;
     memset(&ln, 0, sizeof(ln));
     ln.x = m->x_dec; ln.ldx = c.dec_dim; ln.gamma = m->dec_norm_g; ln.beta = m->dec_norm_b; ln.eps = c.ln_eps; ln.D = c.dec_dim;
-    ln.rows = B * Nm; ln.rows_out_per_b = Nm; ln.rows_in_per_b = Nt; ln.in_offset = Nv;
-    ln.out = m->sb.hbuf; ln.out_plane = (int64_t)B * Nm * c.dec_dim; ln.ldo = c.dec_dim;
+    ln.rows = B * Nret; ln.rows_out_per_b = Nret; ln.rows_in_per_b = Nt; ln.in_offset = Nt - Nret;
+    ln.out = m->sb.hbuf; ln.out_plane = (int64_t)B * Nret * c.dec_dim; ln.ldo = c.dec_dim;
     if ((rc = launch_layernorm(ln, planes, s))) return rc;
-    g = gemm_base(m->sb.hbuf, c.dec_dim, m->head, B * Nm, planes);
+    g = gemm_base(m->sb.hbuf, c.dec_dim, m->head, B * Nret, planes);
     g.epi = EPI_F32; g.C = a->y_tokens_dev; g.ldc = m->out_dim;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
 

@@ -175,11 +175,15 @@ class PretrainVisionTransformer(nn.Module):
                 _lib.get_lib().cwm_model_destroy(self._handle)
             except Exception:
                 pass
-            self._handle = None
-            self._loaded = {}
+            # plain attributes: nn.Module.__setattr__ can already be half torn down when __del__ runs at interpreter exit
+            object.__setattr__(self, "_handle", None)
+            object.__setattr__(self, "_loaded", {})
 
     def __del__(self):
-        self._release()
+        try:
+            self._release()
+        except Exception:
+            pass
 
     def sync_weights(self, device: Optional[torch.device] = None) -> int:
         """Push every parameter that changed since the last call into the library (packs to bf16
@@ -221,7 +225,8 @@ class PretrainVisionTransformer(nn.Module):
         if n_vis is None:
             n_vis = Nt - int(mask[0].sum().item())
         Nm = Nt - n_vis
-        y = torch.empty((B, Nm, c.out_dim), device=dev, dtype=torch.float32)
+        # nothing masked: the reference returns head(norm(x)) for all Nt tokens (vmae.py:250-253)
+        y = torch.empty((B, Nm if Nm > 0 else Nt, c.out_dim), device=dev, dtype=torch.float32)
         video = torch.empty((B, c.num_frames, c.in_chans, c.img_size[0], c.img_size[1]), device=dev, dtype=torch.float32) if want_video else None
         args = _lib.CwmForwardArgs(
             x.data_ptr(), strides[0], strides[1], strides[2], int(normalize), mask.data_ptr(), B, n_vis, y.data_ptr(),

@@ -74,7 +74,8 @@ typedef struct cwm_forward_args {
     const uint8_t* mask_dev; /* bool [B, Nt], 1 = masked (torch.bool storage) */
     int32_t batch;
     int32_t n_vis;           /* visible tokens per row; every row must have exactly this many */
-    float* y_tokens_dev;     /* out [B, Nt - n_vis, in_chans*patch*patch] fp32, feature order (ph pw c) */
+    float* y_tokens_dev;     /* out [B, Nt - n_vis, in_chans*patch*patch] fp32, feature order (ph pw c); n_vis == Nt (nothing masked):
+                              * [B, Nt, ...] = head(norm(x)) of every token, as vmae.py:250-253 (y_video_dev must then be NULL) */
     /* optional fused `pred_patches_to_video`: out [B, T, C, H, W]; visible patches are copied from
      * xraw_dev (same strides as x_dev; NULL = use x_dev, valid when normalize=1) */
     float* y_video_dev;

@@ -380,6 +380,9 @@ def main():
     if args.only == "conj":
         run_conj_cases(ns, args.skip_large)
         return
+    if args.only == "allvis":
+        run_model_case(ns, TINY, batch=2, k_vis=16, clump=1, seed=5, out_name="tiny_8x8_allvis.npz", through_wrapper=False)
+        return
     if args.only == "flowstats":
         run_flowstats_case(ns)
         return
@@ -391,6 +394,8 @@ def main():
     run_block_case(ns)
     run_model_case(ns, TINY, batch=3, k_vis=4, clump=1, seed=3, out_name="tiny_8x8_k4.npz")
     run_model_case(ns, TINY, batch=2, k_vis=1, clump=1, seed=4, out_name="tiny_8x8_k1.npz")
+    # nothing masked: the decoder returns head(norm(x)) for ALL tokens (vmae.py:252-253); the wrapper cannot compose a video from it
+    run_model_case(ns, TINY, batch=2, k_vis=16, clump=1, seed=5, out_name="tiny_8x8_allvis.npz", through_wrapper=False)
     base = C.CONFIGS["base_8x8patch_2frames_1tube"]
     run_model_case(ns, base, batch=2, k_vis=8, clump=1, seed=0, out_name="base8_k8_b2.npz")
     run_model_case(ns, base, batch=1, k_vis=1, clump=1, seed=1, out_name="base8_k1_b1.npz")

@@ -179,3 +179,18 @@ def test_qkv_epilogue_variants_agree_end_to_end():
         _lib.check(lib.cwm_debug_set(b"gemm_staged", 1))
         _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
     assert np.abs(outs[("parity", 1, 0)].numpy() - g["y_tokens"]).max() <= 2e-4
+
+
+def test_nothing_masked_returns_all_tokens():
+    """Edge case of the reference decoder (vmae.py:250-253): no masked token -> head(norm(x)) of all Nt tokens; the fused
+    video path refuses, like the reference wrapper's failing assignment (prediction.py:252-254)."""
+    g = np.load(os.path.join(GOLDEN, "tiny_8x8_allvis.npz"))
+    seed = int(g["seed"])
+    m = build(TINY, seed)
+    G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+    x, mask = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    y = m(G._preprocess(x), mask).cpu().numpy()
+    assert y.shape == g["y_tokens"].shape
+    assert np.abs(y - g["y_tokens"]).max() <= 2e-4
+    with pytest.raises(RuntimeError):
+        m.predict_video(x, mask)

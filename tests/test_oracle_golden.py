@@ -152,3 +152,17 @@ def test_shift_prompts_oracle_vs_reference(tag):
     for i in range(ms.shape[0]):
         a_src = torch.where(~active[0, n:, i])[0]
         assert ms[i, n + a_src].all() or (shifts[i] == 0).all()
+
+
+def test_nothing_masked_returns_all_tokens():
+    """vmae.py:250-253: with no masked token the decoder returns head(norm(x)) for every token."""
+    g = np.load(os.path.join(GOLDEN, "tiny_8x8_allvis.npz"))
+    mask = torch.from_numpy(g["mask"])
+    assert not mask.any()
+    seed = int(g["seed"])
+    W = {k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(TINY, seed).items()}
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        y = O.vmae_forward(W, TINY_SPEC, O.preprocess(x), mask)
+    assert y.shape == g["y_tokens"].shape == (2, 32, 192)
+    assert np.abs(y.numpy() - g["y_tokens"]).max() <= 2e-5
