@@ -258,7 +258,7 @@ static int timer_end(EventPair* e, hipStream_t s) {
 int Engine::run_gemm(const GemmParams& p, int planes, hipStream_t s) {
     EventPair* e;
     if (int rc = timer_begin(timers[CWM_KCLASS_GEMM], 2.0 * p.M * (double)p.N * p.K, s, &e)) return rc;
-    if (e) e->sub = gemm_choose_tile(p, planes) >= 3 ? CWM_KCLASS_GEMM_WIDE : CWM_KCLASS_GEMM_NARROW;
+    if (e) e->sub = (gemm_choose_tile(p, planes) >= 3 && gemm_choose_tile(p, planes) != 6) ? CWM_KCLASS_GEMM_WIDE : CWM_KCLASS_GEMM_NARROW;
     if (int rc = launch_gemm(p, planes, s)) return rc;
     return timer_end(e, s);
 }

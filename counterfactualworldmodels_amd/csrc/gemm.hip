@@ -20,6 +20,7 @@
 //   columns of one row, so epilogue accesses are 16-byte (fp32) / 8-byte (bf16) vectors
 // * fused epilogues: bias, residual(+row map), exact-erf GELU, bf16 hi/lo split, QKV head scatter
 #include "gemm_device.h"
+#include <algorithm>
 
 namespace cwm {
 
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
     for (int jj = 0; jj < NIA; ++jj) {
         const int row = (wave * NIA + jj) * 8 + lane / 8;
         const int logical = (lane % 8) ^ lds_swizzle<64>(row);
-        a_src[jj] = (unsigned)min(m0 + row, p.M - 1) * (unsigned)(p.lda * PLANES) + logical * 8;
+        a_src[jj] = (unsigned)(p.m_offset + min(m0 + row, p.M - 1)) * (unsigned)(p.lda * PLANES) + logical * 8;
     }
 #pragma unroll
     for (int jj = 0; jj < NIB; ++jj) {
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
         for (int jj = 0; jj < 2; ++jj) {
             const int row = wave * 16 + jj * 8 + lane / 8;
             const int logical = (lane % 8) ^ lds_swizzle<64>(row);
-            src[h][jj] = (unsigned)min(m0 + h * 128 + row, p.M - 1) * (unsigned)(p.lda * PLANES) + logical * 8;
+            src[h][jj] = (unsigned)(p.m_offset + min(m0 + h * 128 + row, p.M - 1)) * (unsigned)(p.lda * PLANES) + logical * 8;
             src[2 + h][jj] = (unsigned)(n0 + h * 128 + row) * (unsigned)(p.K * PLANES) + logical * 8;
         }
     auto stage = [&](auto half_c, int buf, int kt) {
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + qm * 128 + wr * 64 + i * 16 + (lane & 15);
             if (m >= p.M) continue;
-            const RowMap rm = map_row(p, m);
+            const RowMap rm = map_row(p, m + p.m_offset);
 #pragma unroll
             for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
@@ -391,19 +392,21 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
 }
 
 int g_gemm_tile = 0;  // 0 = automatic choice per shape
+static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t stream);
 int g_gemm_debug = 0;
 int g_gemm_staged = 1;  // 0: force the direct (per-fragment) epilogue
 
 // Tile configuration for a launch: g_gemm_tile if set, else per shape.
 int gemm_choose_tile(const GemmParams& p, int planes) {
     (void)planes;
-    int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase, 5: stream-K 8-phase
+    int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase, 5: stream-K 8-phase, 6: 4 + 1 by rows
     if (cfg == 0) {
         // Measured on MI355X (tools/microbench.py gemm / gemm_l4: B/8 batch-32 and L/4 batch-8 shapes, both modes;
         // gpurun_out/mb_gemm*_r1n.log):
         //  * N >= 1024 (qkv, fc1, the L/4 proj / fc2): the 256x256 8-phase kernel, main loop at ~1.6 PFLOP/s of executed MFMA work
         //  * N = 512 / 768: 256x256 tiles only if the grid quantises well (392 tiles = 1.53 rounds of 256 CUs: yes; 297 tiles =
-        //    1.16 rounds: no).  If not: 128x128 tiles with two workgroups per CU, whose epilogue overlaps the co-resident
+        //    1.16 rounds: no).  If not: long-K launches are split by rows (6): whole rounds of 256x256 tiles + a remainder of
+        //    128x128 tiles; short-K ones use 128x128 tiles with two workgroups per CU, whose epilogue overlaps the co-resident
         //    workgroup's main loop.  (The persistent stream-K form (5) wins only the long-K case, fc2 of B/8: 305 vs 337 us in
         //    parity mode = 1.8 % of the step; it is NOT selected automatically: its split tiles re-associate the fp32 sums, which
         //    makes a sample's output depend on its position in the batch at the 3e-5 level, and a timed-out hand-off would only
@@ -417,6 +420,7 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
             const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
             const double fill = (double)tiles / (double)(((tiles + cus - 1) / cus) * cus);
             if (fill >= 0.7) cfg = 4;
+            else if (tiles >= cus && p.K >= 1536) cfg = 6;  // mixed tiling (launch_gemm): fc2 of B/8, 297 tiles = 255 big + 168 small
         }
     }
     return cfg;
@@ -447,6 +451,27 @@ int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) {
         else p.staged = (p.ldo % 8 == 0);
     }
     int cfg = gemm_choose_tile(p, planes);
+    if (cfg == 6) {
+        // Mixed tiling: the leading rows that fill whole rounds of 256x256 tiles go to the 8-phase kernel, the remaining rows to
+        // 128x128 tiles.  Both kernels apply the same product sequence to every accumulator, so the result does not depend on the split.
+        const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
+        const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
+        const int rounds = (tiles_m * tiles_n) / cus;
+        const int big_rows = std::min(tiles_m - 1, rounds * cus / tiles_n);  // m-tile rows of the 8-phase part
+        if (rounds >= 1 && big_rows >= 1) {
+            GemmParams a = p, b = p;
+            a.M = big_rows * 256;
+            b.m_offset = p.m_offset + a.M;
+            b.M = p.M - a.M;
+            if (int rc = launch_gemm_cfg(a, planes, 4, stream)) return rc;
+            return launch_gemm_cfg(b, planes, 1, stream);
+        }
+        cfg = 1;
+    }
+    return launch_gemm_cfg(p, planes, cfg, stream);
+}
+
+static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t stream) {
     typedef void (*kern_t)(const GemmParams);
     if (cfg == 5) {
         if (sk_shape_ok(p.M, p.N, p.K, planes, sk_grid_size())) return launch_gemm_sk(p, planes, stream);

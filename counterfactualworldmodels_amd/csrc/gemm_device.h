@@ -127,7 +127,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wr * (16 * FM) + i * 16 + (lane & 15);
         if (m >= p.M) continue;
-        const RowMap rm = map_row(p, m);
+        const RowMap rm = map_row(p, m + p.m_offset);
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int nb = n0 + wc * (16 * FN) + j * 16;  // fragment's first column (wave-uniform)
@@ -152,7 +152,7 @@ __device__ __forceinline__ void epilogue_row_table(const GemmParams& p, int2* ta
         const int m = m0 + tid;
         int2 e = make_int2(-1, 0);
         if (m < p.M) {
-            const RowMap rm = map_row(p, m);
+            const RowMap rm = map_row(p, m + p.m_offset);
             e = (p.epi == EPI_QKV) ? make_int2(rm.b * p.heads * p.n_tok + rm.tok, 0) : make_int2(rm.out_row, rm.res_row);
         }
         tab[tid] = e;

@@ -18,6 +18,7 @@ struct GemmParams {
     const bf16* W;
     int lda;
     int M, N, K;
+    int m_offset;       // this launch covers rows [m_offset, m_offset + M) of the problem (launch_gemm's mixed-tile split); usually 0
     const float* bias;  // [N] or nullptr
     int epi;
     // row mapping (rows_in == 0: identity).  m = b*rows_in + i  ->  out row b*rows_out + i,

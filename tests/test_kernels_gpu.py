@@ -187,6 +187,23 @@ def test_gemm_tile_configurations_agree(gu, tile):
         _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
 
 
+def test_gemm_mixed_tiling_is_bitwise_equal_to_simple_kernel(gu):
+    """Mixed tiling (whole rounds of 256x256 8-phase tiles + a remainder of 128x128 tiles, split by rows): bit-identical to the
+    128x128 kernel on a shape where the split happens (297 big-tile slots -> 255 + remainder), with bias + residual."""
+    lib = _lib.get_lib()
+    try:
+        for mode in ("parity", "fast"):
+            for (M, N, K) in [(25344, 768, 192), (20000, 512, 128)]:
+                a, w, b, r = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5), rnd(N, seed=43), rnd(M, N, seed=44)
+                _lib.check(lib.cwm_debug_set(b"gemm_tile", 1))
+                ref = gu.linear(a, w, b, resid=r, mode=mode)
+                _lib.check(lib.cwm_debug_set(b"gemm_tile", 6))
+                out = gu.linear(a, w, b, resid=r, mode=mode)
+                assert torch.equal(out, ref), (mode, M, N, K, (out - ref).abs().max().item())
+    finally:
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
+
+
 def test_gemm_8phase_is_bitwise_equal_to_simple_kernel_under_repetition(gu):
     """Race screen for the 8-phase GEMM (LDS-DMA in flight across raw barriers, counted vmcnt): every accumulator
     sees the same product sequence as in the one-barrier-per-tile kernel, so the outputs must be bit-identical --
