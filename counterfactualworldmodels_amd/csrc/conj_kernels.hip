@@ -172,17 +172,26 @@ int launch_small_attention(const SmallAttnParams& p, int planes, hipStream_t str
 // shared_similarity=False).  Per head h the 2*hd-wide slice of qk / qk_src splits into
 //   [0,hd):   attn   = softmax_M( scale * qk1 . qk_src1^T )   -> y     = attn   . v_src   (main update)
 //   [hd,2hd): attn_s = softmax_N( scale * qk_src2 . qk2^T )   -> y_src = attn_s . v       (context update)
-// Kernel 1: one wave per main token (4 tokens / workgroup), context K1/K2/V_src of the (b,h) pair in LDS;
-//           lanes split the head dimension, scores via wave reductions; writes y and scores_t[b,h,m,n].
-// Kernel 2: one workgroup per (b,h,m): softmax over n of scores_t, then the weighted sum of v rows.
+// N = 3140 .. 6336 main tokens against M = 25 / 50 context tokens: 4 GFLOP per call, i.e. nothing -- the first version of these
+// kernels (one workgroup per 4 main tokens, each re-loading the whole context; one workgroup per context token, each
+// re-reading all of v) took 5 ms per call = a third of the IMU-conditioned forward.  Now:
+//  A  cross_attn_main_kernel   64 main tokens per workgroup (lane = token), context K1 / K2 / V_src of the (b, h) pair in LDS and
+//     read as wave-wide broadcasts; wave w computes the scores of context tokens m = w, w + 4, ...; main-side softmax and
+//     P . V_src per 32-column group, written as whole [32 hi | 32 lo] operand blocks; the src-side scores go to scores_t[b,h,m,n].
+//  B  cross_attn_src_partial_kernel   (b, h) x 8 splits of the main tokens: local max per m, then p = exp(s - max) staged per 64
+//     tokens in LDS and thread d accumulating acc[m] += p[m][n] v[n][d] for ALL m at once (v is read once per split).
+//  C  cross_attn_src_combine_kernel   merges the 8 (max, sum, acc) partials per (b, h, m) and writes y_src.
 // ---------------------------------------------------------------------------------------------
+constexpr int kCrossSplit = 8;
+
 template <int PLANES>
 __global__ __launch_bounds__(256) void cross_attn_main_kernel(const CrossAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int hd = p.head_dim, M = p.M, D = p.heads * hd;
-    float* k1 = lds;                 // [M][hd]
-    float* k2 = k1 + (size_t)M * hd; // [M][hd]
-    float* vsrc = k2 + (size_t)M * hd;
+    const int hd = p.head_dim, M = p.M, D = p.heads * hd, N = p.N;
+    float* k1 = lds;                    // [M][hd]
+    float* k2 = k1 + (size_t)M * hd;    // [M][hd]
+    float* vsrc = k2 + (size_t)M * hd;  // [M][hd]
+    float* s1 = vsrc + (size_t)M * hd;  // [64][M + 1] main-side scores of this workgroup's tokens
     const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
     for (int i = threadIdx.x; i < M * hd; i += 256) {
         const int m = i / hd, d = i - m * hd;
@@ -192,128 +201,193 @@ __global__ __launch_bounds__(256) void cross_attn_main_kernel(const CrossAttnPar
         vsrc[i] = p.v_src[((size_t)b * M + m) * D + h * hd + d];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= p.N) return;
-    constexpr int PER = 3;  // head_dim <= 192
-    float q1[PER], q2[PER];
-    const float* qr = p.qk + ((size_t)b * p.N + n) * 2 * D + h * 2 * hd;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x * 64 + lane;
+    const bool nv = n < N;
+    const float* qr = p.qk + ((size_t)b * N + min(n, N - 1)) * 2 * D + h * 2 * hd;
+    constexpr int MM = 16;  // context tokens per wave (M <= 64)
+    float a1[MM], a2[MM];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int d = lane + 64 * i;
-        q1[i] = d < hd ? qr[d] * p.scale : 0.f;
-        q2[i] = d < hd ? qr[hd + d] * p.scale : 0.f;
-    }
-    float my = -INFINITY;  // lane m keeps score m (M <= 64): no runtime-indexed register array
-    float* st = p.scores_t + ((size_t)bh * M) * p.N + n;
-#pragma unroll 1
-    for (int m = 0; m < M; ++m) {
-        float a1 = 0.f, a2 = 0.f;
+    for (int mm = 0; mm < MM; ++mm) a1[mm] = a2[mm] = 0.f;
+    for (int d = 0; d < hd; d += 4) {
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(qr + d), q2 = *reinterpret_cast<const f32x4*>(qr + hd + d);
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int d = lane + 64 * i;
-            if (d < hd) {
-                a1 = fmaf(q1[i], k1[m * hd + d], a1);
-                a2 = fmaf(q2[i], k2[m * hd + d], a2);
+        for (int mm = 0; mm < MM; ++mm) {
+            const int m = wave + 4 * mm;
+            if (m < M) {
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(k1 + m * hd + d), kb = *reinterpret_cast<const f32x4*>(k2 + m * hd + d);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a1[mm] = fmaf(q1[e], ka[e], a1[mm]);
+                    a2[mm] = fmaf(q2[e], kb[e], a2[mm]);
+                }
             }
         }
-        a1 = wave_sum(a1);
-        a2 = wave_sum(a2);
-        if (lane == m) my = a1;
-        if (lane == 0) st[(size_t)m * p.N] = a2;
     }
-    float mx = my;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    const float pl = lane < M ? expf(my - mx) : 0.f;
-    const float l = wave_sum(pl);
-    float o[PER] = {0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int m = 0; m < M; ++m) {
-        const float pm = __shfl(pl, m, 64);
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int d = lane + 64 * i;
-            if (d < hd) o[i] = fmaf(pm, vsrc[m * hd + d], o[i]);
+    for (int mm = 0; mm < MM; ++mm) {
+        const int m = wave + 4 * mm;
+        if (m < M) {
+            s1[lane * (M + 1) + m] = a1[mm] * p.scale;
+            if (nv) p.scores_t[((size_t)bh * M + m) * N + n] = a2[mm] * p.scale;
         }
     }
+    __syncthreads();
+    const float* sr = s1 + lane * (M + 1);
+    float mx = -INFINITY;
+    for (int m = 0; m < M; ++m) mx = fmaxf(mx, sr[m]);
+    float l = 0.f;
+    for (int m = 0; m < M; ++m) l += expf(sr[m] - mx);
     const float inv = 1.0f / l;
+    for (int g = wave; g < hd / 32; g += 4) {
+        float acc[32];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int d = lane + 64 * i;
-        if (d < hd) {
-            bf16 hi, lo;
-            split_bf16(o[i] * inv, hi, lo);
-            bf16* dst = p.y + a_pos<PLANES>((int64_t)b * p.N + n, D, h * hd + d);
-            *dst = hi;
-            if constexpr (PLANES == 2) dst[kLoOffset] = lo;
+        for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const float pm = expf(sr[m] - mx) * inv;
+            const float* vr = vsrc + m * hd + g * 32;
+#pragma unroll
+            for (int c = 0; c < 32; c += 4) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(vr + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c + e] = fmaf(pm, vv[e], acc[c + e]);
+            }
+        }
+        if (nv) {
+            bf16* dst = p.y + a_pos<PLANES>((int64_t)b * N + n, D, h * hd + g * 32);  // one whole 32-column operand block
+#pragma unroll
+            for (int c = 0; c < 32; c += 8) {
+                bf16x8 hv, lv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bf16 hi = (bf16)acc[c + e];
+                    hv[e] = hi;
+                    lv[e] = (bf16)(acc[c + e] - (float)hi);
+                }
+                *reinterpret_cast<bf16x8*>(dst + c) = hv;
+                if constexpr (PLANES == 2) *reinterpret_cast<bf16x8*>(dst + kLoOffset + c) = lv;
+            }
+        }
+    }
+}
+
+// partial[((bh * kCrossSplit + split) * M + m) * (hd + 2) + {d | hd: local max | hd + 1: local sum}]
+template <int MMAX>
+__global__ __launch_bounds__(256) void cross_attn_src_partial_kernel(const CrossAttnParams p) {
+    __shared__ __attribute__((aligned(16))) float pb[MMAX * 64];
+    __shared__ float mxs[MMAX], ls[MMAX];
+    const int hd = p.head_dim, D = p.heads * hd, N = p.N, M = p.M;
+    const int split = blockIdx.x, bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n_lo = (int)((int64_t)split * N / kCrossSplit), n_hi = (int)((int64_t)(split + 1) * N / kCrossSplit);
+    const float* st = p.scores_t + (size_t)bh * M * N;
+    for (int m = wave; m < M; m += 4) {  // local max per context token
+        float mx = -INFINITY;
+        for (int n = n_lo + lane; n < n_hi; n += 64) mx = fmaxf(mx, st[(size_t)m * N + n]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        if (lane == 0) mxs[m] = mx;
+    }
+    __syncthreads();
+    float acc[MMAX], lacc[MMAX / 4];
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) acc[m] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MMAX / 4; ++i) lacc[i] = 0.f;
+    const float* vb = p.v + (size_t)b * N * D + h * hd + t;
+    for (int n0 = n_lo; n0 < n_hi; n0 += 64) {
+#pragma unroll
+        for (int i = 0; i < MMAX / 4; ++i) {  // thread (wave, lane) fills p[m = wave + 4 i][j = lane]
+            const int m = wave + 4 * i;
+            if (m < M) {
+                const int n = n0 + lane;
+                const float pv = n < n_hi ? expf(st[(size_t)m * N + n] - mxs[m]) : 0.f;
+                pb[m * 64 + lane] = pv;
+                lacc[i] += pv;
+            }
+        }
+        __syncthreads();
+        if (t < hd) {
+            for (int j = 0; j < 64; j += 4) {
+                float vv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vv[e] = (n0 + j + e < n_hi) ? vb[(size_t)(n0 + j + e) * D] : 0.f;
+#pragma unroll
+                for (int m = 0; m < MMAX; ++m) {
+                    if (m < M) {
+                        const f32x4 pv = *reinterpret_cast<const f32x4*>(pb + m * 64 + j);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[m] = fmaf(pv[e], vv[e], acc[m]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MMAX / 4; ++i) {
+        const float lsum = wave_sum(lacc[i]);
+        if (lane == 0 && wave + 4 * i < M) ls[wave + 4 * i] = lsum;
+    }
+    __syncthreads();
+    float* out = p.partial + ((size_t)(bh * kCrossSplit + split) * M) * (hd + 2);
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) {
+        if (m < M) {
+            if (t < hd) out[(size_t)m * (hd + 2) + t] = acc[m];
+            if (t == 0) {
+                out[(size_t)m * (hd + 2) + hd] = mxs[m];
+                out[(size_t)m * (hd + 2) + hd + 1] = ls[m];
+            }
         }
     }
 }
 
 template <int PLANES>
-__global__ __launch_bounds__(256) void cross_attn_src_kernel(const CrossAttnParams p) {
-    __shared__ float red[256];
-    __shared__ float pbuf[256];
-    const int hd = p.head_dim, D = p.heads * hd, N = p.N;
-    const int m = blockIdx.x, bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
-    const int t = threadIdx.x;
-    const float* st = p.scores_t + ((size_t)bh * p.M + m) * N;
+__global__ __launch_bounds__(256) void cross_attn_src_combine_kernel(const CrossAttnParams p) {
+    const int hd = p.head_dim, D = p.heads * hd, M = p.M;
+    const int m = blockIdx.x, bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads, t = threadIdx.x;
+    if (t >= hd) return;
+    const float* part = p.partial + ((size_t)bh * kCrossSplit * M + m) * (hd + 2);
+    const size_t sstride = (size_t)M * (hd + 2);
     float mx = -INFINITY;
-    for (int n = t; n < N; n += 256) mx = fmaxf(mx, st[n]);
-    red[t] = mx;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (t < s) red[t] = fmaxf(red[t], red[t + s]);
-        __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kCrossSplit; ++s) mx = fmaxf(mx, part[s * sstride + hd]);
+    float l = 0.f, acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < kCrossSplit; ++s) {
+        const float w = expf(part[s * sstride + hd] - mx);  // an empty split has max = -inf: weight 0
+        l = fmaf(part[s * sstride + hd + 1], w, l);
+        acc = fmaf(part[s * sstride + t], w, acc);
     }
-    mx = red[0];
-    __syncthreads();
-    float l = 0.f;
-    float acc = 0.f;  // thread t < hd accumulates output feature t
-    for (int n0 = 0; n0 < N; n0 += 256) {
-        const int n = n0 + t;
-        const float pm = n < N ? expf(st[n] - mx) : 0.f;
-        pbuf[t] = pm;
-        l += pm;
-        __syncthreads();
-        if (t < hd) {
-            const int cnt = min(256, N - n0);
-            const float* vb = p.v + ((size_t)b * N + n0) * D + h * hd + t;
-            for (int j = 0; j < cnt; ++j) acc = fmaf(pbuf[j], vb[(size_t)j * D], acc);
-        }
-        __syncthreads();
-    }
-    red[t] = l;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (t < s) red[t] += red[t + s];
-        __syncthreads();
-    }
-    if (t < hd) {
-        bf16 hi, lo;
-        split_bf16(acc / red[0], hi, lo);
-        bf16* dst = p.y_src + a_pos<PLANES>((int64_t)b * p.M + m, D, h * hd + t);
-        *dst = hi;
-        if constexpr (PLANES == 2) dst[kLoOffset] = lo;
-    }
+    bf16 hi, lo;
+    split_bf16(acc / l, hi, lo);
+    bf16* dst = p.y_src + a_pos<PLANES>((int64_t)b * M + m, D, h * hd + t);
+    *dst = hi;
+    if constexpr (PLANES == 2) dst[kLoOffset] = lo;
 }
 
+size_t cross_attention_partial_floats(int B, int heads, int M, int head_dim) { return (size_t)B * heads * kCrossSplit * M * (head_dim + 2); }
+
 int launch_cross_attention(const CrossAttnParams& p, int planes, hipStream_t stream) {
-    CWM_REQUIRE(p.M > 0 && p.M <= 64 && p.head_dim > 0 && p.head_dim <= 192, "cross_attention: needs M <= 64 and head_dim <= 192 (got %d, %d)", p.M, p.head_dim);
-    const size_t smem = (size_t)3 * p.M * p.head_dim * sizeof(float);
-    const dim3 g1((p.N + 3) / 4, p.B * p.heads), g2(p.M, p.B * p.heads);
+    CWM_REQUIRE(p.M > 0 && p.M <= 64 && p.head_dim > 0 && p.head_dim <= 256 && p.head_dim % 32 == 0,
+                "cross_attention: needs M <= 64 and head_dim a multiple of 32, <= 256 (got %d, %d)", p.M, p.head_dim);
+    CWM_REQUIRE(p.scores_t && p.partial, "cross_attention: scratch buffers missing");
+    const size_t smem = ((size_t)3 * p.M * p.head_dim + (size_t)64 * (p.M + 1)) * sizeof(float);
+    const dim3 g1((p.N + 63) / 64, p.B * p.heads), g2(kCrossSplit, p.B * p.heads), g3(p.M, p.B * p.heads);
     if (planes == 1) {
         static bool a1 = false;
         if (!a1) { CWM_HIP_CHECK(hipFuncSetAttribute((const void*)cross_attn_main_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a1 = true; }
         hipLaunchKernelGGL(cross_attn_main_kernel<1>, g1, dim3(256), smem, stream, p);
-        hipLaunchKernelGGL(cross_attn_src_kernel<1>, g2, dim3(256), 0, stream, p);
     } else {
         static bool a2 = false;
         if (!a2) { CWM_HIP_CHECK(hipFuncSetAttribute((const void*)cross_attn_main_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a2 = true; }
         hipLaunchKernelGGL(cross_attn_main_kernel<2>, g1, dim3(256), smem, stream, p);
-        hipLaunchKernelGGL(cross_attn_src_kernel<2>, g2, dim3(256), 0, stream, p);
     }
+    if (p.M <= 32) hipLaunchKernelGGL(cross_attn_src_partial_kernel<32>, g2, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(cross_attn_src_partial_kernel<64>, g2, dim3(256), 0, stream, p);
+    if (planes == 1) hipLaunchKernelGGL(cross_attn_src_combine_kernel<1>, g3, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(cross_attn_src_combine_kernel<2>, g3, dim3(256), 0, stream, p);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }

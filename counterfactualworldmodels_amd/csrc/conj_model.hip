@@ -39,7 +39,7 @@ struct cwm_conj_model {
     // workspace shared by the cross blocks
     int ws_batch = 0, ws_vmain = 0, ws_vctx = 0;
     int* err = nullptr;
-    float *qk = nullptr, *v = nullptr, *qk_src = nullptr, *v_src = nullptr, *scores_t = nullptr;
+    float *qk = nullptr, *v = nullptr, *qk_src = nullptr, *v_src = nullptr, *scores_t = nullptr, *cross_partial = nullptr;
     bf16 *ybuf = nullptr, *ysbuf = nullptr;
 };
 
@@ -151,7 +151,8 @@ int ensure_workspace(cwm_conj_model* m, int B, int vmain, int vctx) {
     const size_t Dmax = std::max(m->main.enc_dim, m->main.dec_dim);
     const int Mtok = m->ctx.n_tok + m->ctx.max_pad;
     if ((rc = E.ws(&m->err, 4)) || (rc = E.ws(&m->qk, Nmax * 2 * Dmax)) || (rc = E.ws(&m->v, Nmax * Dmax)) || (rc = E.ws(&m->qk_src, Mmax * 2 * Dmax)) ||
-        (rc = E.ws(&m->v_src, Mmax * Dmax)) || (rc = E.ws(&m->scores_t, Nmax * m->cfg.cross_heads * Mtok)) || (rc = E.ws(&m->ybuf, 2 * Nmax * Dmax)) ||
+        (rc = E.ws(&m->v_src, Mmax * Dmax)) || (rc = E.ws(&m->scores_t, Nmax * m->cfg.cross_heads * Mtok)) ||
+        (rc = E.ws(&m->cross_partial, cross_attention_partial_floats(Bc, m->cfg.cross_heads, Mtok, (int)Dmax / m->cfg.cross_heads))) || (rc = E.ws(&m->ybuf, 2 * Nmax * Dmax)) ||
         (rc = E.ws(&m->ysbuf, 2 * Mmax * Dmax)))
         return rc;
     m->ws_batch = Bc;
@@ -196,7 +197,7 @@ int run_cross(cwm_conj_model* m, const CrossW& C, float* x, int N, int ci, float
     memset(&ca, 0, sizeof(ca));
     ca.qk = m->qk; ca.v = m->v; ca.qk_src = m->qk_src; ca.v_src = m->v_src; ca.B = B; ca.N = N; ca.M = M; ca.heads = heads; ca.head_dim = hd;
     ca.scale = 1.0f / sqrtf((float)hd);
-    ca.y = m->ybuf; ca.y_plane = (int64_t)rows * D; ca.y_src = m->ysbuf; ca.y_src_plane = (int64_t)rows_s * D; ca.scores_t = m->scores_t;
+    ca.y = m->ybuf; ca.y_plane = (int64_t)rows * D; ca.y_src = m->ysbuf; ca.y_src_plane = (int64_t)rows_s * D; ca.scores_t = m->scores_t; ca.partial = m->cross_partial;
     if ((rc = launch_cross_attention(ca, planes, s))) return rc;
     if ((rc = linear_f32(E, m->ybuf, rows, D, C.proj, x, x, planes, s))) return rc;          // x += proj(y) + b
     if ((rc = linear_f32(E, m->ysbuf, rows_s, D, C.proj_src, src, src, planes, s))) return rc;

@@ -182,8 +182,10 @@ struct CrossAttnParams {
     bf16* y_src;          // [planes][B*M][D]  context update (softmax over the N main tokens)
     int64_t y_src_plane;
     float* scores_t;      // scratch [B][heads][M][N]
+    float* partial;       // scratch, cross_attention_partial_floats(B, heads, M, head_dim) floats
 };
 int launch_cross_attention(const CrossAttnParams& p, int planes, hipStream_t stream);
+size_t cross_attention_partial_floats(int B, int heads, int M, int head_dim);
 
 int launch_perm_to_rank(const int* perm, int* rank, int B, int Nt, hipStream_t stream);
 
