@@ -178,11 +178,11 @@ int launch_small_attention(const SmallAttnParams& p, int planes, hipStream_t str
 //  A  cross_attn_main_kernel   64 main tokens per workgroup (lane = token), context K1 / K2 / V_src of the (b, h) pair in LDS and
 //     read as wave-wide broadcasts; wave w computes the scores of context tokens m = w, w + 4, ...; main-side softmax and
 //     P . V_src per 32-column group, written as whole [32 hi | 32 lo] operand blocks; the src-side scores go to scores_t[b,h,m,n].
-//  B  cross_attn_src_partial_kernel   (b, h) x 8 splits of the main tokens: local max per m, then p = exp(s - max) staged per 64
+//  B  cross_attn_src_partial_kernel   (b, h) x 16 splits of the main tokens: local max per m, then p = exp(s - max) staged per 64
 //     tokens in LDS and thread d accumulating acc[m] += p[m][n] v[n][d] for ALL m at once (v is read once per split).
-//  C  cross_attn_src_combine_kernel   merges the 8 (max, sum, acc) partials per (b, h, m) and writes y_src.
+//  C  cross_attn_src_combine_kernel   merges the 16 (max, sum, acc) partials per (b, h, m) and writes y_src.
 // ---------------------------------------------------------------------------------------------
-constexpr int kCrossSplit = 8;
+constexpr int kCrossSplit = 16;
 
 template <int PLANES>
 __global__ __launch_bounds__(256) void cross_attn_main_kernel(const CrossAttnParams p) {
