@@ -256,11 +256,24 @@ static int timer_end(EventPair* e, hipStream_t s) {
 }
 
 int Engine::run_gemm(const GemmParams& p, int planes, hipStream_t s) {
-    EventPair* e;
-    if (int rc = timer_begin(timers[CWM_KCLASS_GEMM], 2.0 * p.M * (double)p.N * p.K, s, &e)) return rc;
-    if (e) e->sub = (gemm_choose_tile(p, planes) >= 3 && gemm_choose_tile(p, planes) != 6) ? CWM_KCLASS_GEMM_WIDE : CWM_KCLASS_GEMM_NARROW;
-    if (int rc = launch_gemm(p, planes, s)) return rc;
-    return timer_end(e, s);
+    const int cfg = gemm_choose_tile(p, planes);
+    GemmParams part[2];
+    int cfgs[2] = {cfg, 0}, nparts = 1;
+    part[0] = p;
+    if (cfg == 6 && timers[CWM_KCLASS_GEMM].enabled && gemm_mixed_split(p, &part[0], &part[1])) {
+        // timed runs book the two kernels of a mixed-tiling launch separately (so that the per-kernel averages are those rocprofv3 sees)
+        cfgs[0] = 4;
+        cfgs[1] = 1;
+        nparts = 2;
+    }
+    for (int i = 0; i < nparts; ++i) {
+        EventPair* e;
+        if (int rc = timer_begin(timers[CWM_KCLASS_GEMM], 2.0 * part[i].M * (double)part[i].N * part[i].K, s, &e)) return rc;
+        if (e) e->sub = (cfgs[i] >= 3 && cfgs[i] != 6) ? CWM_KCLASS_GEMM_WIDE : CWM_KCLASS_GEMM_NARROW;
+        if (int rc = (nparts == 2 ? launch_gemm_tile(part[i], planes, cfgs[i], s) : launch_gemm(part[i], planes, s))) return rc;
+        if (int rc = timer_end(e, s)) return rc;
+    }
+    return 0;
 }
 
 int Engine::run_attention(const AttnParams& p, int planes, hipStream_t s) {

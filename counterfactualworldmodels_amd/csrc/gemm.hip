@@ -396,6 +396,32 @@ static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t strea
 int g_gemm_debug = 0;
 int g_gemm_staged = 1;  // 0: force the direct (per-fragment) epilogue
 
+// Mixed tiling (tile configuration 6): the leading rows that fill whole rounds of 256x256 tiles go to the 8-phase kernel, the
+// remaining rows to 128x128 tiles.  Both kernels apply the same product sequence to every accumulator, so the result does not
+// depend on the split.  Returns false if the shape has no such split.
+bool gemm_mixed_split(const GemmParams& p, GemmParams* big, GemmParams* rest) {
+    const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
+    const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
+    const int rounds = (tiles_m * tiles_n) / cus;
+    const int big_rows = std::min(tiles_m - 1, rounds * cus / tiles_n);  // m-tile rows of the 8-phase part
+    if (rounds < 1 || big_rows < 1) return false;
+    *big = p;
+    *rest = p;
+    big->M = big_rows * 256;
+    rest->m_offset = p.m_offset + big->M;
+    rest->M = p.M - big->M;
+    return true;
+}
+
+// One launch with a given tile configuration (1 .. 5), after launch_gemm's argument checks
+int launch_gemm_tile(const GemmParams& p_in, int planes, int cfg, hipStream_t stream) {
+    const int saved = g_gemm_tile;
+    g_gemm_tile = cfg;
+    const int rc = launch_gemm(p_in, planes, stream);
+    g_gemm_tile = saved;
+    return rc;
+}
+
 // Tile configuration for a launch: g_gemm_tile if set, else per shape.
 int gemm_choose_tile(const GemmParams& p, int planes) {
     (void)planes;
@@ -452,17 +478,8 @@ int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) {
     }
     int cfg = gemm_choose_tile(p, planes);
     if (cfg == 6) {
-        // Mixed tiling: the leading rows that fill whole rounds of 256x256 tiles go to the 8-phase kernel, the remaining rows to
-        // 128x128 tiles.  Both kernels apply the same product sequence to every accumulator, so the result does not depend on the split.
-        const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
-        const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
-        const int rounds = (tiles_m * tiles_n) / cus;
-        const int big_rows = std::min(tiles_m - 1, rounds * cus / tiles_n);  // m-tile rows of the 8-phase part
-        if (rounds >= 1 && big_rows >= 1) {
-            GemmParams a = p, b = p;
-            a.M = big_rows * 256;
-            b.m_offset = p.m_offset + a.M;
-            b.M = p.M - a.M;
+        GemmParams a, b;
+        if (gemm_mixed_split(p, &a, &b)) {
             if (int rc = launch_gemm_cfg(a, planes, 4, stream)) return rc;
             return launch_gemm_cfg(b, planes, 1, stream);
         }

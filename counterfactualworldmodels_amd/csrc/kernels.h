@@ -52,7 +52,9 @@ struct GemmParams {
 };
 
 int launch_gemm(const GemmParams& p, int planes, hipStream_t stream);
-int gemm_choose_tile(const GemmParams& p, int planes);  // 1: 128x128 ... 4: 256x256 8-phase, 5: stream-K (see g_gemm_tile)
+int gemm_choose_tile(const GemmParams& p, int planes);
+bool gemm_mixed_split(const GemmParams& p, GemmParams* big, GemmParams* rest);  // tile configuration 6
+int launch_gemm_tile(const GemmParams& p, int planes, int cfg, hipStream_t stream);  // 1: 128x128 ... 4: 256x256 8-phase, 5: stream-K (see g_gemm_tile)
 int launch_gemm_sk(GemmParams& p, int planes, hipStream_t stream);  // persistent stream-K 8-phase kernel (gemm_sk.hip)
 bool sk_shape_ok(int M, int N, int K, int planes, int grid);
 int sk_grid_size();
