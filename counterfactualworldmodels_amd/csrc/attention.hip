@@ -141,6 +141,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
 
         if (active) {
         // ---- S^T = K Q^T ------------------------------------------------------------------------
+        // All K fragments of the tile are requested before the first MFMA (hipcc otherwise sinks every ds_read next to its
+        // use: one exposed LDS latency per 3 MFMAs), and all V^T fragments right after the S MFMAs have been issued, so that
+        // they land under the softmax's VALU work.
+        bf16x8 kfr[2][4][PLANES];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) kfr[kb][s][pl] = *reinterpret_cast<const bf16x8*>(base + pl * TILE_BYTES + k_off[kb][s]);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 sacc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -148,15 +159,26 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(base + k_off[kb][s]);
                 if constexpr (PLANES == 2) {
-                    const bf16x8 kl = *reinterpret_cast<const bf16x8*>(base + TILE_BYTES + k_off[kb][s]);
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][s], sacc[kb], 0, 0, 0);
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sacc[kb], 0, 0, 0);
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][s][PLANES - 1], qf[0][s], sacc[kb], 0, 0, 0);
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][s][0], qf[1][s], sacc[kb], 0, 0, 0);
                 }
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sacc[kb], 0, 0, 0);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][s][0], qf[0][s], sacc[kb], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x4 vfr[4][2][PLANES][2];  // [k-step][d-block][plane][half]: transposed reads
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) {
+                    const char* vb = base + (PLANES + pl) * TILE_BYTES + v_base[db] + ks * 2048;
+                    vfr[ks][db][pl][0] = lds_read_tr16(vb);
+                    vfr[ks][db][pl][1] = lds_read_tr16(vb + 1024);
+                }
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- online softmax (per query column; lanes l and l^32 share a query) ------------------
         if (kt == nkt - 1 && (N & 63)) {
@@ -211,11 +233,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
             }
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const char* vb = base + PLANES * TILE_BYTES + v_base[db] + ks * 2048;
-                const bf16x8 vf = __builtin_shufflevector(lds_read_tr16(vb), lds_read_tr16(vb + 1024), 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 vf = __builtin_shufflevector(vfr[ks][db][0][0], vfr[ks][db][0][1], 0, 1, 2, 3, 4, 5, 6, 7);
                 if constexpr (PLANES == 2) {
-                    const bf16x8 vl = __builtin_shufflevector(lds_read_tr16(vb + TILE_BYTES), lds_read_tr16(vb + TILE_BYTES + 1024), 0, 1, 2,
-                                                              3, 4, 5, 6, 7);
+                    const bf16x8 vl = __builtin_shufflevector(vfr[ks][db][PLANES - 1][0], vfr[ks][db][PLANES - 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc[db], 0, 0, 0);
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, plo, oacc[db], 0, 0, 0);
                 }
