@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     const int q0 = blockIdx.x * 128 + wave * 32;
     // a wave whose 32 query rows all lie past the sequence end (N = 792: three of the 28 wave slots per head) only helps to
     // stage the K / V tiles: its MFMA / softmax work is skipped, leaving the matrix pipe to the co-resident workgroup
-    const bool active = q0 < p.n_tok;
+    const int NQ = p.n_q > 0 ? p.n_q : p.n_tok;  // queries are rows [q_off, q_off + NQ) (last decoder block: the masked tokens only)
+    const bool active = q0 < NQ;
 
     const bf16* Qb = p.q + (size_t)bh * N * 64;
     const bf16* Kb = p.k + (size_t)bh * N * 64;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     // ---- Q fragments (B operand): lane (q = qcol, half hh) holds Q[q][16 s + 8 hh + 0..7] --------
     bf16x8 qf[PLANES][4];
     {
-        const int qrow = min(q0 + qcol, N - 1);
+        const int qrow = p.q_off + min(q0 + qcol, NQ - 1);
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
@@ -252,8 +253,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = q0 + qcol;
-    if (q < N) {
-        const int64_t orow = (int64_t)b * N + q;
+    if (q < NQ) {
+        const int64_t orow = (int64_t)b * NQ + q;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -335,7 +336,8 @@ __global__ __launch_bounds__(512, 2) void attention8_kernel(const AttnParams p) 
     const int bh = blockIdx.y;
     const int b = bh / p.heads, h = bh - b * p.heads;
     const int q0 = (blockIdx.x * 2 + grp) * 128 + (wave & 3) * 32;
-    const bool active = q0 < N;  // idle waves (query rows past the end) only stage tiles and keep the barrier count
+    const int NQ = p.n_q > 0 ? p.n_q : N;
+    const bool active = q0 < NQ;  // idle waves (query rows past the end) only stage tiles and keep the barrier count
 
     const bf16* Qb = p.q + (size_t)bh * N * 64;
     const bf16* Kb = p.k + (size_t)bh * N * 64;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void attention8_kernel(const AttnParams p) 
 
     bf16x8 qf[PLANES][4];
     {
-        const int qrow = min(q0 + qcol, N - 1);
+        const int qrow = p.q_off + min(q0 + qcol, NQ - 1);
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
@@ -559,8 +561,8 @@ __global__ __launch_bounds__(512, 2) void attention8_kernel(const AttnParams p) 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = q0 + qcol;
-    if (q < N) {
-        const int64_t orow = (int64_t)b * N + q;
+    if (q < NQ) {
+        const int64_t orow = (int64_t)b * NQ + q;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -587,7 +589,8 @@ int launch_attention(const AttnParams& p, int planes, hipStream_t stream) {
     CWM_REQUIRE(planes == 1 || planes == 2, "attention: planes must be 1 or 2");
     CWM_REQUIRE(p.n_tok > 0 && p.batch > 0 && p.heads > 0, "attention: empty problem");
     CWM_REQUIRE(p.ldo % 4 == 0, "attention: ldo must be a multiple of 4");
-    const int nqb = (p.n_tok + 127) / 128;
+    CWM_REQUIRE(p.q_off >= 0 && p.n_q >= 0 && p.q_off + p.n_q <= p.n_tok, "attention: query rows [%d, %d) outside the %d tokens", p.q_off, p.q_off + p.n_q, p.n_tok);
+    const int nqb = ((p.n_q > 0 ? p.n_q : p.n_tok) + 127) / 128;
     // Measured (tools/microbench.py attn, MI355X): the staggered 8-wave kernel ties the 4-wave kernel in parity mode (both
     // deliver ~1.0 PFLOP/s of executed MFMA work at ~1.8 GHz: the attention loop is bound by what the chip sustains under
     // this MFMA + transcendental mix, not by phase alignment) and loses 25-35 % in fast mode, where the 4-wave kernel runs

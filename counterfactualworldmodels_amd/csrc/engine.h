@@ -97,7 +97,7 @@ struct Engine {
     int run_gemm(const GemmParams& p, int planes, hipStream_t s);
     int run_attention(const AttnParams& p, int planes, hipStream_t s);
     // Block.forward (VideoMAE/utils.py:146-153) on a residual stream x[B*n_tok, D] (in place), head_dim 64
-    int run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, StreamBuffers& sb, hipStream_t s);
+    int run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, StreamBuffers& sb, hipStream_t s, int n_keep = 0);
     // same for short sequences with any head_dim (fp32 VALU attention): the IMU context stream
     int run_block_small(const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, StreamBuffers& sb, hipStream_t s);
 

@@ -336,10 +336,15 @@ GemmParams gemm_base(const bf16* A, int lda, const LinearW& L, int M, int planes
 }
 
 // Block.forward (VideoMAE/utils.py:146-153): x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x)))
-int Engine::run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, StreamBuffers& sb, hipStream_t s) {
+// n_keep (0 = all): only the LAST n_keep tokens of every sample are needed downstream (the last decoder block: the decoder returns
+// head(norm(x[:, -Nm:])), vmae.py:250-251).  Keys / values still come from all tokens; queries, proj, LN2 and the MLP run on the
+// kept rows only (compact activations, residual rows addressed with an offset).  Kept rows are bit-identical to the full block.
+int Engine::run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, StreamBuffers& sb, hipStream_t s, int n_keep) {
     const int M = B * n_tok;
     const int64_t hplane = (int64_t)M * D;
     const int hidden = w.fc1.N;
+    const bool part = n_keep > 0 && n_keep < n_tok;
+    const int n_out = part ? n_keep : n_tok, Mo = B * n_out, first = n_tok - n_out;
     int rc;
     LayerNormParams ln;
     memset(&ln, 0, sizeof(ln));
@@ -359,22 +364,26 @@ int Engine::run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H,
     AttnParams a;
     memset(&a, 0, sizeof(a));
     a.q = sb.qbuf; a.k = sb.kbuf; a.v = sb.vbuf; a.qk_plane = hplane;
-    a.o = sb.hbuf; a.o_plane = hplane; a.ldo = D; a.n_tok = n_tok; a.heads = H; a.batch = B;
+    a.o = sb.hbuf; a.o_plane = (int64_t)Mo * D; a.ldo = D; a.n_tok = n_tok; a.heads = H; a.batch = B;
+    if (part) { a.q_off = first; a.n_q = n_out; }
     if ((rc = run_attention(a, planes, s))) return rc;
 
-    g = gemm_base(sb.hbuf, D, w.proj, M, planes);
+    g = gemm_base(sb.hbuf, D, w.proj, Mo, planes);
     g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
+    if (part) { g.rows_in = n_out; g.rows_out = n_tok; g.out_row_offset = first; }
     if ((rc = run_gemm(g, planes, s))) return rc;
 
     ln.gamma = w.ln2_g; ln.beta = w.ln2_b;
+    if (part) { ln.rows = Mo; ln.rows_out_per_b = n_out; ln.rows_in_per_b = n_tok; ln.in_offset = first; ln.out_plane = (int64_t)Mo * D; }
     if ((rc = launch_layernorm(ln, planes, s))) return rc;
 
-    g = gemm_base(sb.hbuf, D, w.fc1, M, planes);
-    g.epi = EPI_BF16_GELU; g.out_hi = sb.gbuf; g.out_plane = (int64_t)M * hidden; g.ldo = hidden;
+    g = gemm_base(sb.hbuf, D, w.fc1, Mo, planes);
+    g.epi = EPI_BF16_GELU; g.out_hi = sb.gbuf; g.out_plane = (int64_t)Mo * hidden; g.ldo = hidden;
     if ((rc = run_gemm(g, planes, s))) return rc;
 
-    g = gemm_base(sb.gbuf, hidden, w.fc2, M, planes);
+    g = gemm_base(sb.gbuf, hidden, w.fc2, Mo, planes);
     g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
+    if (part) { g.rows_in = n_out; g.rows_out = n_tok; g.out_row_offset = first; }
     return run_gemm(g, planes, s);
 }
 

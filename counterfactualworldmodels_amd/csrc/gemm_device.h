@@ -52,7 +52,7 @@ __device__ __forceinline__ RowMap map_row(const GemmParams& p, int m) {
     if (p.rows_in > 0) {
         r.b = m / p.rows_in;
         r.tok = m - r.b * p.rows_in;
-        r.out_row = r.b * p.rows_out + r.tok;
+        r.out_row = r.b * p.rows_out + r.tok + p.out_row_offset;
         r.res_row = p.resid_rowmap ? p.resid_rowmap[r.b * p.map_stride + r.tok] : r.out_row;
     } else {
         r.b = 0;

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_kernel(const GemmParams p) {
                 ++b;
                 tok -= p.rows_in;
             }
-            out_row = b * p.rows_out + tok;
+            out_row = b * p.rows_out + tok + p.out_row_offset;
             res_row = out_row;
             if constexpr (EPI == EPI_F32) {
                 if (p.resid_rowmap) res_row = p.resid_rowmap[b * p.map_stride + tok];

@@ -24,6 +24,7 @@ struct GemmParams {
     // row mapping (rows_in == 0: identity).  m = b*rows_in + i  ->  out row b*rows_out + i,
     // residual row = resid_rowmap ? resid_rowmap[b*map_stride + i] : out row
     int rows_in, rows_out, map_stride;
+    int out_row_offset;  // added to the out row (and to the default residual row): writes a per-sample row block (last decoder block)
     const int* resid_rowmap;
     // EPI_F32
     float* C;
@@ -72,6 +73,7 @@ struct AttnParams {
     int64_t o_plane;
     int ldo;
     int n_tok, heads, batch;
+    int q_off, n_q;  // queries = rows [q_off, q_off + n_q) of every (batch, head); n_q == 0: all n_tok.  O rows are b * n_q + (q - q_off)
 };
 
 int launch_attention(const AttnParams& p, int planes, hipStream_t stream);

@@ -118,6 +118,8 @@ extern "C" int cwm_model_load_weight(cwm_model* m, const char* key, const float*
 
 extern "C" int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen) { return m->eng.missing_weights(buf, buflen); }
 
+static int g_prune_last_block = 1;
+
 extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     CWM_REQUIRE(m && a, "cwm_forward: null argument");
     CWM_REQUIRE(a->x_dev && a->mask_dev && a->y_tokens_dev, "cwm_forward: x_dev, mask_dev and y_tokens_dev are required");
@@ -175,8 +177,11 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     if (Nm > 0 && (rc = launch_fill_mask_tokens(m->x_dec, m->mask_token, m->pos_dec, m->perm, B, Nt, Nv, c.dec_dim, s))) return rc;
 
     // a9: decoder blocks over the full token set, norm + head on the last Nm tokens
-    for (int i = 0; i < c.dec_depth; ++i)
-        if ((rc = E.run_block(m->dec[i], m->x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, m->sb, s))) return rc;
+    // (the last block only has to produce the Nm rows the head reads: debug key "prune_last_block" = 0 runs it in full)
+    for (int i = 0; i < c.dec_depth; ++i) {
+        const int keep = (i == c.dec_depth - 1 && Nm > 0 && g_prune_last_block) ? Nm : 0;
+        if ((rc = E.run_block(m->dec[i], m->x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, m->sb, s, keep))) return rc;
+    }
     memset(&ln, 0, sizeof(ln));
     ln.x = m->x_dec; ln.ldx = c.dec_dim; ln.gamma = m->dec_norm_g; ln.beta = m->dec_norm_b; ln.eps = c.ln_eps; ln.D = c.dec_dim;
     ln.rows = B * Nret; ln.rows_out_per_b = Nret; ln.rows_in_per_b = Nt; ln.in_offset = Nt - Nret;
@@ -467,6 +472,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
         return CWM_OK;
     }
     if (!strcmp(key, "sk_error")) return sk_error_flag() == 0 ? CWM_OK : CWM_ERR_INVALID;  // query: stream-K hand-off timeouts
+    if (!strcmp(key, "prune_last_block")) {
+        g_prune_last_block = value;
+        return CWM_OK;
+    }
     if (!strcmp(key, "attn_kernel")) {
         g_attn_kernel = value;
         return CWM_OK;

@@ -194,3 +194,24 @@ def test_nothing_masked_returns_all_tokens():
     assert np.abs(y - g["y_tokens"]).max() <= 2e-4
     with pytest.raises(RuntimeError):
         m.predict_video(x, mask)
+
+
+def test_last_decoder_block_pruning_is_exact():
+    """The last decoder block computes queries / proj / MLP only for the Nm rows the head reads (vmae.py:250-251 discards the rest):
+    outputs are bit-identical to running the block in full, for the tiny model and for B/8 (both modes)."""
+    lib = _lib.get_lib()
+    cases = [(TINY, "tiny_8x8_k4.npz"), (C.CONFIGS["base_8x8patch_2frames_1tube"], "base8_k8_b2.npz")]
+    try:
+        for cfg, name in cases:
+            g = np.load(os.path.join(GOLDEN, name))
+            seed, x, mask = case_inputs(g, cfg)
+            for mode in ("parity", "fast"):
+                m = build(cfg, seed, mode)
+                G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+                outs = []
+                for prune in (1, 0):
+                    _lib.check(lib.cwm_debug_set(b"prune_last_block", prune))
+                    outs.append(m(G._preprocess(x.cuda()), mask.cuda()).cpu())
+                assert torch.equal(outs[0], outs[1]), (name, mode, (outs[0] - outs[1]).abs().max().item())
+    finally:
+        _lib.check(lib.cwm_debug_set(b"prune_last_block", 1))
