@@ -135,9 +135,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     store_tiles(0);
     __syncthreads();
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    // One key tile.  LAST (peeled): no next tile to stage, and keys past the sequence end are masked -- only there, so that
+    // the 32 selects per tile that the mask costs are not paid in every tile (the fast-mode loop is VALU-bound).
+    auto tile_step = [&](int kt, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
         const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tiles(kt + 1);
+        if constexpr (!LAST) load_tiles(kt + 1);
         const char* base = smem + cur * STAGE_BYTES;
 
         if (active) {
@@ -182,14 +185,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- online softmax (per query column; lanes l and l^32 share a query) ------------------
-        if (kt == nkt - 1 && (N & 63)) {
+        if constexpr (LAST) {
+            if (N & 63) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= N) sacc[kb][r] = -INFINITY;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        if (key >= N) sacc[kb][r] = -INFINITY;
+                    }
+            }
         }
         float mx = sacc[0][0];
 #pragma unroll
@@ -245,9 +250,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
         }
         }  // active
 
-        if (kt + 1 < nkt) store_tiles(cur ^ 1);
-        __syncthreads();
-    }
+        if constexpr (!LAST) {
+            store_tiles(cur ^ 1);
+            __syncthreads();
+        }
+    };
+    for (int kt = 0; kt + 1 < nkt; ++kt) tile_step(kt, std::false_type{});
+    tile_step(nkt - 1, std::true_type{});
 
     // ---- normalise and store O[q][h*64 + d] ----------------------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
