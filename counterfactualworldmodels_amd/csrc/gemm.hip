@@ -4,21 +4,25 @@
 // fc1/fc2, :93 qkv, :119 proj; vmae.py:547 encoder_to_decoder, :251 head; the Conv3d patch embed of
 // VideoMAE/utils.py:174-197 expressed as an im2col GEMM).
 //
-// * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 4x4 MFMA 16x16x32 tiles),
-//   two workgroups per CU
+// Kernels in this file (launch_gemm picks per shape, gemm_choose_tile; gemm_sk.hip holds a persistent stream-K form):
+//   gemm_bf16_kernel<PLANES, BM, BN, WM, WN>  one barrier + vmcnt(0) per K tile, 2-stage LDS ring; used as 128x128 / 256 threads
+//                                            with two workgroups per CU for narrow outputs (N <= 768) and remainders
+//   gemm8p_kernel<PLANES>                     256x256 / 512 threads, 8-phase main loop (staggered wave groups, LDS-DMA in flight
+//                                            across raw barriers): wide outputs (N >= 1024) and whole rounds of narrow ones
+// Common to both:
 // * A and W are both K-contiguous, so one lane's MFMA fragment is one 16-byte LDS read
 // * K tiles are staged by LDS-DMA (`global_load_lds_dwordx4`, 1 KiB per wave-instruction, no staging
-//   VGPRs, no ds_write pass) into a 2-stage LDS ring; tile t+1 is in flight while tile t is multiplied.
-//   An LDS-DMA piece lands linearly (lane l -> base + 16 l), so the bank-conflict XOR swizzle is applied
-//   to the per-lane SOURCE address and again on the fragment reads (measured SQ_LDS_BANK_CONFLICT = 0)
+//   VGPRs, no ds_write pass).  An LDS-DMA piece lands linearly (lane l -> base + 16 l), so the bank-conflict XOR
+//   swizzle is applied to the per-lane SOURCE address and again on the fragment reads (measured SQ_LDS_BANK_CONFLICT = 0)
 // * PLANES==2 ("parity" mode): operands are split into bf16 hi + lo and each product is
 //   hi*hi + hi*lo + lo*hi, fp32-accumulated -> ~2^-16 relative operand error instead of 2^-9.  hi and lo
 //   are stored interleaved per 32-k block ([32 hi | 32 lo] = one 128-byte line, common.h a_pos) so the
 //   tile rows are full cache lines in both modes (64-byte half-line DMA requests filled LDS ~1.5x slower)
 // * XCD-aware, grouped tile order so that co-resident tiles of one XCD share A panels / W tiles in L2
 // * accumulators are kept TRANSPOSED (D^T = W_frag . A_frag^T): a lane then owns 4 consecutive output
-//   columns of one row, so epilogue accesses are 16-byte (fp32) / 8-byte (bf16) vectors
-// * fused epilogues: bias, residual(+row map), exact-erf GELU, bf16 hi/lo split, QKV head scatter
+//   columns of one row
+// * fused epilogues (bias, residual(+row map), exact-erf GELU, bf16 hi/lo split, Q / K / V head scatter), staged through LDS so
+//   that every global access is an unconditional 16-byte lane access forming whole row segments (gemm_device.h)
 #include "gemm_device.h"
 #include <algorithm>
 
