@@ -431,26 +431,26 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
     (void)planes;
     int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase, 5: stream-K 8-phase, 6: 4 + 1 by rows
     if (cfg == 0) {
-        // Measured on MI355X (tools/microbench.py gemm / gemm_l4: B/8 batch-32 and L/4 batch-8 shapes, both modes;
-        // gpurun_out/mb_gemm*_r1n.log):
-        //  * N >= 1024 (qkv, fc1, the L/4 proj / fc2): the 256x256 8-phase kernel, main loop at ~1.6 PFLOP/s of executed MFMA work
-        //  * N = 512 / 768: 256x256 tiles only if the grid quantises well (392 tiles = 1.53 rounds of 256 CUs: yes; 297 tiles =
-        //    1.16 rounds: no).  If not: long-K launches are split by rows (6): whole rounds of 256x256 tiles + a remainder of
-        //    128x128 tiles; short-K ones use 128x128 tiles with two workgroups per CU, whose epilogue overlaps the co-resident
-        //    workgroup's main loop.  (The persistent stream-K form (5) wins only the long-K case, fc2 of B/8: 305 vs 337 us in
-        //    parity mode = 1.8 % of the step; it is NOT selected automatically: its split tiles re-associate the fp32 sums, which
-        //    makes a sample's output depend on its position in the batch at the 3e-5 level, and a timed-out hand-off would only
-        //    show in an error word.)
-        //  * everything else (N = 384, head, patch embed, ragged N): 128x128
+        // Measured on MI355X (tools/microbench.py gemm / gemm_mid / gemm_l4: B/8 at batch 8, 16, 32 and L/4 batch 8, both modes;
+        // profiles/r1n_*, r1o_*, r1p_* logs).  The 256x256 8-phase kernel has the fastest main loop (~1.6 PFLOP/s of executed MFMA
+        // work) but one workgroup per CU, so what decides is how its grid fills the chip:
+        //  * fewer tiles than CUs: one partial round -- fine from half the CUs up, else 128x128 tiles (more, smaller workgroups)
+        //  * whole rounds mostly full (fill >= 0.75 for long K, 0.85 for K < 1024, where the un-overlapped epilogue weighs more): 8-phase
+        //  * otherwise mixed tiling by rows (6): whole rounds of 256x256 tiles + a remainder of 128x128 tiles -- except the small
+        //    short-K launches (proj of B/8), which stay on 128x128 tiles with two workgroups per CU
+        //  * N < 512 or ragged narrow N (N = 384, head, patch embed): 128x128
+        // (The persistent stream-K form (5) is never selected: it is no faster than (6) and its split tiles re-associate fp32 sums.)
         cfg = 1;
-        if (p.M >= 512 && p.N >= 1024) {
-            cfg = 4;
-        } else if (p.M >= 512 && p.N >= 512 && p.N % 256 == 0) {
-            const int64_t tiles = (int64_t)((p.M + 255) / 256) * (p.N / 256);
+        if (p.M >= 512 && (p.N >= 1024 || (p.N >= 512 && p.N % 256 == 0))) {
+            const int64_t tiles = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
             const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
-            const double fill = (double)tiles / (double)(((tiles + cus - 1) / cus) * cus);
-            if (fill >= 0.7) cfg = 4;
-            else if (tiles >= cus && p.K >= 1536) cfg = 6;  // mixed tiling (launch_gemm): fc2 of B/8, 297 tiles = 255 big + 168 small
+            if (tiles < cus) {
+                cfg = tiles * 2 >= cus ? 4 : 1;
+            } else {
+                const double fill = (double)tiles / (double)(((tiles + cus - 1) / cus) * cus);
+                if (fill >= (p.K >= 1024 ? 0.75 : 0.85)) cfg = 4;
+                else if (p.K >= 1024 || p.N >= 1024) cfg = 6;
+            }
         }
     }
     return cfg;

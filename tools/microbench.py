@@ -23,6 +23,20 @@ GEMM_SHAPES = [
     ("b8.dec.fc1", 50176, 1536, 384, 1),
     ("b8.dec.fc2", 50176, 384, 1536, 0),
 ]
+MID_SHAPES = [  # B/8 at batch 8 and 16 (encoder rows 792 B, decoder rows 1568 B)
+    ("b8x8.enc.qkv", 6336, 2304, 768, 3),
+    ("b8x8.enc.proj", 6336, 768, 768, 0),
+    ("b8x8.enc.fc1", 6336, 3072, 768, 1),
+    ("b8x8.enc.fc2", 6336, 768, 3072, 0),
+    ("b8x8.dec.qkv", 12544, 1152, 384, 3),
+    ("b8x8.dec.fc1", 12544, 1536, 384, 1),
+    ("b8x16.enc.qkv", 12672, 2304, 768, 3),
+    ("b8x16.enc.proj", 12672, 768, 768, 0),
+    ("b8x16.enc.fc1", 12672, 3072, 768, 1),
+    ("b8x16.enc.fc2", 12672, 768, 3072, 0),
+    ("b8x16.dec.qkv", 25088, 1152, 384, 3),
+    ("b8x16.dec.fc1", 25088, 1536, 384, 1),
+]
 L4_SHAPES = [
     ("l4.enc.qkv", 25344, 3072, 1024, 3),
     ("l4.enc.proj", 25344, 1024, 1024, 0),
@@ -42,8 +56,8 @@ def main():
     torch.cuda.init()
     lib = _lib.get_lib()
     us = C.c_double()
-    if what in ("gemm", "gemm_l4"):
-        for name, M, N, K, epi in (GEMM_SHAPES if what == "gemm" else L4_SHAPES):
+    if what in ("gemm", "gemm_l4", "gemm_mid"):
+        for name, M, N, K, epi in {"gemm": GEMM_SHAPES, "gemm_l4": L4_SHAPES, "gemm_mid": MID_SHAPES}[what]:
             for mode in ("fast", "parity"):
                 row = []
                 for v in variants:
