@@ -10,8 +10,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcwm_hip.so")
-SOURCES = ["gemm.hip", "gemm_sk.hip", "attention.hip", "elementwise.hip", "conj_kernels.hip", "flowstats.hip", "engine.hip", "model.hip", "conj_model.hip"]
-HEADERS = ["common.h", "kernels.h", "gemm_device.h", "engine.h", os.path.join("..", "..", "include", "cwm_hip.h")]
+SOURCES = ["gemm.hip", "gemm_sk.hip", "attention.hip", "attention_pipe.hip", "elementwise.hip", "conj_kernels.hip", "flowstats.hip", "engine.hip", "model.hip", "conj_model.hip"]
+HEADERS = ["common.h", "kernels.h", "gemm_device.h", "attention_device.h", "engine.h", os.path.join("..", "..", "include", "cwm_hip.h")]
 
 
 def _hipcc() -> str:
@@ -43,6 +43,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         "-Wall",
         "-Wno-unused-function",
     ]
+    cmd += os.environ.get("CWM_HIPCC_EXTRA", "").split()  # e.g. -DCWM_ATTN_PROF (phase timers in attention_pipe.hip)
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB_PATH + ".tmp"]
     if verbose:

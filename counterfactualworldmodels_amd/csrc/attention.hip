@@ -18,22 +18,9 @@
 // issued before the MFMAs of tile t.  LDS images are XOR-swizzled (K: conflict-free ds_read_b128; V: the four
 // key rows of a transposed read land on the four 64-byte quarters of the 256-byte bank row).
 // PLANES==2 is the split-bf16 "parity" mode (hi*hi + hi*lo + lo*hi for both products).
-#include "common.h"
-#include "kernels.h"
-#include <type_traits>
+#include "attention_device.h"
 
 namespace cwm {
-
-__device__ __forceinline__ int lds_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-// V tile image: key row of 128 bytes, 16-byte chunk c (8 d) stored at c ^ 4 on key rows with bit 1 set
-__device__ __forceinline__ int lds_off_v(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
-
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-__device__ __forceinline__ bf16x4 lds_read_tr16(const char* ptr) {
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr);
-    return __builtin_bit_cast(bf16x4, v);
-}
 
 template <int PLANES>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
@@ -284,32 +271,6 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     }
 }
 
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-// ds_read_b64_tr_b16 as inline asm (see attention8_kernel, phase c); OFF = immediate byte offset
-template <int OFF>
-__device__ __forceinline__ u32x2 lds_read_tr16_asm(unsigned addr) {
-    u32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-    return v;
-}
-// all V^T fragments of k-step KS: [d-block][plane][half]
-template <int KS, int PLANES>
-__device__ __forceinline__ void lds_read_v_step(u32x2 (&dst)[2][PLANES][2], unsigned va0, unsigned va1) {
-    constexpr int T = 64 * 64 * 2;
-    dst[0][0][0] = lds_read_tr16_asm<KS * 2048>(va0);
-    dst[0][0][1] = lds_read_tr16_asm<KS * 2048 + 1024>(va0);
-    if constexpr (PLANES == 2) {
-        dst[0][PLANES - 1][0] = lds_read_tr16_asm<KS * 2048 + T>(va0);
-        dst[0][PLANES - 1][1] = lds_read_tr16_asm<KS * 2048 + T + 1024>(va0);
-    }
-    dst[1][0][0] = lds_read_tr16_asm<KS * 2048>(va1);
-    dst[1][0][1] = lds_read_tr16_asm<KS * 2048 + 1024>(va1);
-    if constexpr (PLANES == 2) {
-        dst[1][PLANES - 1][0] = lds_read_tr16_asm<KS * 2048 + T>(va1);
-        dst[1][PLANES - 1][1] = lds_read_tr16_asm<KS * 2048 + T + 1024>(va1);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // 8-wave form: two 128-query blocks of one (batch, head) per workgroup, the two wave groups one barrier apart.
 //
@@ -543,15 +504,15 @@ __global__ __launch_bounds__(512, 2) void attention8_kernel(const AttnParams p) 
             __builtin_amdgcn_s_setprio(1);
             lds_read_v_step<0, PLANES>(vr0, va0, va1);
             lds_read_v_step<1, PLANES>(vr1, va0, va1);
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
+            lds_wait_v_step<NRD, PLANES>(vr0);
             CWM_PV_STEP(0, vr0);
             lds_read_v_step<2, PLANES>(vr0, va0, va1);
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
+            lds_wait_v_step<NRD, PLANES>(vr1);
             CWM_PV_STEP(1, vr1);
             lds_read_v_step<3, PLANES>(vr1, va0, va1);
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
+            lds_wait_v_step<NRD, PLANES>(vr0);
             CWM_PV_STEP(2, vr0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lds_wait_v_step<0, PLANES>(vr1);
             CWM_PV_STEP(3, vr1);
 #undef CWM_PV_STEP
             __builtin_amdgcn_s_setprio(0);
@@ -592,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void attention8_kernel(const AttnParams p) 
     }
 }
 
-int g_attn_kernel = 0;  // 0 auto, 1: 4-wave kernel, 2: 8-wave staggered kernel
+int g_attn_kernel = 0;  // 0 auto, 1: 4-wave kernel, 2: 8-wave staggered kernel, 3: software-pipelined kernel (attention_pipe.hip)
 
 int launch_attention(const AttnParams& p, int planes, hipStream_t stream) {
     CWM_REQUIRE(planes == 1 || planes == 2, "attention: planes must be 1 or 2");
@@ -600,11 +561,17 @@ int launch_attention(const AttnParams& p, int planes, hipStream_t stream) {
     CWM_REQUIRE(p.ldo % 4 == 0, "attention: ldo must be a multiple of 4");
     CWM_REQUIRE(p.q_off >= 0 && p.n_q >= 0 && p.q_off + p.n_q <= p.n_tok, "attention: query rows [%d, %d) outside the %d tokens", p.q_off, p.q_off + p.n_q, p.n_tok);
     const int nqb = ((p.n_q > 0 ? p.n_q : p.n_tok) + 127) / 128;
-    // Measured (tools/microbench.py attn, MI355X): the staggered 8-wave kernel ties the 4-wave kernel in parity mode (both
-    // deliver ~1.0 PFLOP/s of executed MFMA work at ~1.8 GHz: the attention loop is bound by what the chip sustains under
-    // this MFMA + transcendental mix, not by phase alignment) and loses 25-35 % in fast mode, where the 4-wave kernel runs
-    // two workgroups per CU.  It stays selectable (cwm_debug_set "attn_kernel" = 2) and is covered by a bitwise test.
-    const int kern = g_attn_kernel ? g_attn_kernel : 1;
+    // Measured (tools/microbench.py attn, MI355X; profiles/r1q_microbench_attn.log):
+    //   parity mode: the software-pipelined kernel (3) is 10-13 % faster than the 4-wave kernel (1) on every model shape --
+    //     each wave overlaps the MFMAs of one tile with the softmax of the previous one; under this load the chip settles at
+    //     ~1.55-1.6 GHz (s_memtime vs s_memrealtime, tools/attn_prof.py), where both the matrix pipe and the VALU issue port
+    //     are ~70 % busy;
+    //   fast mode: one MFMA per product leaves the loop VALU-bound and the kernels tie (1 ahead on the short encoder
+    //     sequences) -> kernel 1;
+    //   the staggered 8-wave kernel (2) ties kernel 1 in parity mode and loses 25-35 % in fast mode.
+    // All three produce bit-identical outputs (tests/test_kernels_gpu.py); cwm_debug_set "attn_kernel" forces one.
+    const int kern = g_attn_kernel ? g_attn_kernel : (planes == 2 ? 3 : 1);
+    if (kern == 3) return launch_attention_pipe(p, planes, stream);
     if (kern == 2) {
         const dim3 grid((nqb + 1) / 2, p.batch * p.heads);
         const size_t smem = (size_t)4 * (64 * 64 * 2) * planes;  // 2 K slots + 2 V slots

@@ -1,0 +1,62 @@
+// Device-side helpers shared by the attention kernels (attention.hip, attention_pipe.hip): LDS tile images and the
+// hardware transpose read.  Not part of the C ABI.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+#include <type_traits>
+
+namespace cwm {
+
+__device__ __forceinline__ int lds_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// V tile image: key row of 128 bytes, 16-byte chunk c (8 d) stored at c ^ 4 on key rows with bit 1 set
+__device__ __forceinline__ int lds_off_v(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x4 lds_read_tr16(const char* ptr) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr);
+    return __builtin_bit_cast(bf16x4, v);
+}
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+// ds_read_b64_tr_b16 as inline asm (see attention8_kernel, phase c); OFF = immediate byte offset
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read_tr16_asm(unsigned addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// all V^T fragments of k-step KS: [d-block][plane][half]
+template <int KS, int PLANES>
+__device__ __forceinline__ void lds_read_v_step(u32x2 (&dst)[2][PLANES][2], unsigned va0, unsigned va1) {
+    constexpr int T = 64 * 64 * 2;
+    dst[0][0][0] = lds_read_tr16_asm<KS * 2048>(va0);
+    dst[0][0][1] = lds_read_tr16_asm<KS * 2048 + 1024>(va0);
+    if constexpr (PLANES == 2) {
+        dst[0][PLANES - 1][0] = lds_read_tr16_asm<KS * 2048 + T>(va0);
+        dst[0][PLANES - 1][1] = lds_read_tr16_asm<KS * 2048 + T + 1024>(va0);
+    }
+    dst[1][0][0] = lds_read_tr16_asm<KS * 2048>(va1);
+    dst[1][0][1] = lds_read_tr16_asm<KS * 2048 + 1024>(va1);
+    if constexpr (PLANES == 2) {
+        dst[1][PLANES - 1][0] = lds_read_tr16_asm<KS * 2048 + T>(va1);
+        dst[1][PLANES - 1][1] = lds_read_tr16_asm<KS * 2048 + T + 1024>(va1);
+    }
+}
+
+// s_waitcnt lgkmcnt(N) for fragments requested by lds_read_v_step.  The registers are operands of the wait: hipcc treats the
+// output of the asm read as available at once, and without the dependency it is free to schedule a consumer (an MFMA) above
+// a bare s_waitcnt statement -- which goes unnoticed as long as the LDS answers quickly (one workgroup per CU) and reads stale
+// registers when it does not.
+template <int N, int PLANES>
+__device__ __forceinline__ void lds_wait_v_step(u32x2 (&v)[2][PLANES][2]) {
+    if constexpr (PLANES == 2)
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(v[0][0][0]), "+v"(v[0][0][1]), "+v"(v[0][1][0]), "+v"(v[0][1][1]), "+v"(v[1][0][0]), "+v"(v[1][0][1]), "+v"(v[1][1][0]), "+v"(v[1][1][1])
+                     : "n"(N)
+                     : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(v[0][0][0]), "+v"(v[0][0][1]), "+v"(v[1][0][0]), "+v"(v[1][0][1]) : "n"(N) : "memory");
+}
+
+}  // namespace cwm

@@ -1,0 +1,475 @@
+// Software-pipelined attention kernel (head_dim 64): the per-wave arithmetic of attention_kernel (attention.hip), with the
+// matrix and vector work of consecutive key tiles interleaved inside each wave.
+//
+// PMC counters on attention_kernel (profiles/r1m_pmc_summary.json) show the matrix pipe busy ~50 % of the time and the
+// waves issue-stalled for as long: within a wave the tile is a strict chain  S = K Q^T (MFMA) -> softmax (VALU) -> P V
+// (MFMA), so MFMA and VALU work only overlap by chance between the two waves of a SIMD.  Per tile and wave the two
+// pipes carry about the same load (parity mode: 48 MFMAs of 32 cycles vs ~1500 VALU cycles), so a wave has to keep
+// both busy by itself.  Here iteration t of a wave runs, in instruction order,
+//     phase A:  S(t+1) = K(t+1) Q^T         one MFMA per slot, each followed by a slice of softmax(t)
+//     phase B:  O += V(t)^T P(t)^T          one MFMA per slot, each followed by a slice of the bf16 (hi, lo) split of
+//                                           the next k-step's P
+// with sched_barrier(0) between slots, so that the ~7 VALU issue cycles behind every MFMA issue are filled with
+// independent work.  The two S accumulator chains (key halves) and the two O chains (d halves) alternate slot by slot: a
+// dependent MFMA never issues straight behind its producer, and every accumulator still sees the additions in
+// attention_kernel's order -- the outputs are bit-identical (tests/test_kernels_gpu.py).
+//
+// K / V tiles go global -> LDS by LDS-DMA, two slots each: iteration t first issues K(t+2) (slot of K(t), whose S was
+// computed in iteration t - 1) and V(t+1) (slot of V(t-1)), and ends with vmcnt(0) + one workgroup barrier, a whole
+// tile of work later.
+#include "attention_device.h"
+#include <cstdio>
+
+namespace cwm {
+
+#ifdef CWM_ATTN_PROF
+__device__ unsigned long long g_pipe_prof[8];
+__device__ unsigned long long g_pipe_blocks[8192 * 4];
+#define PROF_T(i) do { if (prof) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define PROF_T(i) do {} while (0)
+#endif
+
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+template <int PLANES>
+struct PipeWave {
+    bf16x8 qf[PLANES][4];
+    f32x16 oacc[2];
+    float m_run, l_run;
+    int k_off[2][4];
+    int hh;
+};
+
+// S = K Q^T for one tile without interleaving (prologue)
+template <int PLANES>
+__device__ __forceinline__ void qk_plain(const PipeWave<PLANES>& w, const char* kbase, f32x16 (&s)[2]) {
+    constexpr int TILE_BYTES = 64 * 64 * 2;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase + w.k_off[kb][sx]);
+            if constexpr (PLANES == 2) {
+                const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kbase + TILE_BYTES + w.k_off[kb][sx]);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, w.qf[0][sx], s[kb], 0, 0, 0);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, w.qf[1][sx], s[kb], 0, 0, 0);
+            }
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, w.qf[0][sx], s[kb], 0, 0, 0);
+        }
+    }
+}
+
+// bf16 (hi, lo) split of the P values pair (2 j, 2 j + 1) of k-step KS
+template <int PLANES>
+__device__ __forceinline__ void split_pair(const f32x16 (&sc)[2], int ks, int j, bf16x8& ph, bf16x8& plo) {
+#pragma unroll
+    for (int e = 2 * j; e < 2 * j + 2; ++e) {
+        const float pv = sc[ks >> 1][8 * (ks & 1) + e];
+        const bf16 hi = (bf16)pv;
+        ph[e] = hi;
+        if constexpr (PLANES == 2) plo[e] = (bf16)(pv - (float)hi);
+    }
+}
+
+// One k-step of O^T += V^T P^T: 2 NM slots (MFMA + a slice of the next k-step's P split)
+template <int PLANES, int KS>
+__device__ __forceinline__ void pv_step(PipeWave<PLANES>& w, const f32x16 (&sc)[2], const u32x2 (&vr)[2][PLANES][2], const bf16x8& ph, const bf16x8& plo,
+                                        bf16x8& ph_next, bf16x8& plo_next) {
+    constexpr int NM = PLANES == 2 ? 3 : 1;
+    constexpr int NSLOT = 2 * NM;
+    bf16x8 vf[2], vl[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        vf[db] = __builtin_shufflevector(__builtin_bit_cast(bf16x4, vr[db][0][0]), __builtin_bit_cast(bf16x4, vr[db][0][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (PLANES == 2)
+            vl[db] = __builtin_shufflevector(__builtin_bit_cast(bf16x4, vr[db][PLANES - 1][0]), __builtin_bit_cast(bf16x4, vr[db][PLANES - 1][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int slot = m * 2 + db;
+            if constexpr (PLANES == 2) {
+                if (m == 0) w.oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[db], ph, w.oacc[db], 0, 0, 0);
+                if (m == 1) w.oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db], plo, w.oacc[db], 0, 0, 0);
+                if (m == 2) w.oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db], ph, w.oacc[db], 0, 0, 0);
+            } else {
+                w.oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db], ph, w.oacc[db], 0, 0, 0);
+            }
+            if constexpr (KS < 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j * NSLOT / 4 == slot) split_pair<PLANES>(sc, KS + 1, j, ph_next, plo_next);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+// One key tile of one wave: phase A (S of the next tile into sn, softmax of this tile in sc), phase B (P V of this tile).
+//   kbase: LDS image of K(t+1); va0 / va1: LDS addresses of this lane's V(t) transposed-read blocks (d halves)
+//   dma(i): issues LDS-DMA piece i (< NDMA) of the tiles staged in this iteration -- one per slot at the head of phase
+//   A: issued back to back they hold the wave for ~60 cycles each (measured: ~500 cycles per tile)
+template <int PLANES, bool HAS_NEXT, int NDMA, typename Dma>
+__device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], f32x16 (&sn)[2], const char* kbase, unsigned va0, unsigned va1, int kt, int N, Dma&& dma
+#ifdef CWM_ATTN_PROF
+    , bool prof, unsigned long long (&pacc)[8], unsigned long long& tlast
+#endif
+    ) {
+    constexpr int TILE_BYTES = 64 * 64 * 2;
+    constexpr int NM = PLANES == 2 ? 3 : 1;
+    constexpr int NS = 8 * NM;       // slots of phase A
+    constexpr int NMAX = NS / 4;     // ... of which the first carry the running-maximum chain,
+    constexpr int NE = NS - NMAX - 1;  // one the maximum's cross-lane step, the rest the exponentials
+    constexpr int NRD = 4 * PLANES;  // transposed reads per k-step
+
+    if constexpr (!HAS_NEXT) {
+        if (N & 63) {  // keys past the sequence end (last tile only)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * w.hh;
+                    if (key >= N) sc[kb][r] = -INFINITY;
+                }
+        }
+    }
+
+    // ---- phase A --------------------------------------------------------------------------------------
+    // slot order g = 2 sx + kb: the two accumulator chains alternate; K fragments are requested two groups ahead
+    bf16x8 kfr[8][PLANES];
+    auto read_k = [&](int g) {
+        const int kb = g & 1, sx = g >> 1;
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) kfr[g][pl] = *reinterpret_cast<const bf16x8*>(kbase + pl * TILE_BYTES + w.k_off[kb][sx]);
+    };
+    if constexpr (HAS_NEXT) {
+        read_k(0);
+        read_k(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sn[kb][r] = 0.f;
+    }
+    float mx = sc[0][0];
+    float m_new = 0.f, alpha = 1.f, mc = 0.f, rowsum = 0.f;
+    bool grew = false;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int kb = g & 1, sx = g >> 1;
+        if constexpr (HAS_NEXT) {
+            if (g + 2 < 8) read_k(g + 2);
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int slot = g * NM + m;
+            if (slot < NDMA) dma(slot);
+            if constexpr (HAS_NEXT) {
+                if constexpr (PLANES == 2) {
+                    if (m == 0) sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g][PLANES - 1], w.qf[0][sx], sn[kb], 0, 0, 0);
+                    if (m == 1) sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g][0], w.qf[PLANES - 1][sx], sn[kb], 0, 0, 0);
+                    if (m == 2) sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g][0], w.qf[0][sx], sn[kb], 0, 0, 0);
+                } else {
+                    sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g][0], w.qf[0][sx], sn[kb], 0, 0, 0);
+                }
+            }
+            if (slot < NMAX) {
+#pragma unroll
+                for (int v = 32 * slot / NMAX; v < 32 * (slot + 1) / NMAX; ++v) mx = fmaxf(mx, sc[v >> 4][v & 15]);
+            } else if (slot == NMAX) {
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                m_new = fmaxf(w.m_run, mx);
+                // the running maximum rarely moves after the first tiles: skip the rescale of O and l (alpha would be exactly 1)
+                grew = __any(m_new > w.m_run);
+                alpha = grew ? __builtin_amdgcn_exp2f((w.m_run - m_new) * kLog2e) : 1.0f;
+                w.m_run = m_new;
+                mc = m_new * kLog2e;
+                // (rescale here, not between the phases: a branch there lets LLVM sink every exponential below it, out of
+                // the MFMA shadow)
+                if (grew) {
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) w.oacc[db][r] *= alpha;
+                }
+            } else {
+                // exponentials of this slot's values; the row sum takes the previous slot's (an addition straight behind its
+                // v_exp_f32 waits out the transcendental latency)
+                const int j = slot - NMAX - 1;
+                if (j > 0) {
+#pragma unroll
+                    for (int v = 32 * (j - 1) / NE; v < 32 * j / NE; ++v) rowsum += sc[v >> 4][v & 15];
+                }
+#pragma unroll
+                for (int v = 32 * j / NE; v < 32 * (j + 1) / NE; ++v) sc[v >> 4][v & 15] = __builtin_amdgcn_exp2f(fmaf(sc[v >> 4][v & 15], kLog2e, -mc));
+                asm volatile("" : "+v"(rowsum));  // keeps the additions in their slot (they otherwise sink behind the last MFMA)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    PROF_T(1);
+    // ---- phase B --------------------------------------------------------------------------------------
+    u32x2 vr0[2][PLANES][2], vr1[2][PLANES][2];
+    lds_read_v_step<0, PLANES>(vr0, va0, va1);
+    lds_read_v_step<1, PLANES>(vr1, va0, va1);
+#pragma unroll
+    for (int v = 32 * (NE - 1) / NE; v < 32; ++v) rowsum += sc[v >> 4][v & 15];
+    w.l_run = w.l_run * alpha + rowsum;
+    bf16x8 ph0, pl0, ph1, pl1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_pair<PLANES>(sc, 0, j, ph0, pl0);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_wait_v_step<NRD, PLANES>(vr0);
+    pv_step<PLANES, 0>(w, sc, vr0, ph0, pl0, ph1, pl1);
+    lds_read_v_step<2, PLANES>(vr0, va0, va1);
+    lds_wait_v_step<NRD, PLANES>(vr1);
+    pv_step<PLANES, 1>(w, sc, vr1, ph1, pl1, ph0, pl0);
+    lds_read_v_step<3, PLANES>(vr1, va0, va1);
+    lds_wait_v_step<NRD, PLANES>(vr0);
+    pv_step<PLANES, 2>(w, sc, vr0, ph0, pl0, ph1, pl1);
+    lds_wait_v_step<0, PLANES>(vr1);
+    pv_step<PLANES, 3>(w, sc, vr1, ph1, pl1, ph0, pl0);
+    PROF_T(2);
+}
+
+}  // namespace
+
+template <int PLANES, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kernel(const AttnParams p) {
+    constexpr int TILE_BYTES = 64 * 64 * 2;         // one 64x64 bf16 tile
+    constexpr int SLOT_BYTES = TILE_BYTES * PLANES;  // hi [, lo] planes of one K or V tile
+    constexpr int V_BASE = 2 * SLOT_BYTES;           // LDS: 2 K slots, then 2 V slots
+    constexpr int NP = 8 * PLANES / NW;              // 1-KiB LDS-DMA pieces per wave, tile and operand
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qcol = lane & 31, hh = lane >> 5;
+    const int N = p.n_tok;
+    const int bh = blockIdx.y;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+    const int NQ = p.n_q > 0 ? p.n_q : N;
+    const bool active = q0 < NQ;  // idle waves (query rows past the end) only stage tiles and keep the barrier count
+
+    const bf16* Qb = p.q + (size_t)bh * N * 64;
+    const bf16* Kb = p.k + (size_t)bh * N * 64;
+    const bf16* Vb = p.v + (size_t)bh * N * 64;
+
+    PipeWave<PLANES> w;
+    w.hh = hh;
+    {
+        const int qrow = p.q_off + min(q0 + qcol, NQ - 1);
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                w.qf[pl][s] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)pl * p.qk_plane + (size_t)qrow * 64 + s * 16 + hh * 8);
+    }
+
+    // ---- LDS-DMA bookkeeping: piece = 8 key rows x 128 B; lane l lands at chunk l % 8 of row l / 8 ----
+    int st_row[NP], st_lds[NP], st_kchunk[NP], st_vchunk[NP];
+    const char *st_kp[NP], *st_vp[NP];  // wave-uniform plane bases: the DMA address is base (SGPR pair) + 32-bit lane offset
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) {
+        const int pi = wave * NP + jj, plane = pi >> 3, pc = pi & 7;
+        const int r = pc * 8 + (lane >> 3);
+        st_row[jj] = r;
+        st_lds[jj] = plane * TILE_BYTES + pc * 1024;
+        st_kchunk[jj] = ((lane & 7) ^ ((r >> 1) & 7)) * 16;         // K image: chunk c of row r at c ^ ((r >> 1) & 7)
+        st_vchunk[jj] = ((lane & 7) ^ (((r >> 1) & 1) << 2)) * 16;  // V image: lds_off_v
+        st_kp[jj] = reinterpret_cast<const char*>(Kb + (size_t)plane * p.qk_plane);
+        st_vp[jj] = reinterpret_cast<const char*>(Vb + (size_t)plane * p.qk_plane);
+    }
+    auto stage_k1 = [&](int kt, int jj) {
+        const int key = min(kt * 64 + st_row[jj], N - 1);  // rows past the end re-read the last key (P is exactly 0 there)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(st_kp[jj] + (unsigned)(key * 128 + st_kchunk[jj])),
+                                         (lds_void*)(smem + (kt & 1) * SLOT_BYTES + st_lds[jj]), 16, 0, 0);
+    };
+    auto stage_v1 = [&](int kt, int jj) {
+        const int key = min(kt * 64 + st_row[jj], N - 1);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(st_vp[jj] + (unsigned)(key * 128 + st_vchunk[jj])),
+                                         (lds_void*)(smem + V_BASE + (kt & 1) * SLOT_BYTES + st_lds[jj]), 16, 0, 0);
+    };
+    auto stage_k = [&](int kt) {
+#pragma unroll
+        for (int jj = 0; jj < NP; ++jj) stage_k1(kt, jj);
+    };
+    auto stage_v = [&](int kt) {
+#pragma unroll
+        for (int jj = 0; jj < NP; ++jj) stage_v1(kt, jj);
+    };
+
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w.k_off[kb][s] = lds_off128(kb * 32 + qcol, 2 * s + hh);
+    unsigned v_addr[2];  // LDS addresses of this lane's transposed-read blocks in V slot 0
+    {
+        const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+            v_addr[db] = (unsigned)(size_t)(lds_void*)(smem + V_BASE + lds_off_v(4 * (g >> 1) + q, db * 4 + (g & 1) * 2 + (pc >> 1)) + (pc & 1) * 8);
+    }
+
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w.oacc[db][r] = 0.f;
+    w.m_run = -1e30f;
+    w.l_run = 0.f;
+
+#define CWM_TILE_END()                                     \
+    do {                                                   \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        __builtin_amdgcn_s_barrier();                      \
+        __builtin_amdgcn_sched_barrier(0);                 \
+    } while (0)
+// tile KT of the wave: S accumulators SC (this tile) -> SN (next tile)
+#define CWM_TILE(HAS_NEXT, SC, SN, KT)                                                                                                 \
+    do {                                                                                                                               \
+        const bool more_k = (KT) + 2 < nkt;                                                                                            \
+        auto dma = [&](int i) {                                                                                                        \
+            if (i < NP) {                                                                                                              \
+                if (more_k) stage_k1((KT) + 2, i);                                                                                     \
+            } else if (HAS_NEXT) {                                                                                                     \
+                stage_v1((KT) + 1, i - NP);                                                                                            \
+            }                                                                                                                          \
+        };                                                                                                                             \
+        PROF_T(0);                                                                                                                     \
+        if (active) {                                                                                                                  \
+            pipe_tile<PLANES, HAS_NEXT, 2 * NP>(w, SC, SN, smem + (((KT) + 1) & 1) * SLOT_BYTES, v_addr[0] + ((KT)&1) * SLOT_BYTES,             \
+                                        v_addr[1] + ((KT)&1) * SLOT_BYTES, (KT), N, dma PROF_ARGS);                                    \
+        } else {                                                                                                                       \
+            if (more_k) stage_k((KT) + 2);                                                                                             \
+            if (HAS_NEXT) stage_v((KT) + 1);                                                                                           \
+        }                                                                                                                              \
+        if (HAS_NEXT) CWM_TILE_END();                                                                                                  \
+        PROF_T(3);                                                                                                                     \
+    } while (0)
+
+#ifdef CWM_ATTN_PROF
+#define PROF_ARGS , prof, pacc, tlast
+    const bool prof = blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = tlast, r_begin = __builtin_amdgcn_s_memrealtime();
+#else
+#define PROF_ARGS
+#endif
+    const int nkt = (N + 63) / 64;
+    f32x16 sa[2], sb[2];
+    stage_k(0);
+    stage_v(0);
+    if (nkt > 1) stage_k(1);
+    CWM_TILE_END();
+    if (active) qk_plain<PLANES>(w, smem, sa);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();  // K(0) is re-staged by tile 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 2) {
+        CWM_TILE(true, sa, sb, kt);
+        CWM_TILE(true, sb, sa, kt + 1);
+    }
+    if (kt + 2 == nkt) {
+        CWM_TILE(true, sa, sb, kt);
+        CWM_TILE(false, sb, sa, kt + 1);
+    } else {
+        CWM_TILE(false, sa, sb, kt);
+    }
+#undef CWM_TILE
+#undef CWM_TILE_END
+#ifdef CWM_ATTN_PROF
+    pacc[4] = __builtin_amdgcn_s_memtime() - t_begin;
+    pacc[5] = __builtin_amdgcn_s_memrealtime() - r_begin;
+    {
+        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+        if (wave == 0 && lane == 0 && bid < 8192) {
+            g_pipe_blocks[bid * 4 + 0] = r_begin;
+            g_pipe_blocks[bid * 4 + 1] = r_begin + pacc[5];
+            g_pipe_blocks[bid * 4 + 2] = pacc[4];
+            g_pipe_blocks[bid * 4 + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+        }
+    }
+    if (prof && lane == 0)
+        for (int i = 0; i < 8; ++i) g_pipe_prof[i] = pacc[i];
+#endif
+
+    // ---- normalise and store O[q][h*64 + d] ----------------------------------------------------------
+    const float l_tot = w.l_run + __shfl_xor(w.l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + qcol;
+    if (q < NQ) {
+        const int64_t orow = (int64_t)b * NQ + q;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 hi4, lo4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = w.oacc[db][4 * g + e] * inv;
+                    const bf16 hi = (bf16)v;
+                    hi4[e] = hi;
+                    if constexpr (PLANES == 2) lo4[e] = (bf16)(v - (float)hi);
+                }
+                const int d0 = db * 32 + 8 * g + 4 * hh;
+                bf16* dst = p.o + a_pos<PLANES>(orow, p.ldo, h * 64 + d0);  // GEMM A-operand layout (common.h)
+                *reinterpret_cast<bf16x4*>(dst) = hi4;
+                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + kLoOffset) = lo4;
+            }
+    }
+}
+
+#ifdef CWM_ATTN_PROF
+int attention_pipe_prof(int i) {
+    if (i >= 1000) {  // dump the per-block records to /tmp/attn_blocks.bin
+        static unsigned long long h[8192 * 4];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pipe_blocks), sizeof(h)) != hipSuccess) return -1;
+        FILE* f = fopen("/tmp/attn_blocks.bin", "wb");
+        if (!f) return -1;
+        fwrite(h, 1, sizeof(h), f);
+        fclose(f);
+        return 0;
+    }
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pipe_prof), sizeof(h)) != hipSuccess) return -1;
+    return (int)h[i & 7];
+}
+#else
+int attention_pipe_prof(int) { return -1; }
+#endif
+
+template <int PLANES, int NW>
+static int launch_pipe(const AttnParams& p, hipStream_t stream) {
+    const int nq = p.n_q > 0 ? p.n_q : p.n_tok;
+    const dim3 grid((nq + 32 * NW - 1) / (32 * NW), p.batch * p.heads);
+    const size_t smem = (size_t)4 * (64 * 64 * 2) * PLANES;  // 2 K slots + 2 V slots
+    static bool attr = false;
+    if (!attr && smem > 48 * 1024) {
+        CWM_HIP_CHECK(hipFuncSetAttribute((const void*)attention_pipe_kernel<PLANES, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    hipLaunchKernelGGL((attention_pipe_kernel<PLANES, NW>), grid, dim3(64 * NW), smem, stream, p);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// 4 waves: 128 queries per workgroup, two workgroups per CU.  (8 waves -- 256 queries, one workgroup per CU, half the
+// LDS-DMA work per query -- measured 5-15 % slower: the barrier then couples all eight waves of the CU.)
+int launch_attention_pipe(const AttnParams& p, int planes, hipStream_t stream) {
+    return planes == 1 ? launch_pipe<1, 4>(p, stream) : launch_pipe<2, 4>(p, stream);
+}
+
+}  // namespace cwm

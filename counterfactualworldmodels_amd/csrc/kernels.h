@@ -77,6 +77,8 @@ struct AttnParams {
 };
 
 int launch_attention(const AttnParams& p, int planes, hipStream_t stream);
+int attention_pipe_prof(int i);  // per-phase s_memtime totals of block 0 wave 0 (builds with -DCWM_ATTN_PROF only)
+int launch_attention_pipe(const AttnParams& p, int planes, hipStream_t stream);  // attention_pipe.hip; arguments checked by launch_attention
 extern int g_attn_kernel;  // 0 auto, 1: 4-wave kernel, 2: 8-wave staggered kernel
 
 struct LayerNormParams {

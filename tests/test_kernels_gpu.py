@@ -278,12 +278,16 @@ def test_gemm_stream_k_matches_simple_kernel(gu, mode):
         _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
 
 
-def test_attention_8wave_kernel_is_bitwise_equal_to_4wave_kernel(gu):
-    """Race screen for the staggered 8-wave attention (LDS-DMA K/V rings, counted vmcnt, waves 4-7 one barrier behind waves
-    0-3): per-wave arithmetic is that of the 4-wave kernel, so outputs must be bit-identical -- one tile, ragged tails, odd
-    and even numbers of 128-query blocks, idle waves, the online-softmax rescale branch, repeated launches."""
+@pytest.mark.parametrize("kern", [2, 3])
+def test_attention_variants_are_bitwise_equal_to_4wave_kernel(gu, kern):
+    """Race screen for the staggered 8-wave attention (2: LDS-DMA K/V rings, counted vmcnt, waves 4-7 one barrier behind
+    waves 0-3) and the software-pipelined kernel (3: S of tile t+1 interleaved with the softmax of tile t): per-wave
+    arithmetic is that of the 4-wave kernel, so outputs must be bit-identical -- one tile, two tiles, odd and even tile
+    counts, ragged tails, idle waves, the online-softmax rescale branch, repeated launches."""
     lib = _lib.get_lib()
-    cases = [(2, 40, 1), (1, 64, 2), (3, 129, 2), (2, 300, 3), (2, 792, 12), (1, 1568, 6), (1, 1000, 2), (1, 3200, 1)]
+    # (the last two fill the chip: more than one workgroup per CU)
+    cases = [(2, 40, 1), (1, 64, 2), (2, 100, 1), (3, 129, 2), (1, 192, 2), (2, 300, 3), (2, 792, 12), (1, 1568, 6), (1, 1000, 2), (1, 3200, 1),
+             (8, 792, 12), (6, 1568, 6)]
     try:
         for mode in ("parity", "fast"):
             for (B, N, H) in cases:
@@ -292,7 +296,7 @@ def test_attention_8wave_kernel_is_bitwise_equal_to_4wave_kernel(gu):
                     qkv[0, N - 5, H * 64:H * 64 + 64] = qkv[0, 7, :64] * 6.0  # late spike: the running max jumps in the last tile
                 _lib.check(lib.cwm_debug_set(b"attn_kernel", 1))
                 ref = gu.attention(qkv, H, mode=mode)
-                _lib.check(lib.cwm_debug_set(b"attn_kernel", 2))
+                _lib.check(lib.cwm_debug_set(b"attn_kernel", kern))
                 for rep in range(4):
                     out = gu.attention(qkv, H, mode=mode)
                     assert torch.equal(out, ref), (mode, B, N, H, rep, (out - ref).abs().max().item())

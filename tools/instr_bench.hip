@@ -1,0 +1,215 @@
+// Instruction issue / throughput microbenchmark for gfx950 (MI355X): cycles per instruction of the VALU and MFMA
+// operations the attention and GEMM kernels are built from, for one wave per SIMD and for two waves sharing a SIMD.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/instr_bench tools/instr_bench.hip && /tmp/instr_bench
+// Results: profiles/instr_bench_gfx950.txt (and DESIGN.md, attention section).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+#define R2(x) x x
+#define R4(x) x x x x
+#define R8(x) R4(x) R4(x)
+#define R16(x) R4(R4(x))
+#define R64(x) R16(R4(x))
+
+enum { T_FMA, T_EXP, T_CVT, T_PKMUL, T_MAX3, T_ADD, T_MFMA32, T_MFMA16, T_MFMA32_FMA7, T_MFMA32_FMA6, T_MFMA32_EXP2FMA4, T_MFMA32_DEP, T_MFMA32_FMA4, T_MFMA32_FMA2, T_LSHL, T_M_EXP1, T_M_EXP2, T_M_EXP4, T_M_CVT6, T_M_PKMUL6, T_M_MAX6, T_M_LSHL6, T_M_ADD6, T_M_PKMUL3, T_M16_EXP2, T_COUNT };
+static const char* kNames[T_COUNT] = {"v_fma_f32 x8 indep",        "v_exp_f32 x8 indep",           "v_cvt_pk_bf16_f32 x8",          "v_pk_mul_f32 x8",
+                                      "v_max3_f32 x8",             "v_add_f32 dependent chain x8", "mfma 32x32x16 bf16 x2 indep",   "mfma 16x16x32 bf16 x2 indep",
+                                      "mfma32 + 7 fma",            "mfma32 + 6 fma",               "mfma32 + 2 exp + 4 fma",        "mfma 32x32x16 dependent chain",
+                                      "mfma32 + 4 fma",            "mfma32 + 2 fma",               "v_lshlrev_b32 x8",
+                                      "mfma32 + 1 exp", "mfma32 + 2 exp", "mfma32 + 4 exp", "mfma32 + 6 cvt_pk_bf16", "mfma32 + 6 pk_mul_f32", "mfma32 + 6 max3", "mfma32 + 6 lshl", "mfma32 + 6 add", "mfma32 + 3 pk_mul_f32", "2 x mfma16x16x32 + 2 exp"};
+static const int kInstrPerIter[T_COUNT] = {8, 8, 8, 8, 8, 8, 2, 2, 8, 7, 7, 1, 5, 3, 8, 2, 3, 5, 7, 7, 7, 7, 7, 4, 4};
+
+template <int TEST>
+__global__ __launch_bounds__(512) void bench_kernel(unsigned long long* out, int iters, int active_mask) {
+    const int wave = threadIdx.x >> 6;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = 0.001f * (threadIdx.x + i);
+    f32x16 acc0 = {0}, acc1 = {0};
+    f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+    bf16x8 va, vb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        va[i] = (__bf16)(0.01f * i);
+        vb[i] = (__bf16)(0.02f * i);
+    }
+    f32x2 pa[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pa[i] = f32x2{a[i], a[i] + 1.f};
+    unsigned long long t0 = 0, t1 = 0;
+    __syncthreads();
+    if ((active_mask >> wave) & 1) {
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < iters; ++it) {
+            if constexpr (TEST == T_FMA) {
+                asm volatile(R8("v_fma_f32 %0, %0, %0, %1\n v_fma_f32 %1, %1, %1, %2\n v_fma_f32 %2, %2, %2, %3\n v_fma_f32 %3, %3, %3, %4\n"
+                                "v_fma_f32 %4, %4, %4, %5\n v_fma_f32 %5, %5, %5, %6\n v_fma_f32 %6, %6, %6, %7\n v_fma_f32 %7, %7, %7, %0\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+            } else if constexpr (TEST == T_EXP) {
+                asm volatile(R8("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
+                                "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+            } else if constexpr (TEST == T_CVT) {
+                asm volatile(R8("v_cvt_pk_bf16_f32 %0, %0, %1\n v_cvt_pk_bf16_f32 %1, %1, %2\n v_cvt_pk_bf16_f32 %2, %2, %3\n v_cvt_pk_bf16_f32 %3, %3, %4\n"
+                                "v_cvt_pk_bf16_f32 %4, %4, %5\n v_cvt_pk_bf16_f32 %5, %5, %6\n v_cvt_pk_bf16_f32 %6, %6, %7\n v_cvt_pk_bf16_f32 %7, %7, %0\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+            } else if constexpr (TEST == T_PKMUL) {
+                asm volatile(R8("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %3\n v_pk_mul_f32 %3, %3, %4\n"
+                                "v_pk_mul_f32 %4, %4, %5\n v_pk_mul_f32 %5, %5, %6\n v_pk_mul_f32 %6, %6, %7\n v_pk_mul_f32 %7, %7, %0\n")
+                             : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]), "+v"(pa[5]), "+v"(pa[6]), "+v"(pa[7]));
+            } else if constexpr (TEST == T_MAX3) {
+                asm volatile(R8("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %1, %1, %2, %3\n v_max3_f32 %2, %2, %3, %4\n v_max3_f32 %3, %3, %4, %5\n"
+                                "v_max3_f32 %4, %4, %5, %6\n v_max3_f32 %5, %5, %6, %7\n v_max3_f32 %6, %6, %7, %0\n v_max3_f32 %7, %7, %0, %1\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+            } else if constexpr (TEST == T_LSHL) {
+                asm volatile(R8("v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3\n"
+                                "v_lshlrev_b32 %4, 1, %4\n v_lshlrev_b32 %5, 1, %5\n v_lshlrev_b32 %6, 1, %6\n v_lshlrev_b32 %7, 1, %7\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+            } else if constexpr (TEST == T_ADD) {
+                asm volatile(R8(R8("v_add_f32 %0, %0, %1\n")) : "+v"(a[0]) : "v"(a[1]));
+            } else if constexpr (TEST == T_MFMA32) {
+                asm volatile(R8("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n v_mfma_f32_32x32x16_bf16 %1, %2, %3, %1\n") : "+v"(acc0), "+v"(acc1) : "v"(va), "v"(vb));
+            } else if constexpr (TEST == T_MFMA16) {
+                asm volatile(R8("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n") : "+v"(c0), "+v"(c1) : "v"(va), "v"(vb));
+            } else if constexpr (TEST == T_MFMA32_DEP) {
+                asm volatile(R8("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n") : "+v"(acc0) : "v"(va), "v"(vb));
+            } else if constexpr (TEST == T_MFMA32_FMA7) {
+                asm volatile(R8("v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n"
+                                "v_fma_f32 %0, %0, %0, %1\n v_fma_f32 %1, %1, %1, %2\n v_fma_f32 %2, %2, %2, %3\n v_fma_f32 %3, %3, %3, %4\n"
+                                "v_fma_f32 %4, %4, %4, %5\n v_fma_f32 %5, %5, %5, %6\n v_fma_f32 %6, %6, %6, %7\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(acc0), "+v"(acc1)
+                             : "v"(va), "v"(vb));
+            } else if constexpr (TEST == T_MFMA32_FMA6) {
+                asm volatile(R8("v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n"
+                                "v_fma_f32 %0, %0, %0, %1\n v_fma_f32 %1, %1, %1, %2\n v_fma_f32 %2, %2, %2, %3\n v_fma_f32 %3, %3, %3, %4\n"
+                                "v_fma_f32 %4, %4, %4, %5\n v_fma_f32 %5, %5, %5, %6\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(acc0), "+v"(acc1)
+                             : "v"(va), "v"(vb));
+            } else if constexpr (TEST == T_MFMA32_FMA4) {
+                asm volatile(R8("v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n"
+                                "v_fma_f32 %0, %0, %0, %1\n v_fma_f32 %1, %1, %1, %2\n v_fma_f32 %2, %2, %2, %3\n v_fma_f32 %3, %3, %3, %4\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(acc0), "+v"(acc1)
+                             : "v"(va), "v"(vb));
+            } else if constexpr (TEST == T_MFMA32_FMA2) {
+                asm volatile(R8("v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n"
+                                "v_fma_f32 %0, %0, %0, %1\n v_fma_f32 %1, %1, %1, %2\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(acc0), "+v"(acc1)
+                             : "v"(va), "v"(vb));
+            } else if constexpr (TEST == T_MFMA32_EXP2FMA4) {
+                asm volatile(R8("v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n"
+                                "v_fma_f32 %0, %0, %0, %1\n v_exp_f32 %1, %1\n v_fma_f32 %2, %2, %2, %3\n v_exp_f32 %3, %3\n"
+                                "v_fma_f32 %4, %4, %4, %5\n v_fma_f32 %5, %5, %5, %6\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(acc0), "+v"(acc1)
+                             : "v"(va), "v"(vb));
+            }
+
+#define MF "v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n"
+#define OPS8 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(acc0), "+v"(acc1) : "v"(va), "v"(vb)
+            else if constexpr (TEST == T_M_EXP1) { asm volatile(R8(MF "v_exp_f32 %0, %0\n") OPS8); }
+            else if constexpr (TEST == T_M_EXP2) { asm volatile(R8(MF "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n") OPS8); }
+            else if constexpr (TEST == T_M_EXP4) { asm volatile(R8(MF "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n") OPS8); }
+            else if constexpr (TEST == T_M_CVT6) { asm volatile(R8(MF "v_cvt_pk_bf16_f32 %0, %0, %1\n v_cvt_pk_bf16_f32 %1, %1, %2\n v_cvt_pk_bf16_f32 %2, %2, %3\n v_cvt_pk_bf16_f32 %3, %3, %4\n v_cvt_pk_bf16_f32 %4, %4, %5\n v_cvt_pk_bf16_f32 %5, %5, %6\n") OPS8); }
+            else if constexpr (TEST == T_M_MAX6) { asm volatile(R8(MF "v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %1, %1, %2, %3\n v_max3_f32 %2, %2, %3, %4\n v_max3_f32 %3, %3, %4, %5\n v_max3_f32 %4, %4, %5, %6\n v_max3_f32 %5, %5, %6, %7\n") OPS8); }
+            else if constexpr (TEST == T_M_LSHL6) { asm volatile(R8(MF "v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3\n v_lshlrev_b32 %4, 1, %4\n v_lshlrev_b32 %5, 1, %5\n") OPS8); }
+            else if constexpr (TEST == T_M_ADD6) { asm volatile(R8(MF "v_add_f32 %0, %0, %1\n v_add_f32 %1, %1, %2\n v_add_f32 %2, %2, %3\n v_add_f32 %3, %3, %4\n v_add_f32 %4, %4, %5\n v_add_f32 %5, %5, %6\n") OPS8); }
+            else if constexpr (TEST == T_M_PKMUL6) { asm volatile(R8("v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %3\n v_pk_mul_f32 %3, %3, %4\n v_pk_mul_f32 %4, %4, %5\n v_pk_mul_f32 %5, %5, %6\n") : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]), "+v"(pa[5]), "+v"(pa[6]), "+v"(pa[7]), "+v"(acc0), "+v"(acc1) : "v"(va), "v"(vb)); }
+            else if constexpr (TEST == T_M_PKMUL3) { asm volatile(R8("v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %3\n") : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]), "+v"(pa[5]), "+v"(pa[6]), "+v"(pa[7]), "+v"(acc0), "+v"(acc1) : "v"(va), "v"(vb)); }
+            else if constexpr (TEST == T_M16_EXP2) { asm volatile(R8("v_mfma_f32_16x16x32_bf16 %2, %4, %5, %2\n v_exp_f32 %0, %0\n v_mfma_f32_16x16x32_bf16 %3, %4, %5, %3\n v_exp_f32 %1, %1\n") : "+v"(a[0]), "+v"(a[1]), "+v"(c0), "+v"(c1) : "v"(va), "v"(vb)); }
+        }
+        asm volatile("s_nop 0" ::: "memory");
+        t1 = __builtin_amdgcn_s_memtime();
+    }
+    float sink = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sink += a[i] + pa[i][0] + pa[i][1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sink += acc0[i] + acc1[i];
+    sink += c0[0] + c1[0] + c0[1] + c1[1] + c0[2] + c1[2] + c0[3] + c1[3];
+    if ((threadIdx.x & 63) == 0) {
+        out[blockIdx.x * 16 + wave] = t0;
+        out[blockIdx.x * 16 + 8 + wave] = t1;
+    }
+    if (sink == 123.456f) out[16000] = 1;
+}
+
+template <int TEST>
+void run(unsigned long long* d_out, const char* label, int threads, int mask, int blocks) {
+    const int iters = 200;
+    std::vector<unsigned long long> h(16);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL(bench_kernel<TEST>, dim3(blocks), dim3(threads), 0, 0, d_out, iters, mask);
+        hipDeviceSynchronize();
+    }
+    hipMemcpy(h.data(), d_out, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    // block 0: wave 0 alone, and first start -> last end over the waves of SIMD 0 (waves 0 and 4)
+    const int nw = threads / 64;
+    const double w0 = (double)(h[8] - h[0]) / iters / 8.0;
+    unsigned long long lo = h[0], hi = h[8];
+    for (int w = 0; w < nw; w += 4) {
+        lo = h[w] < lo ? h[w] : lo;
+        hi = h[8 + w] > hi ? h[8 + w] : hi;
+    }
+    const double all = (double)(hi - lo) / iters / 8.0;
+    printf("%-34s %-22s wave 0: ticks/group %7.2f ticks/instr %6.2f | SIMD 0, all waves: ticks/group %7.2f\n", kNames[TEST], label, w0, w0 / kInstrPerIter[TEST], all);
+}
+
+template <int TEST>
+void run_all(unsigned long long* d_out) {
+    run<TEST>(d_out, "1 wave/SIMD, 1 WG", 256, 0x0f, 1);
+    run<TEST>(d_out, "2 waves/SIMD, 1 WG", 512, 0xff, 1);
+    run<TEST>(d_out, "2 waves/SIMD, 512 WGs", 512, 0xff, 512);
+}
+
+int main() {
+    unsigned long long* d_out;
+    hipMalloc(&d_out, 16384 * sizeof(unsigned long long));
+    // s_memtime ticks vs wall clock
+    {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(bench_kernel<T_FMA>, dim3(1), dim3(256), 0, 0, d_out, 20000, 0x0f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long tt[9];
+        hipMemcpy(tt, d_out, 72, hipMemcpyDeviceToHost);
+        const unsigned long long t = tt[8] - tt[0];
+        printf("s_memtime: %.1f ticks/us (kernel %0.3f ms, %llu ticks)\n", t / (ms * 1e3), ms, t);
+    }
+    run_all<T_FMA>(d_out);
+    run_all<T_LSHL>(d_out);
+    run_all<T_EXP>(d_out);
+    run_all<T_CVT>(d_out);
+    run_all<T_PKMUL>(d_out);
+    run_all<T_MAX3>(d_out);
+    run_all<T_ADD>(d_out);
+    run_all<T_MFMA32>(d_out);
+    run_all<T_MFMA16>(d_out);
+    run_all<T_MFMA32_DEP>(d_out);
+    run_all<T_MFMA32_FMA2>(d_out);
+    run_all<T_MFMA32_FMA4>(d_out);
+    run_all<T_MFMA32_FMA6>(d_out);
+    run_all<T_MFMA32_FMA7>(d_out);
+    run_all<T_MFMA32_EXP2FMA4>(d_out);
+    run_all<T_M_EXP1>(d_out);
+    run_all<T_M_EXP2>(d_out);
+    run_all<T_M_EXP4>(d_out);
+    run_all<T_M16_EXP2>(d_out);
+    run_all<T_M_CVT6>(d_out);
+    run_all<T_M_PKMUL6>(d_out);
+    run_all<T_M_PKMUL3>(d_out);
+    run_all<T_M_MAX6>(d_out);
+    run_all<T_M_LSHL6>(d_out);
+    run_all<T_M_ADD6>(d_out);
+    return 0;
+}

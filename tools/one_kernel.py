@@ -18,5 +18,6 @@ if sys.argv[1] == "gemm":
     _lib.check(lib.cwm_bench_gemm(M, N, K, _lib.mode_id(mode), epi, 3, C.byref(us)))
 else:
     B, H, N = (int(v) for v in sys.argv[2:5])
+    _lib.check(lib.cwm_debug_set(b"attn_kernel", int(os.environ.get("ATTN_KERNEL", "0"))))
     _lib.check(lib.cwm_bench_attention(B, H, N, _lib.mode_id(sys.argv[5]), 3, C.byref(us)))
 print(sys.argv[1:], "%.1f us" % us.value)
