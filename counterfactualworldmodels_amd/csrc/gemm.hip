@@ -24,6 +24,7 @@
 // * fused epilogues (bias, residual(+row map), exact-erf GELU, bf16 hi/lo split, Q / K / V head scatter), staged through LDS so
 //   that every global access is an unconditional 16-byte lane access forming whole row segments (gemm_device.h)
 #include "gemm_device.h"
+#include <cstdio>
 #include <algorithm>
 
 namespace cwm {
@@ -195,8 +196,39 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
 // Write-after-read: A half-tiles are staged by the group that reads them (waves 0-3 stage and read rows 0-63,
 // waves 4-7 rows 64-127), so one phase after the reads suffices; W half-tiles are read by both groups, and
 // the leading group re-stages them two phases after the read (W0 read in P1 -> staged in P3, W1 P2 -> P4).
+#ifdef CWM_GEMM_PROF
+// per-workgroup {s_memrealtime begin, end, s_memtime cycles total, cycles to the end of the main loop} (tools/gemm_prof.py)
+__device__ unsigned long long g_gemm_blocks[8192 * 4];
+int gemm_prof_dump() {
+    static unsigned long long h[8192 * 4];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_blocks), sizeof(h)) != hipSuccess) return -1;
+    FILE* f = fopen("/tmp/gemm_blocks.bin", "wb");
+    if (!f) return -1;
+    fwrite(h, 1, sizeof(h), f);
+    fclose(f);
+    return 0;
+}
+#define GEMM_PROF_BEGIN() const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_r0 = __builtin_amdgcn_s_memrealtime(); unsigned long long prof_main = 0
+#define GEMM_PROF_MAIN() prof_main = __builtin_amdgcn_s_memtime() - prof_t0
+#define GEMM_PROF_END()                                                              \
+    do {                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                 \
+            g_gemm_blocks[blockIdx.x * 4 + 0] = prof_r0;                             \
+            g_gemm_blocks[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();    \
+            g_gemm_blocks[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime() - prof_t0; \
+            g_gemm_blocks[blockIdx.x * 4 + 3] = prof_main;                           \
+        }                                                                            \
+    } while (0)
+#else
+int gemm_prof_dump() { return -1; }
+#define GEMM_PROF_BEGIN() do {} while (0)
+#define GEMM_PROF_MAIN() do {} while (0)
+#define GEMM_PROF_END() do {} while (0)
+#endif
+
 template <int PLANES>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
+    GEMM_PROF_BEGIN();
     constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 128 B
     constexpr int BUF_BYTES = 4 * HALF_BYTES;  // A0 | A1 | W0 | W1
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -366,6 +398,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
                     for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[qm][qn][i][j]));
         return;
     }
+    GEMM_PROF_MAIN();
     if (p.staged) {
         // (the balancing barrier above is also the point where every wave is done reading the operand tiles)
         int2* tab = reinterpret_cast<int2*>(smem + 8 * 8192);
@@ -374,6 +407,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
         epilogue_piece_seq<PLANES, 4>(
             p, [&](int pi, int i, int j) { return acc[pi >> 1][pi & 1][i][j]; }, [&](int pi) { return (pi >> 1) * 128 + wr * 64; },
             [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, smem + wave * 8192, tab, lane);
+        GEMM_PROF_END();
         return;
     }
     const int ncol = (lane >> 4) * 4;

@@ -60,6 +60,7 @@ int launch_gemm_sk(GemmParams& p, int planes, hipStream_t stream);  // persisten
 bool sk_shape_ok(int M, int N, int K, int planes, int grid);
 int sk_grid_size();
 int sk_error_flag();
+int gemm_prof_dump();  // builds with -DCWM_GEMM_PROF: per-workgroup timers of gemm8p_kernel -> /tmp/gemm_blocks.bin
 extern int g_gemm_debug;
 extern int g_gemm_staged;
 extern int g_gemm_tile;    // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256 output tile, 4: 256x256 8-phase, 5: persistent stream-K 8-phase

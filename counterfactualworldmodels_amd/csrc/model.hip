@@ -471,6 +471,7 @@ extern "C" int cwm_debug_set(const char* key, int value) {
         g_gemm_tile = value;
         return CWM_OK;
     }
+    if (!strcmp(key, "gemm_prof")) return gemm_prof_dump();  // query (profiling builds)
     if (!strcmp(key, "attn_prof")) return attention_pipe_prof(value);  // query (profiling builds)
     if (!strcmp(key, "sk_error")) return sk_error_flag() == 0 ? CWM_OK : CWM_ERR_INVALID;  // query: stream-K hand-off timeouts
     if (!strcmp(key, "prune_last_block")) {
