@@ -133,6 +133,7 @@ def run_prompts(args, rank, local_rank, world, distributed):
     for _ in range(max(args.warmup, 1)):
         y = step()
     assert y.shape[0] == PROMPTS["total"]
+    model.set_lanes(args.lanes)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -153,7 +154,7 @@ def run_prompts(args, rank, local_rank, world, distributed):
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": PROMPTS["name"], "predictor": cfg.name, "prompts": PROMPTS["total"], "chunk": PROMPTS["chunk"],
-                   "mode": args.mode, "parallelism": "prompts sharded over %d rank(s): broadcast(frame, prompt table) + all_gather(predicted frames)" % n_gpus},
+                   "mode": args.mode, "lanes": args.lanes, "parallelism": "prompts sharded over %d rank(s): broadcast(frame, prompt table) + all_gather(predicted frames)" % n_gpus},
     }
     if distributed:
         dist.barrier()
@@ -225,6 +226,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra fast-mode measurement")
+    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
+                    help="2 (library default): the batch runs as two half batches on two HIP streams; 1: one stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -254,16 +257,29 @@ def main():
     x = torch.from_numpy(S.synthetic_frames(B, cfg, rank)).to(dev)
     mask = torch.from_numpy(S.synthetic_masks(B, cfg, wl["k_vis"], rank, wl["clump"])).to(dev)
 
+    model.sync_weights()
+    model.set_lanes(args.lanes)
     for _ in range(max(args.warmup, 1)):
         model.predict_video(x, mask, normalize=True, n_vis=n_vis, check=True)
     torch.cuda.synchronize()
 
-    model.timing_enable(_lib.KCLASS_GEMM, True)
+    # ---- timed region: `value` -------------------------------------------------------------------------------------------------
     dt = timed_steps(model, x, mask, n_vis, args.steps, distributed)
+
+    # ---- kernel region: the same K steps on ONE lane with a HIP event pair around every GEMM launch -> `roofline`.  With two lanes a
+    # launch shares the chip with whatever the other lane runs, so its duration says nothing about the kernel; here launches are alone.
+    # With --lanes 1 the two regions are the same thing (and that is the command the rocprofv3 summaries under profiles/ are taken from).
+    model.set_lanes(1)
+    if args.lanes != 1:
+        for _ in range(2):
+            model.predict_video(x, mask, normalize=True, n_vis=n_vis, check=False)
+    model.timing_enable(_lib.KCLASS_GEMM, True)
+    dt_one = timed_steps(model, x, mask, n_vis, args.steps, distributed)
     gemm = model.timing_collect(_lib.KCLASS_GEMM)                 # every GEMM launch ...
     gemm_wide = model.timing_collect(_lib.KCLASS_GEMM_WIDE)       # ... split by the kernel that ran it
     gemm_narrow = model.timing_collect(_lib.KCLASS_GEMM_NARROW)
     model.timing_enable(_lib.KCLASS_GEMM, False)
+    model.set_lanes(args.lanes)
 
     value = B * n_gpus * args.steps / dt
     flops_pair = C.algorithmic_flops(cfg, n_vis)
@@ -275,6 +291,8 @@ def main():
         "config": {
             "workload": wl["name"], "predictor": cfg.name, "per_gpu_batch": B, "global_batch": B * n_gpus, "n_vis": n_vis,
             "tokens_decoder": cfg.num_tokens, "mode": args.mode,
+            "lanes": "%d (%s)" % (args.lanes, "the batch runs as two half batches on two HIP streams inside the library" if args.lanes == 2
+                                  else "every kernel on one stream"),
             "arithmetic": "split-bf16 (hi+lo) MFMA operands, 3 MFMAs/product, fp32 accumulate" if args.mode == "parity"
             else "bf16 MFMA operands, fp32 accumulate",
             "parallelism": "dp%d (independent frame pairs per rank, no collective)" % n_gpus,
@@ -298,11 +316,13 @@ def main():
     out["roofline"] = {
         "bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
         "traffic": pmc_traffic(args, dom), "launches": st["launches"], "avg_launch_us": 1e3 * st["total_ms"] / max(st["launches"], 1),
-        "share_of_step": st["total_ms"] / (1e3 * dt) if dt > 0 else None,
-        "note": "algorithmic 2*M*N*K of this kernel's launches in the timed region / their summed HIP-event durations (rank 0)"
+        "share_of_step": st["total_ms"] / (1e3 * dt_one) if dt_one > 0 else None,
+        "region": {"lanes": 1, "steps": args.steps, "ms_per_step": 1e3 * dt_one / args.steps, "value": B * n_gpus * args.steps / dt_one,
+                   "note": "kernel region: the same steps as the timed region, one lane, HIP events around every GEMM launch"},
+        "note": "algorithmic 2*M*N*K of this kernel's launches in the kernel region / their summed HIP-event durations (rank 0)"
                 + ("; parity mode executes 3x these FLOPs on the MFMA pipe" if args.mode == "parity" else ""),
         "all_gemm": {"achieved": tflops(gemm), "launches": gemm["launches"], "avg_launch_us": 1e3 * gemm["total_ms"] / max(gemm["launches"], 1),
-                     "share_of_step": gemm["total_ms"] / (1e3 * dt) if dt > 0 else None},
+                     "share_of_step": gemm["total_ms"] / (1e3 * dt_one) if dt_one > 0 else None},
         "other_kernel": {k: {"achieved": tflops(v), "launches": v["launches"], "avg_launch_us": 1e3 * v["total_ms"] / max(v["launches"], 1)}
                          for k, v in kernels.items() if k != dom},
     }

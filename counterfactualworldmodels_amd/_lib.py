@@ -124,6 +124,7 @@ SIGNATURES = {
     "cwm_model_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "cwm_model_missing_weights": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "cwm_forward": (C.c_int, [C.c_void_p, C.POINTER(CwmForwardArgs)]),
+    "cwm_model_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
     "cwm_conj_create": (C.c_int, [C.POINTER(CwmConjConfig), C.POINTER(C.c_void_p)]),
     "cwm_conj_destroy": (None, [C.c_void_p]),
     "cwm_conj_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),

@@ -22,7 +22,27 @@ struct cwm_model {
     bf16* patches = nullptr;
     float *x_enc = nullptr, *x_dec = nullptr;
     StreamBuffers sb;
+    // batch lanes (cwm_model_set_lanes): a batch whose halves keep >= kMinLaneRows encoder rows runs as two half batches, the first on the
+    // caller's stream and the second on `lane_stream`, joined by events before cwm_forward returns control of the stream
+    int lanes = 2;
+    hipStream_t lane_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~cwm_model() {
+        if (lane_stream) (void)hipStreamDestroy(lane_stream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+    }
 };
+
+// per-lane view of the workspace: every buffer is batch-major, so the lane that starts at batch element b0 owns the slice
+// behind the capacity of b0 elements
+struct LaneWs {
+    int *perm, *rank, *err;
+    bf16* patches;
+    float *x_enc, *x_dec;
+    StreamBuffers sb;
+};
+constexpr int kMinLaneRows = 6000;  // encoder rows (batch elements x visible tokens) a lane must have: below, the GEMM grids no longer fill the chip
 
 namespace {
 
@@ -45,6 +65,26 @@ int ensure_workspace(cwm_model* m, int B, int n_vis) {
     m->ws_batch = Bc;
     m->ws_nvis = Nv;
     return 0;
+}
+
+LaneWs lane_ws(const cwm_model* m, int lane, int b0) {
+    const cwm_config& c = m->cfg;
+    const size_t rows_e = (size_t)b0 * m->ws_nvis, rows_d = (size_t)b0 * m->Nt;
+    const size_t act = std::max(rows_e * c.enc_dim, rows_d * c.dec_dim);
+    LaneWs w;
+    w.perm = m->perm + rows_d;
+    w.rank = m->rank + rows_d;
+    w.err = m->err + lane;
+    w.patches = m->patches + 2 * rows_e * m->patch_kpad;
+    w.x_enc = m->x_enc + rows_e * c.enc_dim;
+    w.x_dec = m->x_dec + rows_d * c.dec_dim;
+    w.sb = m->sb;
+    w.sb.hbuf += 2 * act;
+    w.sb.gbuf += 2 * act * c.mlp_ratio;
+    w.sb.qbuf += 2 * act;
+    w.sb.kbuf += 2 * act;
+    w.sb.vbuf += 2 * act;
+    return w;
 }
 
 }  // namespace
@@ -120,6 +160,81 @@ extern "C" int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen) { 
 
 static int g_prune_last_block = 1;
 
+// One lane: batch elements [b0, b0 + B) of the call, on stream s, in the workspace slice w.
+static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, LaneWs w, hipStream_t s) {
+    const cwm_config& c = m->cfg;
+    const int Nt = m->Nt, Nv = a->n_vis, Nm = Nt - Nv;
+    const int Nret = Nm > 0 ? Nm : Nt;
+    Engine& E = m->eng;
+    const int planes = a->mode == CWM_MODE_PARITY ? 2 : 1;
+    const float* x_in = a->x_dev + (int64_t)b0 * a->x_stride_b;
+    const uint8_t* mask_in = a->mask_dev + (size_t)b0 * Nt;
+    float* y_tokens = a->y_tokens_dev + (size_t)b0 * Nret * m->out_dim;
+    int rc;
+
+    CWM_HIP_CHECK(hipMemsetAsync(w.err, 0, sizeof(int), s));
+    if ((rc = launch_mask_to_perm(mask_in, B, Nt, Nv, w.perm, w.err, s))) return rc;
+
+    // a1-a3: frame load (+normalise) + tubelet patch gather of the visible tokens, patch-embed GEMM
+    // with bias and positional-table add in the epilogue
+    PatchGatherParams pg;
+    memset(&pg, 0, sizeof(pg));
+    pg.x = x_in; pg.sb = a->x_stride_b; pg.sc = a->x_stride_c; pg.st = a->x_stride_t; pg.normalize = a->normalize;
+    pg.C = c.in_chans; pg.H = c.img_h; pg.W = c.img_w; pg.P = c.patch; pg.perm = w.perm; pg.Nt = Nt; pg.n_rows = Nv; pg.B = B;
+    pg.out = w.patches; pg.out_plane = (int64_t)B * Nv * m->patch_kpad; pg.ld = m->patch_kpad;
+    if ((rc = launch_patch_gather(pg, planes, s))) return rc;
+
+    GemmParams g = gemm_base(w.patches, m->patch_kpad, m->patch, B * Nv, planes);
+    g.epi = EPI_F32; g.C = w.x_enc; g.ldc = c.enc_dim;
+    g.resid = m->pos_enc; g.ldr = c.enc_dim; g.resid_rowmap = w.perm; g.rows_in = Nv; g.rows_out = Nv; g.map_stride = Nt;
+    if ((rc = E.run_gemm(g, planes, s))) return rc;
+
+    // a4-a6: encoder blocks over the visible tokens
+    for (int i = 0; i < c.enc_depth; ++i)
+        if ((rc = E.run_block(m->enc[i], w.x_enc, B, Nv, c.enc_dim, c.enc_heads, planes, w.sb, s))) return rc;
+
+    // a7: encoder.norm, encoder_to_decoder (no bias); a8: + pos[vis] written straight into x_full rows [0,Nv)
+    LayerNormParams ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = w.x_enc; ln.ldx = c.enc_dim; ln.gamma = m->enc_norm_g; ln.beta = m->enc_norm_b; ln.eps = c.ln_eps; ln.D = c.enc_dim;
+    ln.rows = B * Nv; ln.out = w.sb.hbuf; ln.out_plane = (int64_t)B * Nv * c.enc_dim; ln.ldo = c.enc_dim;
+    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+    g = gemm_base(w.sb.hbuf, c.enc_dim, m->e2d, B * Nv, planes);
+    g.epi = EPI_F32; g.C = w.x_dec; g.ldc = c.dec_dim;
+    g.resid = m->pos_dec; g.ldr = c.dec_dim; g.resid_rowmap = w.perm; g.rows_in = Nv; g.rows_out = Nt; g.map_stride = Nt;
+    if ((rc = E.run_gemm(g, planes, s))) return rc;
+    if (Nm > 0 && (rc = launch_fill_mask_tokens(w.x_dec, m->mask_token, m->pos_dec, w.perm, B, Nt, Nv, c.dec_dim, s))) return rc;
+
+    // a9: decoder blocks over the full token set, norm + head on the last Nm tokens
+    // (the last block only has to produce the Nm rows the head reads: debug key "prune_last_block" = 0 runs it in full)
+    for (int i = 0; i < c.dec_depth; ++i) {
+        const int keep = (i == c.dec_depth - 1 && Nm > 0 && g_prune_last_block) ? Nm : 0;
+        if ((rc = E.run_block(m->dec[i], w.x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, w.sb, s, keep))) return rc;
+    }
+    memset(&ln, 0, sizeof(ln));
+    ln.x = w.x_dec; ln.ldx = c.dec_dim; ln.gamma = m->dec_norm_g; ln.beta = m->dec_norm_b; ln.eps = c.ln_eps; ln.D = c.dec_dim;
+    ln.rows = B * Nret; ln.rows_out_per_b = Nret; ln.rows_in_per_b = Nt; ln.in_offset = Nt - Nret;
+    ln.out = w.sb.hbuf; ln.out_plane = (int64_t)B * Nret * c.dec_dim; ln.ldo = c.dec_dim;
+    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+    g = gemm_base(w.sb.hbuf, c.dec_dim, m->head, B * Nret, planes);
+    g.epi = EPI_F32; g.C = y_tokens; g.ldc = m->out_dim;
+    if ((rc = E.run_gemm(g, planes, s))) return rc;
+
+    // a11: patch un-embed scatter
+    if (a->y_video_dev) {
+        const float* xr = a->xraw_dev ? a->xraw_dev + (int64_t)b0 * a->x_stride_b : x_in;
+        if ((rc = launch_perm_to_rank(w.perm, w.rank, B, Nt, s))) return rc;
+        UnembedParams u;
+        memset(&u, 0, sizeof(u));
+        u.y = y_tokens; u.x = xr; u.sb = a->x_stride_b; u.sc = a->x_stride_c; u.st = a->x_stride_t;
+        u.mask = mask_in; u.rank = w.rank; u.B = B; u.T = c.num_frames; u.C = c.in_chans; u.H = c.img_h; u.W = c.img_w;
+        u.P = c.patch; u.n_vis = Nv; u.Nm = Nm;
+        u.out = a->y_video_dev + (size_t)b0 * c.num_frames * c.in_chans * c.img_h * c.img_w;
+        if ((rc = launch_unembed(u, s))) return rc;
+    }
+    return CWM_OK;
+}
+
 extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     CWM_REQUIRE(m && a, "cwm_forward: null argument");
     CWM_REQUIRE(a->x_dev && a->mask_dev && a->y_tokens_dev, "cwm_forward: x_dev, mask_dev and y_tokens_dev are required");
@@ -131,89 +246,56 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     // nothing masked: the reference decoder then returns head(norm(x)) for ALL tokens (vmae.py:250-253), and its wrapper cannot
     // compose a video from that (prediction.py:252-254 would assign Nt rows to an empty selection)
     CWM_REQUIRE(Nm > 0 || !a->y_video_dev, "cwm_forward: no token is masked, there is no predicted patch to un-embed");
-    const int Nret = Nm > 0 ? Nm : Nt;
+    CWM_REQUIRE(!a->y_video_dev || a->xraw_dev || a->normalize, "cwm_forward: y_video_dev needs the raw frames (xraw_dev) when normalize=0");
     {
         char miss[256];
         const int nmiss = m->eng.missing_weights(miss, sizeof(miss));
         CWM_REQUIRE(nmiss == 0, "cwm_forward: %d state-dict tensors not loaded (first: %s)", nmiss, miss);
     }
     if (int rc = ensure_workspace(m, B, Nv)) return rc;
-    Engine& E = m->eng;
     hipStream_t s = (hipStream_t)a->stream;
-    const int planes = a->mode == CWM_MODE_PARITY ? 2 : 1;
-    int rc;
 
-    CWM_HIP_CHECK(hipMemsetAsync(m->err, 0, sizeof(int), s));
-    if ((rc = launch_mask_to_perm(a->mask_dev, B, Nt, Nv, m->perm, m->err, s))) return rc;
-
-    // a1-a3: frame load (+normalise) + tubelet patch gather of the visible tokens, patch-embed GEMM
-    // with bias and positional-table add in the epilogue
-    PatchGatherParams pg;
-    memset(&pg, 0, sizeof(pg));
-    pg.x = a->x_dev; pg.sb = a->x_stride_b; pg.sc = a->x_stride_c; pg.st = a->x_stride_t; pg.normalize = a->normalize;
-    pg.C = c.in_chans; pg.H = c.img_h; pg.W = c.img_w; pg.P = c.patch; pg.perm = m->perm; pg.Nt = Nt; pg.n_rows = Nv; pg.B = B;
-    pg.out = m->patches; pg.out_plane = (int64_t)B * Nv * m->patch_kpad; pg.ld = m->patch_kpad;
-    if ((rc = launch_patch_gather(pg, planes, s))) return rc;
-
-    GemmParams g = gemm_base(m->patches, m->patch_kpad, m->patch, B * Nv, planes);
-    g.epi = EPI_F32; g.C = m->x_enc; g.ldc = c.enc_dim;
-    g.resid = m->pos_enc; g.ldr = c.enc_dim; g.resid_rowmap = m->perm; g.rows_in = Nv; g.rows_out = Nv; g.map_stride = Nt;
-    if ((rc = E.run_gemm(g, planes, s))) return rc;
-
-    // a4-a6: encoder blocks over the visible tokens
-    for (int i = 0; i < c.enc_depth; ++i)
-        if ((rc = E.run_block(m->enc[i], m->x_enc, B, Nv, c.enc_dim, c.enc_heads, planes, m->sb, s))) return rc;
-
-    // a7: encoder.norm, encoder_to_decoder (no bias); a8: + pos[vis] written straight into x_full rows [0,Nv)
-    LayerNormParams ln;
-    memset(&ln, 0, sizeof(ln));
-    ln.x = m->x_enc; ln.ldx = c.enc_dim; ln.gamma = m->enc_norm_g; ln.beta = m->enc_norm_b; ln.eps = c.ln_eps; ln.D = c.enc_dim;
-    ln.rows = B * Nv; ln.out = m->sb.hbuf; ln.out_plane = (int64_t)B * Nv * c.enc_dim; ln.ldo = c.enc_dim;
-    if ((rc = launch_layernorm(ln, planes, s))) return rc;
-    g = gemm_base(m->sb.hbuf, c.enc_dim, m->e2d, B * Nv, planes);
-    g.epi = EPI_F32; g.C = m->x_dec; g.ldc = c.dec_dim;
-    g.resid = m->pos_dec; g.ldr = c.dec_dim; g.resid_rowmap = m->perm; g.rows_in = Nv; g.rows_out = Nt; g.map_stride = Nt;
-    if ((rc = E.run_gemm(g, planes, s))) return rc;
-    if (Nm > 0 && (rc = launch_fill_mask_tokens(m->x_dec, m->mask_token, m->pos_dec, m->perm, B, Nt, Nv, c.dec_dim, s))) return rc;
-
-    // a9: decoder blocks over the full token set, norm + head on the last Nm tokens
-    // (the last block only has to produce the Nm rows the head reads: debug key "prune_last_block" = 0 runs it in full)
-    for (int i = 0; i < c.dec_depth; ++i) {
-        const int keep = (i == c.dec_depth - 1 && Nm > 0 && g_prune_last_block) ? Nm : 0;
-        if ((rc = E.run_block(m->dec[i], m->x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, m->sb, s, keep))) return rc;
+    // Two lanes: between two dependent kernels the queue idles ~6 us (x 136 kernels = 5 % of a batch-32 step) and every kernel ends in a
+    // partially filled round of workgroups; a second, independent half batch on another queue fills both.
+    const bool two = m->lanes >= 2 && B >= 2 && (int64_t)(B / 2) * Nv >= kMinLaneRows;
+    const int B0 = two ? (B + 1) / 2 : B;
+    int n_lanes = 1;
+    if (two) {
+        if (!m->lane_stream) {
+            CWM_HIP_CHECK(hipStreamCreateWithFlags(&m->lane_stream, hipStreamNonBlocking));
+            CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+            CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+        }
+        CWM_HIP_CHECK(hipEventRecord(m->ev_fork, s));  // inputs written on the caller's stream are complete for the second lane
+        CWM_HIP_CHECK(hipStreamWaitEvent(m->lane_stream, m->ev_fork, 0));
+        n_lanes = 2;
     }
-    memset(&ln, 0, sizeof(ln));
-    ln.x = m->x_dec; ln.ldx = c.dec_dim; ln.gamma = m->dec_norm_g; ln.beta = m->dec_norm_b; ln.eps = c.ln_eps; ln.D = c.dec_dim;
-    ln.rows = B * Nret; ln.rows_out_per_b = Nret; ln.rows_in_per_b = Nt; ln.in_offset = Nt - Nret;
-    ln.out = m->sb.hbuf; ln.out_plane = (int64_t)B * Nret * c.dec_dim; ln.ldo = c.dec_dim;
-    if ((rc = launch_layernorm(ln, planes, s))) return rc;
-    g = gemm_base(m->sb.hbuf, c.dec_dim, m->head, B * Nret, planes);
-    g.epi = EPI_F32; g.C = a->y_tokens_dev; g.ldc = m->out_dim;
-    if ((rc = E.run_gemm(g, planes, s))) return rc;
-
-    // a11: patch un-embed scatter
-    if (a->y_video_dev) {
-        const float* xr = a->xraw_dev ? a->xraw_dev : a->x_dev;
-        CWM_REQUIRE(a->xraw_dev || a->normalize, "cwm_forward: y_video_dev needs the raw frames (xraw_dev) when normalize=0");
-        if ((rc = launch_perm_to_rank(m->perm, m->rank, B, Nt, s))) return rc;
-        UnembedParams u;
-        memset(&u, 0, sizeof(u));
-        u.y = a->y_tokens_dev; u.x = xr; u.sb = a->x_stride_b; u.sc = a->x_stride_c; u.st = a->x_stride_t;
-        u.mask = a->mask_dev; u.rank = m->rank; u.B = B; u.T = c.num_frames; u.C = c.in_chans; u.H = c.img_h; u.W = c.img_w;
-        u.P = c.patch; u.n_vis = Nv; u.Nm = Nm; u.out = a->y_video_dev;
-        if ((rc = launch_unembed(u, s))) return rc;
+    int rc = forward_lane(m, a, 0, B0, lane_ws(m, 0, 0), s);
+    if (two) {
+        const int rc1 = rc ? rc : forward_lane(m, a, B0, B - B0, lane_ws(m, 1, B0), m->lane_stream);
+        // join even after a failed launch: the caller's stream must not run ahead of work already queued on the lane
+        CWM_HIP_CHECK(hipEventRecord(m->ev_join, m->lane_stream));
+        CWM_HIP_CHECK(hipStreamWaitEvent(s, m->ev_join, 0));
+        rc = rc1;
     }
+    if (rc) return rc;
 
     if (a->check) {
-        int herr = 0;
-        CWM_HIP_CHECK(hipMemcpyAsync(&herr, m->err, sizeof(int), hipMemcpyDeviceToHost, s));
+        int herr[2] = {0, 0};
+        CWM_HIP_CHECK(hipMemcpyAsync(herr, m->err, n_lanes * sizeof(int), hipMemcpyDeviceToHost, s));
         CWM_HIP_CHECK(hipStreamSynchronize(s));
-        if (herr) {
+        if (herr[0] || herr[1]) {
             cwm_set_error("mask rows do not all have n_vis=%d visible tokens (shape '[%d, -1, %d]' is invalid for the gathered input)", Nv, B,
                           c.enc_dim);
             return CWM_ERR_MASK;
         }
     }
+    return CWM_OK;
+}
+
+extern "C" int cwm_model_set_lanes(cwm_model* m, int lanes) {
+    CWM_REQUIRE(m && (lanes == 1 || lanes == 2), "cwm_model_set_lanes: lanes must be 1 or 2");
+    m->lanes = lanes;
     return CWM_OK;
 }
 

@@ -269,6 +269,14 @@ class PretrainVisionTransformer(nn.Module):
         x, strides = self._frame_strides(x_btchw, 2, 1)
         return self._run(x, strides, normalize, mask, n_vis, True, xraw=x, check=check)
 
+    # ---- execution options ----------------------------------------------------------------------------
+    def set_lanes(self, lanes: int):
+        """1: every kernel on the current stream; 2 (library default): batches whose halves keep >= 6000 encoder rows run as two half batches on two HIP
+        streams (forked / joined inside the library), which fills the idle time between dependent kernels."""
+        if self._handle is None:
+            raise RuntimeError("run a forward pass (or sync_weights) before set_lanes")
+        _lib.check(_lib.get_lib().cwm_model_set_lanes(self._handle, int(lanes)))
+
     # ---- kernel timing (bench.py roofline) ------------------------------------------------------------
     def timing_enable(self, kclass: int, enable: bool = True):
         if self._handle is None:

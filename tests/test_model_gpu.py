@@ -215,3 +215,32 @@ def test_last_decoder_block_pruning_is_exact():
                 assert torch.equal(outs[0], outs[1]), (name, mode, (outs[0] - outs[1]).abs().max().item())
     finally:
         _lib.check(lib.cwm_debug_set(b"prune_last_block", 1))
+
+
+def test_two_lanes_match_one_lane_and_report_mask_errors_of_both():
+    """cwm_model_set_lanes: a batch of 17 runs as 9 + 8 on two streams (fork / join inside cwm_forward).  Tokens and video must be
+    those of the single-lane call up to the per-shape kernel choice, the caller's stream must see finished outputs, and a bad mask row
+    in the SECOND lane must still raise the reference's error."""
+    cfg = C.CONFIGS["base_8x8patch_2frames_1tube"]
+    m = build(cfg, 3)
+    B = 17
+    x = torch.from_numpy(S.synthetic_frames(B, cfg, 5)).cuda()
+    mask = torch.from_numpy(S.synthetic_masks(B, cfg, 8, 5)).cuda()
+    n_vis = cfg.tokens_per_frame + 8
+    y2, v2 = m.predict_video(x, mask, n_vis=n_vis)          # library default: two lanes
+    m.set_lanes(1)
+    y1, v1 = m.predict_video(x, mask, n_vis=n_vis)
+    m.set_lanes(2)
+    y2b, v2b = m.predict_video(x, mask, n_vis=n_vis)
+    assert torch.equal(y2, y2b) and torch.equal(v2, v2b)    # deterministic
+    err_t, err_v = (y2 - y1).abs().max().item(), (v2 - v1).abs().max().item()
+    print(f"[lanes] 2 vs 1 lanes: tokens {err_t:.2e} video {err_v:.2e}")
+    assert err_t <= 5e-5 and err_v <= 5e-5
+    bad = mask.clone()
+    row = B - 2                                              # second lane
+    j = int(torch.nonzero(~bad[row])[0])
+    bad[row, j] = True                                       # one visible token fewer in that row
+    with pytest.raises(RuntimeError, match="is invalid for"):
+        m.predict_video(x, bad, n_vis=n_vis)
+    y3, _ = m.predict_video(x, mask, n_vis=n_vis)            # the model is usable afterwards
+    assert torch.equal(y3, y2)

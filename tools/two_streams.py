@@ -21,7 +21,9 @@ def model():
 B = 32
 x = torch.from_numpy(S.synthetic_frames(B, cfg, 0)).cuda()
 mask = torch.from_numpy(S.synthetic_masks(B, cfg, 8, 0)).cuda()
-m0, m1, m2 = model(), model(), model()
+m0, m1, m2, m3 = model(), model(), model(), model()
+m3.predict_video(x, mask, n_vis=792, check=False)
+m3.set_lanes(1)
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 h = B // 2
 
@@ -29,6 +31,19 @@ h = B // 2
 def full(n):
     for _ in range(n):
         m0.predict_video(x, mask, n_vis=792, check=False)
+
+
+def full_one_lane(n):
+    for _ in range(n):
+        m3.predict_video(x, mask, n_vis=792, check=False)
+
+
+def two_full(n):
+    for _ in range(n):
+        with torch.cuda.stream(s1):
+            m1.predict_video(x, mask, n_vis=792, check=False)
+        with torch.cuda.stream(s2):
+            m2.predict_video(x, mask, n_vis=792, check=False)
 
 
 def halves(n):
@@ -39,11 +54,11 @@ def halves(n):
             m2.predict_video(x[h:], mask[h:], n_vis=792, check=False)
 
 
-for name, fn in (("one stream, batch 32", full), ("two streams, batch 16 each", halves), ("one stream, batch 32", full)):
+for name, fn, nb in (("library lanes=2, batch 32", full, 1), ("library lanes=1, batch 32", full_one_lane, 1), ("two streams, batch 16 each", halves, 1), ("two streams, batch 32 each", two_full, 2), ("library lanes=2, batch 32", full, 1)):
     fn(3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     fn(15)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("%-28s %.2f ms / 32 frame pairs  %.1f frames/s" % (name, 1e3 * dt / 15, B * 15 / dt), flush=True)
+    print("%-28s %.2f ms / step  %.1f frames/s" % (name, 1e3 * dt / 15, nb * B * 15 / dt), flush=True)
