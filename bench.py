@@ -182,6 +182,8 @@ def run_imu(args, rank, local_rank, world, distributed):
     def step():
         return model(x, mask, x_context=imu, mask_context=mc, normalize=True, check=False)
 
+    step()
+    model.set_lanes(args.lanes)
     for _ in range(max(args.warmup, 1)):
         step()
     if distributed:
@@ -206,7 +208,7 @@ def run_imu(args, rank, local_rank, world, distributed):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "IMU-conditioned ViT-base 4x4 (conjoined RGB+IMU streams), batch=16 (BASELINE configs[4])", "predictor": cfg.name,
-                   "per_gpu_batch": B, "mode": args.mode, "tokens_decoder": cfg.main.num_tokens + cfg.main_max_pad},
+                   "per_gpu_batch": B, "mode": args.mode, "lanes": args.lanes, "tokens_decoder": cfg.main.num_tokens + cfg.main_max_pad},
         "model_tflops": flops_pair * value / 1e12, "model_frac_of_bf16_peak": flops_pair * value / 1e12 / (PEAK_BF16_TFLOPS * n_gpus),
     }
     if distributed:

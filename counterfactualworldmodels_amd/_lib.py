@@ -130,6 +130,7 @@ SIGNATURES = {
     "cwm_conj_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "cwm_conj_missing_weights": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "cwm_conj_forward": (C.c_int, [C.c_void_p, C.POINTER(CwmConjForwardArgs)]),
+    "cwm_conj_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
     "cwm_conj_timing_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "cwm_conj_timing_collect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(CwmKernelStats)]),
     "cwm_timing_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -242,6 +242,12 @@ class ConjoinedPaddedVisionTransformer(nn.Module):
         self.main_stream.null_mask = torch.cat([torch.zeros(B, Nt - vmax, dtype=torch.bool, device=dev), pad], -1)
         return y
 
+    def set_lanes(self, lanes: int):
+        """See `vmae.PretrainVisionTransformer.set_lanes`."""
+        if self._handle is None:
+            raise RuntimeError("run a forward pass (or sync_weights) before set_lanes")
+        _lib.check(_lib.get_lib().cwm_conj_set_lanes(self._handle, int(lanes)))
+
     def timing_enable(self, kclass: int, enable: bool = True):
         _lib.check(_lib.get_lib().cwm_conj_timing_enable(self._handle, kclass, int(enable)))
 

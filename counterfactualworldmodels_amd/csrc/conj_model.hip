@@ -41,7 +41,72 @@ struct cwm_conj_model {
     int* err = nullptr;
     float *qk = nullptr, *v = nullptr, *qk_src = nullptr, *v_src = nullptr, *scores_t = nullptr, *cross_partial = nullptr;
     bf16 *ybuf = nullptr, *ysbuf = nullptr;
+    // batch lanes (cwm_conj_set_lanes; see cwm_model in model.hip)
+    int lanes = 2;
+    hipStream_t lane_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~cwm_conj_model() {
+        if (lane_stream) (void)hipStreamDestroy(lane_stream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+    }
 };
+
+namespace {
+
+// One lane's view of the model: the weight pointers of both streams (copied), and the slice of every batch-major workspace buffer
+// that lies behind the capacity of the b0 batch elements of the lanes before it.
+struct ConjLane {
+    cwm_conj_model* m;
+    StreamW main, ctx;
+    int* err;
+    float *qk, *v, *qk_src, *v_src, *scores_t, *cross_partial;
+    bf16 *ybuf, *ysbuf;
+};
+
+void shift_stream(StreamW& S, int b0, int vcap, int mlp_ratio, bool small) {
+    const int next = S.n_tok + S.max_pad;
+    const size_t rows_e = (size_t)b0 * vcap, rows_d = (size_t)b0 * next;
+    const size_t act = std::max(rows_e * S.enc_dim, rows_d * S.dec_dim);
+    S.ext_mask += rows_d;
+    S.perm += rows_d;
+    S.tokens_in += 2 * rows_e * S.embed_kpad;
+    S.x_enc += rows_e * S.enc_dim;
+    S.x_dec += rows_d * S.dec_dim;
+    S.sb.hbuf += 2 * act;
+    S.sb.gbuf += 2 * act * mlp_ratio;
+    if (small) {
+        S.sb.qkv_f32 += 3 * act;
+    } else {
+        S.sb.qbuf += 2 * act;
+        S.sb.kbuf += 2 * act;
+        S.sb.vbuf += 2 * act;
+    }
+}
+
+ConjLane conj_lane(cwm_conj_model* m, int lane, int b0) {
+    ConjLane L;
+    L.m = m;
+    L.main = m->main;
+    L.ctx = m->ctx;
+    shift_stream(L.main, b0, m->ws_vmain, m->cfg.main.mlp_ratio, false);
+    shift_stream(L.ctx, b0, m->ws_vctx, m->cfg.main.mlp_ratio, true);
+    const size_t Nb = (size_t)b0 * (m->main.n_tok + m->main.max_pad), Mb = (size_t)b0 * (m->ctx.n_tok + m->ctx.max_pad);
+    const size_t Dmax = std::max(m->main.enc_dim, m->main.dec_dim);
+    const int Mtok = m->ctx.n_tok + m->ctx.max_pad;
+    L.err = m->err + lane;
+    L.qk = m->qk + Nb * 2 * Dmax;
+    L.v = m->v + Nb * Dmax;
+    L.qk_src = m->qk_src + Mb * 2 * Dmax;
+    L.v_src = m->v_src + Mb * Dmax;
+    L.scores_t = m->scores_t + Nb * m->cfg.cross_heads * Mtok;
+    L.cross_partial = m->cross_partial + cross_attention_partial_floats(b0, m->cfg.cross_heads, Mtok, (int)Dmax / m->cfg.cross_heads);
+    L.ybuf = m->ybuf + 2 * Nb * Dmax;
+    L.ysbuf = m->ysbuf + 2 * Mb * Dmax;
+    return L;
+}
+
+}  // namespace
 
 namespace {
 
@@ -182,31 +247,32 @@ int linear_gelu(Engine& E, const bf16* A, int rows, int K, const LinearW& L, bf1
 }
 
 // CrossAttentionTransformerBlock.forward (transformer.py:559-583) with with_self_attention=False
-int run_cross(cwm_conj_model* m, const CrossW& C, float* x, int N, int ci, float* src, int M, int cs, int B, int planes, hipStream_t s) {
+int run_cross(ConjLane& L, const CrossW& C, float* x, int N, int ci, float* src, int M, int cs, int B, int planes, hipStream_t s) {
+    cwm_conj_model* m = L.m;
     Engine& E = m->eng;
     const int D = ci, heads = m->cfg.cross_heads, hd = D / heads;
     const int rows = B * N, rows_s = B * M;
     int rc;
-    if ((rc = layernorm_to(E, x, rows, ci, C.n1_g, C.n1_b, m->main.sb.hbuf, planes, s))) return rc;
-    if ((rc = layernorm_to(E, src, rows_s, cs, C.n1s_g, C.n1s_b, m->ctx.sb.hbuf, planes, s))) return rc;
-    if ((rc = linear_f32(E, m->main.sb.hbuf, rows, ci, C.qk, m->qk, nullptr, planes, s))) return rc;
-    if ((rc = linear_f32(E, m->main.sb.hbuf, rows, ci, C.v, m->v, nullptr, planes, s))) return rc;
-    if ((rc = linear_f32(E, m->ctx.sb.hbuf, rows_s, cs, C.qk_src, m->qk_src, nullptr, planes, s))) return rc;
-    if ((rc = linear_f32(E, m->ctx.sb.hbuf, rows_s, cs, C.v_src, m->v_src, nullptr, planes, s))) return rc;
+    if ((rc = layernorm_to(E, x, rows, ci, C.n1_g, C.n1_b, L.main.sb.hbuf, planes, s))) return rc;
+    if ((rc = layernorm_to(E, src, rows_s, cs, C.n1s_g, C.n1s_b, L.ctx.sb.hbuf, planes, s))) return rc;
+    if ((rc = linear_f32(E, L.main.sb.hbuf, rows, ci, C.qk, L.qk, nullptr, planes, s))) return rc;
+    if ((rc = linear_f32(E, L.main.sb.hbuf, rows, ci, C.v, L.v, nullptr, planes, s))) return rc;
+    if ((rc = linear_f32(E, L.ctx.sb.hbuf, rows_s, cs, C.qk_src, L.qk_src, nullptr, planes, s))) return rc;
+    if ((rc = linear_f32(E, L.ctx.sb.hbuf, rows_s, cs, C.v_src, L.v_src, nullptr, planes, s))) return rc;
     CrossAttnParams ca;
     memset(&ca, 0, sizeof(ca));
-    ca.qk = m->qk; ca.v = m->v; ca.qk_src = m->qk_src; ca.v_src = m->v_src; ca.B = B; ca.N = N; ca.M = M; ca.heads = heads; ca.head_dim = hd;
+    ca.qk = L.qk; ca.v = L.v; ca.qk_src = L.qk_src; ca.v_src = L.v_src; ca.B = B; ca.N = N; ca.M = M; ca.heads = heads; ca.head_dim = hd;
     ca.scale = 1.0f / sqrtf((float)hd);
-    ca.y = m->ybuf; ca.y_plane = (int64_t)rows * D; ca.y_src = m->ysbuf; ca.y_src_plane = (int64_t)rows_s * D; ca.scores_t = m->scores_t; ca.partial = m->cross_partial;
+    ca.y = L.ybuf; ca.y_plane = (int64_t)rows * D; ca.y_src = L.ysbuf; ca.y_src_plane = (int64_t)rows_s * D; ca.scores_t = L.scores_t; ca.partial = L.cross_partial;
     if ((rc = launch_cross_attention(ca, planes, s))) return rc;
-    if ((rc = linear_f32(E, m->ybuf, rows, D, C.proj, x, x, planes, s))) return rc;          // x += proj(y) + b
-    if ((rc = linear_f32(E, m->ysbuf, rows_s, D, C.proj_src, src, src, planes, s))) return rc;
-    if ((rc = layernorm_to(E, x, rows, ci, C.n2_g, C.n2_b, m->main.sb.hbuf, planes, s))) return rc;
-    if ((rc = linear_gelu(E, m->main.sb.hbuf, rows, ci, C.mlp_t0, m->main.sb.gbuf, planes, s))) return rc;
-    if ((rc = linear_f32(E, m->main.sb.gbuf, rows, C.mlp_t0.N, C.mlp_t2, x, x, planes, s))) return rc;
-    if ((rc = layernorm_to(E, src, rows_s, cs, C.n2s_g, C.n2s_b, m->ctx.sb.hbuf, planes, s))) return rc;
-    if ((rc = linear_gelu(E, m->ctx.sb.hbuf, rows_s, cs, C.mlp_s0, m->ctx.sb.gbuf, planes, s))) return rc;
-    return linear_f32(E, m->ctx.sb.gbuf, rows_s, C.mlp_s0.N, C.mlp_s2, src, src, planes, s);
+    if ((rc = linear_f32(E, L.ybuf, rows, D, C.proj, x, x, planes, s))) return rc;          // x += proj(y) + b
+    if ((rc = linear_f32(E, L.ysbuf, rows_s, D, C.proj_src, src, src, planes, s))) return rc;
+    if ((rc = layernorm_to(E, x, rows, ci, C.n2_g, C.n2_b, L.main.sb.hbuf, planes, s))) return rc;
+    if ((rc = linear_gelu(E, L.main.sb.hbuf, rows, ci, C.mlp_t0, L.main.sb.gbuf, planes, s))) return rc;
+    if ((rc = linear_f32(E, L.main.sb.gbuf, rows, C.mlp_t0.N, C.mlp_t2, x, x, planes, s))) return rc;
+    if ((rc = layernorm_to(E, src, rows_s, cs, C.n2s_g, C.n2s_b, L.ctx.sb.hbuf, planes, s))) return rc;
+    if ((rc = linear_gelu(E, L.ctx.sb.hbuf, rows_s, cs, C.mlp_s0, L.ctx.sb.gbuf, planes, s))) return rc;
+    return linear_f32(E, L.ctx.sb.gbuf, rows_s, C.mlp_s0.N, C.mlp_s2, src, src, planes, s);
 }
 
 // tokens + pos | null tokens, gathered by the padded mask (pad_and_mask_input, conjoined_vmae.py:125-134)
@@ -301,46 +367,43 @@ extern "C" int cwm_conj_load_weight(cwm_conj_model* m, const char* key, const fl
 
 extern "C" int cwm_conj_missing_weights(cwm_conj_model* m, char* buf, int buflen) { return m->eng.missing_weights(buf, buflen); }
 
-extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* a) {
-    CWM_REQUIRE(m && a, "cwm_conj_forward: null argument");
-    CWM_REQUIRE(a->x_dev && a->mask_dev && a->ctx_dev && a->ctx_mask_dev && a->y_tokens_dev, "cwm_conj_forward: x, mask, context, context mask and y are required");
-    CWM_REQUIRE(a->mode == CWM_MODE_FAST || a->mode == CWM_MODE_PARITY, "cwm_conj_forward: bad mode %d", a->mode);
+// One lane: batch elements [b0, b0 + B) of the call on stream s.
+static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0, int B, hipStream_t s) {
+    cwm_conj_model* m = L.m;
     const cwm_conj_config& c = m->cfg;
     const cwm_config& mc = c.main;
-    StreamW& A = m->main;
-    StreamW& S = m->ctx;
-    const int B = a->batch, vm = a->n_vis_max, vc = a->n_vis_ctx_max;
+    StreamW& A = L.main;
+    StreamW& S = L.ctx;
+    const int vm = a->n_vis_max, vc = a->n_vis_ctx_max;
     const int Nx = A.n_tok + A.max_pad, Mx = S.n_tok + S.max_pad;
-    CWM_REQUIRE(B > 0 && vm > 0 && vm < Nx && vc > 0 && vc <= S.n_tok, "cwm_conj_forward: bad batch / visible counts (%d, %d, %d)", B, vm, vc);
-    {
-        char miss[256];
-        const int nmiss = m->eng.missing_weights(miss, sizeof(miss));
-        CWM_REQUIRE(nmiss == 0, "cwm_conj_forward: %d state-dict tensors not loaded (first: %s)", nmiss, miss);
-    }
-    if (int rc = ensure_workspace(m, B, vm, vc)) return rc;
+    const int n_out = Nx - vm;
     Engine& E = m->eng;
-    hipStream_t s = (hipStream_t)a->stream;
     const int planes = a->mode == CWM_MODE_PARITY ? 2 : 1;
+    const float* x_in = a->x_dev + (int64_t)b0 * a->x_stride_b;
+    const uint8_t* mask_in = a->mask_dev + (size_t)b0 * A.n_tok;
+    const float* ctx_in = a->ctx_dev + (size_t)b0 * c.ctx_in_chans * c.ctx_seq_len;
+    const uint8_t* ctx_mask_in = a->ctx_mask_dev + (size_t)b0 * S.n_tok;
+    float* y_tokens = a->y_tokens_dev + (size_t)b0 * n_out * A.out_dim;
     int rc;
 
     // a13: padded masks -> permutations [visible slots ascending | masked slots ascending] over n_tok + max_pad slots
-    CWM_HIP_CHECK(hipMemsetAsync(m->err, 0, sizeof(int), s));
-    if ((rc = launch_pad_mask(a->mask_dev, B, A.n_tok, A.max_pad, vm, A.ext_mask, s))) return rc;
-    if ((rc = launch_mask_to_perm(A.ext_mask, B, Nx, vm, A.perm, m->err, s))) return rc;
-    if ((rc = launch_pad_mask(a->ctx_mask_dev, B, S.n_tok, S.max_pad, vc, S.ext_mask, s))) return rc;
-    if ((rc = launch_mask_to_perm(S.ext_mask, B, Mx, vc, S.perm, m->err, s))) return rc;
+    CWM_HIP_CHECK(hipMemsetAsync(L.err, 0, sizeof(int), s));
+    if ((rc = launch_pad_mask(mask_in, B, A.n_tok, A.max_pad, vm, A.ext_mask, s))) return rc;
+    if ((rc = launch_mask_to_perm(A.ext_mask, B, Nx, vm, A.perm, L.err, s))) return rc;
+    if ((rc = launch_pad_mask(ctx_mask_in, B, S.n_tok, S.max_pad, vc, S.ext_mask, s))) return rc;
+    if ((rc = launch_mask_to_perm(S.ext_mask, B, Mx, vc, S.perm, L.err, s))) return rc;
 
     // a2/a14: tokenise both streams (visible slots only)
     PatchGatherParams pg;
     memset(&pg, 0, sizeof(pg));
-    pg.x = a->x_dev; pg.sb = a->x_stride_b; pg.sc = a->x_stride_c; pg.st = a->x_stride_t; pg.normalize = a->normalize;
+    pg.x = x_in; pg.sb = a->x_stride_b; pg.sc = a->x_stride_c; pg.st = a->x_stride_t; pg.normalize = a->normalize;
     pg.C = mc.in_chans; pg.H = mc.img_h; pg.W = mc.img_w; pg.P = mc.patch; pg.perm = A.perm; pg.Nt = A.n_tok; pg.perm_stride = Nx; pg.n_rows = vm; pg.B = B;
     pg.out = A.tokens_in; pg.out_plane = (int64_t)B * vm * A.embed_kpad; pg.ld = A.embed_kpad;
     if ((rc = launch_patch_gather(pg, planes, s))) return rc;
     if ((rc = embed_stream(m, A, B, vm, planes, s))) return rc;
     ImuGatherParams ig;
     memset(&ig, 0, sizeof(ig));
-    ig.imu = a->ctx_dev; ig.B = B; ig.C = c.ctx_in_chans; ig.L = c.ctx_seq_len; ig.tubelet = c.ctx_tubelet; ig.perm = S.perm; ig.perm_stride = Mx;
+    ig.imu = ctx_in; ig.B = B; ig.C = c.ctx_in_chans; ig.L = c.ctx_seq_len; ig.tubelet = c.ctx_tubelet; ig.perm = S.perm; ig.perm_stride = Mx;
     ig.n_rows = vc; ig.n_real = S.n_tok; ig.out = S.tokens_in; ig.out_plane = (int64_t)B * vc * S.embed_kpad; ig.ld = S.embed_kpad;
     if ((rc = launch_imu_gather(ig, planes, s))) return rc;
     if ((rc = embed_stream(m, S, B, vc, planes, s))) return rc;
@@ -348,7 +411,7 @@ extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* 
     // encoder: cross block BEFORE the self-attention blocks listed in enc_cross (forward_encoder_blocks :543-576)
     for (int i = 0; i < mc.enc_depth; ++i) {
         for (int k = 0; k < c.n_enc_cross; ++k)
-            if (c.enc_cross[k] == i && (rc = run_cross(m, m->enc_cross[k], A.x_enc, vm, A.enc_dim, S.x_enc, vc, S.enc_dim, B, planes, s))) return rc;
+            if (c.enc_cross[k] == i && (rc = run_cross(L, m->enc_cross[k], A.x_enc, vm, A.enc_dim, S.x_enc, vc, S.enc_dim, B, planes, s))) return rc;
         if ((rc = E.run_block(A.enc[i], A.x_enc, B, vm, A.enc_dim, A.enc_heads, planes, A.sb, s))) return rc;
         if ((rc = E.run_block_small(S.enc[i], S.x_enc, B, vc, S.enc_dim, S.enc_heads, planes, S.sb, s))) return rc;
     }
@@ -359,11 +422,10 @@ extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* 
         if ((rc = E.run_block(A.dec[i], A.x_dec, B, Nx, A.dec_dim, A.dec_heads, planes, A.sb, s))) return rc;
         if ((rc = E.run_block_small(S.dec[i], S.x_dec, B, Mx, S.dec_dim, S.dec_heads, planes, S.sb, s))) return rc;
         for (int k = 0; k < c.n_dec_cross; ++k)
-            if (c.dec_cross[k] == i && (rc = run_cross(m, m->dec_cross[k], A.x_dec, Nx, A.dec_dim, S.x_dec, Mx, S.dec_dim, B, planes, s))) return rc;
+            if (c.dec_cross[k] == i && (rc = run_cross(L, m->dec_cross[k], A.x_dec, Nx, A.dec_dim, S.x_dec, Mx, S.dec_dim, B, planes, s))) return rc;
     }
 
     // main output: head(norm(x[:, -n_out:])) * ~null_mask   (conjoined_decode :984-1002)
-    const int n_out = Nx - vm;
     LayerNormParams ln;
     memset(&ln, 0, sizeof(ln));
     ln.x = A.x_dec; ln.ldx = A.dec_dim; ln.gamma = A.dec_norm_g; ln.beta = A.dec_norm_b; ln.eps = E.ln_eps; ln.D = A.dec_dim;
@@ -371,19 +433,64 @@ extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* 
     ln.out = A.sb.hbuf; ln.out_plane = (int64_t)B * n_out * A.dec_dim; ln.ldo = A.dec_dim;
     if ((rc = launch_layernorm(ln, planes, s))) return rc;
     GemmParams g = gemm_base(A.sb.hbuf, A.dec_dim, A.head, B * n_out, planes);
-    g.epi = EPI_F32; g.C = a->y_tokens_dev; g.ldc = A.out_dim;
+    g.epi = EPI_F32; g.C = y_tokens; g.ldc = A.out_dim;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
-    if ((rc = launch_zero_pad_out_rows(a->y_tokens_dev, A.perm, B, Nx, vm, n_out, A.n_tok, A.out_dim, s))) return rc;
+    return launch_zero_pad_out_rows(y_tokens, A.perm, B, Nx, vm, n_out, A.n_tok, A.out_dim, s);
+}
+
+extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* a) {
+    CWM_REQUIRE(m && a, "cwm_conj_forward: null argument");
+    CWM_REQUIRE(a->x_dev && a->mask_dev && a->ctx_dev && a->ctx_mask_dev && a->y_tokens_dev, "cwm_conj_forward: x, mask, context, context mask and y are required");
+    CWM_REQUIRE(a->mode == CWM_MODE_FAST || a->mode == CWM_MODE_PARITY, "cwm_conj_forward: bad mode %d", a->mode);
+    const int B = a->batch, vm = a->n_vis_max, vc = a->n_vis_ctx_max;
+    const int Nx = m->main.n_tok + m->main.max_pad;
+    CWM_REQUIRE(B > 0 && vm > 0 && vm < Nx && vc > 0 && vc <= m->ctx.n_tok, "cwm_conj_forward: bad batch / visible counts (%d, %d, %d)", B, vm, vc);
+    {
+        char miss[256];
+        const int nmiss = m->eng.missing_weights(miss, sizeof(miss));
+        CWM_REQUIRE(nmiss == 0, "cwm_conj_forward: %d state-dict tensors not loaded (first: %s)", nmiss, miss);
+    }
+    if (int rc = ensure_workspace(m, B, vm, vc)) return rc;
+    hipStream_t s = (hipStream_t)a->stream;
+
+    // two lanes as in cwm_forward (model.hip): the halves share n_vis_max / n_vis_ctx_max, so the padded layout of every row is unchanged
+    const bool two = m->lanes >= 2 && B >= 2 && (int64_t)(B / 2) * vm >= 6000;
+    const int B0 = two ? (B + 1) / 2 : B;
+    if (two) {
+        if (!m->lane_stream) {
+            CWM_HIP_CHECK(hipStreamCreateWithFlags(&m->lane_stream, hipStreamNonBlocking));
+            CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+            CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+        }
+        CWM_HIP_CHECK(hipEventRecord(m->ev_fork, s));
+        CWM_HIP_CHECK(hipStreamWaitEvent(m->lane_stream, m->ev_fork, 0));
+    }
+    ConjLane L0 = conj_lane(m, 0, 0);
+    int rc = conj_forward_lane(L0, a, 0, B0, s);
+    if (two) {
+        ConjLane L1 = conj_lane(m, 1, B0);
+        const int rc1 = rc ? rc : conj_forward_lane(L1, a, B0, B - B0, m->lane_stream);
+        CWM_HIP_CHECK(hipEventRecord(m->ev_join, m->lane_stream));
+        CWM_HIP_CHECK(hipStreamWaitEvent(s, m->ev_join, 0));
+        rc = rc1;
+    }
+    if (rc) return rc;
 
     if (a->check) {
-        int herr = 0;
-        CWM_HIP_CHECK(hipMemcpyAsync(&herr, m->err, sizeof(int), hipMemcpyDeviceToHost, s));
+        int herr[2] = {0, 0};
+        CWM_HIP_CHECK(hipMemcpyAsync(herr, m->err, (two ? 2 : 1) * sizeof(int), hipMemcpyDeviceToHost, s));
         CWM_HIP_CHECK(hipStreamSynchronize(s));
-        if (herr) {
+        if (herr[0] || herr[1]) {
             cwm_set_error("n_vis_max / n_vis_ctx_max do not match the masks (a row has more visible tokens, or the padding budget is exceeded)");
             return CWM_ERR_MASK;
         }
     }
+    return CWM_OK;
+}
+
+extern "C" int cwm_conj_set_lanes(cwm_conj_model* m, int lanes) {
+    CWM_REQUIRE(m && (lanes == 1 || lanes == 2), "cwm_conj_set_lanes: lanes must be 1 or 2");
+    m->lanes = lanes;
     return CWM_OK;
 }
 

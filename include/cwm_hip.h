@@ -136,6 +136,7 @@ typedef struct cwm_conj_forward_args {
 
 /* replaces: `self.predictor(self._preprocess(x), mask, x_context=..., mask_context=...)` (prediction.py:419-422) */
 int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* args);
+int cwm_conj_set_lanes(cwm_conj_model* m, int lanes); /* as cwm_model_set_lanes; the halves keep the call's n_vis_max / n_vis_ctx_max */
 int cwm_conj_timing_enable(cwm_conj_model* m, int kclass, int enable);
 int cwm_conj_timing_collect(cwm_conj_model* m, int kclass, struct cwm_kernel_stats* out);
 

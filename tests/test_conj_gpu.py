@@ -76,3 +76,29 @@ def test_conj_errors():
         m(x, bad, x_context=imu)
     with pytest.raises(RuntimeError):
         m(x.cpu(), mask.cpu(), x_context=imu.cpu())
+
+
+def test_imu400_two_lanes_match_one_lane():
+    """cwm_conj_set_lanes: batch 5 of the full-size IMU model (ragged visible counts, ragged context masks) runs as 3 + 2 on two
+    streams; both halves keep the call's n_vis_max, so every row -- values and the zeroed pad slots -- must equal the one-lane result."""
+    g = np.load(os.path.join(GOLDEN, "conj_imu400_b2.npz"))
+    cfg = C.CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"]
+    m = build(cfg, int(g["seed"]))
+    B = 5
+    x = V.preprocess(torch.from_numpy(S.synthetic_frames(B, cfg.main, 1))).cuda()
+    mask2 = torch.from_numpy(g["mask"])                       # two rows with different visible counts
+    mask = torch.stack([mask2[i % 2] for i in range(B)]).cuda()
+    imu = torch.from_numpy(g["imu"])
+    imu = torch.stack([imu[i % 2] * (1.0 + 0.1 * i) for i in range(B)]).cuda()
+    mc = torch.zeros(B, 25, dtype=torch.bool, device="cuda")
+    mc[1, 3] = True
+    mc[4, 7:9] = True
+    y2 = m(x, mask, x_context=imu, mask_context=mc)           # library default: two lanes (3 + 2)
+    m.set_lanes(1)
+    y1 = m(x, mask, x_context=imu, mask_context=mc)
+    m.set_lanes(2)
+    err = (y2 - y1).abs().max().item()
+    print(f"[imu400 lanes] 2 vs 1 lanes: {err:.2e}")
+    assert y1.shape == y2.shape and err <= 5e-5
+    assert torch.equal(y1.abs().sum(-1) == 0, y2.abs().sum(-1) == 0)
+    assert torch.equal(m(x, mask, x_context=imu, mask_context=mc), y2)
