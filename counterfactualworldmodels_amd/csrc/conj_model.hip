@@ -466,10 +466,12 @@ extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* 
         CWM_HIP_CHECK(hipStreamWaitEvent(m->lane_stream, m->ev_fork, 0));
     }
     ConjLane L0 = conj_lane(m, 0, 0);
+    m->eng.overlapped = two;
     int rc = conj_forward_lane(L0, a, 0, B0, s);
     if (two) {
         ConjLane L1 = conj_lane(m, 1, B0);
         const int rc1 = rc ? rc : conj_forward_lane(L1, a, B0, B - B0, m->lane_stream);
+        m->eng.overlapped = 0;
         CWM_HIP_CHECK(hipEventRecord(m->ev_join, m->lane_stream));
         CWM_HIP_CHECK(hipStreamWaitEvent(s, m->ev_join, 0));
         rc = rc1;

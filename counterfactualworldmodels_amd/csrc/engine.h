@@ -65,6 +65,7 @@ struct StreamBuffers {
 
 struct Engine {
     int device = 0;
+    int overlapped = 0;  // 1 while a forward call runs two batch lanes (passed to the GEMM kernel choice)
     float ln_eps = 1e-6f;
     std::map<std::string, Slot> slots;
     std::vector<void*> allocs;     // weights etc., freed on destroy

@@ -255,7 +255,9 @@ static int timer_end(EventPair* e, hipStream_t s) {
     return 0;
 }
 
-int Engine::run_gemm(const GemmParams& p, int planes, hipStream_t s) {
+int Engine::run_gemm(const GemmParams& p_in, int planes, hipStream_t s) {
+    GemmParams p = p_in;
+    p.overlapped = overlapped;
     const int cfg = gemm_choose_tile(p, planes);
     GemmParams part[2];
     int cfgs[2] = {cfg, 0}, nparts = 1;

@@ -480,6 +480,10 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
             const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
             if (tiles < cus) {
                 cfg = tiles * 2 >= cus ? 4 : 1;
+            } else if (p.overlapped) {
+                // two batch lanes: the other lane's kernels take the CUs a partly filled last round leaves idle, so the kernel with the
+                // fastest main loop wins regardless of the fill (B/8 batch 32 as 2 x 16: +2 % over the single-lane rule below)
+                cfg = 4;
             } else {
                 const double fill = (double)tiles / (double)(((tiles + cus - 1) / cus) * cus);
                 if (fill >= (p.K >= 1024 ? 0.75 : 0.85)) cfg = 4;

@@ -49,6 +49,7 @@ struct GemmParams {
     unsigned* sk_err;    // set to 1 if a hand-off wait timed out
     unsigned sk_epoch;
     int staged;  // set by launch_gemm: epilogue through LDS with full-line global accesses (gemm.hip)
+    int overlapped;  // set by the engine: the launch runs beside another lane's kernels, so a partly filled last round of workgroups is not lost
     int debug;  // development ablations (cwm_debug_set "gemm_debug"): bit 0 skip the epilogue's global stores, bit 1 skip the epilogue
 };
 

@@ -270,9 +270,11 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
         CWM_HIP_CHECK(hipStreamWaitEvent(m->lane_stream, m->ev_fork, 0));
         n_lanes = 2;
     }
+    m->eng.overlapped = two;
     int rc = forward_lane(m, a, 0, B0, lane_ws(m, 0, 0), s);
     if (two) {
         const int rc1 = rc ? rc : forward_lane(m, a, B0, B - B0, lane_ws(m, 1, B0), m->lane_stream);
+        m->eng.overlapped = 0;
         // join even after a failed launch: the caller's stream must not run ahead of work already queued on the lane
         CWM_HIP_CHECK(hipEventRecord(m->ev_join, m->lane_stream));
         CWM_HIP_CHECK(hipStreamWaitEvent(s, m->ev_join, 0));
