@@ -9,11 +9,11 @@ namespace cwm {
 // ---------------------------------------------------------------------------------------------
 // LayerNorm (eps 1e-6, affine) -> bf16 hi(/lo) planes.  Reference: nn.LayerNorm call sites
 // VideoMAE/utils.py:148-149 (norm1/norm2), vmae.py:172 (encoder.norm), :251 (decoder.norm on the
-// last Nm tokens).  One wave per row, row kept in registers, two-pass mean/variance in fp32.
+// last Nm tokens).  One wave per row, row kept in registers (16-byte loads, 8-byte stores), two-pass mean/variance in fp32.
 // ---------------------------------------------------------------------------------------------
 template <int PLANES>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p) {
-    constexpr int MAXI = 8;  // D <= 1024
+    constexpr int MAXI = 4;  // D <= 1024: lane l owns elements 4 l + 256 i .. + 3 (16-byte loads, 8-byte stores per plane)
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= p.rows) return;
@@ -23,55 +23,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
         in_row = b * p.rows_in_per_b + p.in_offset + (r - b * p.rows_out_per_b);
     }
     const float* x = p.x + (size_t)in_row * p.ldx;
-    float2 v[MAXI];
+    f32x4 v[MAXI];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-        const int idx = lane * 2 + i * 128;
+        const int idx = lane * 4 + i * 256;
         if (idx < p.D) {
-            v[i] = *reinterpret_cast<const float2*>(x + idx);
-            s += v[i].x + v[i].y;
+            v[i] = *reinterpret_cast<const f32x4*>(x + idx);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         } else {
-            v[i] = make_float2(0.f, 0.f);
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     const float mean = wave_sum(s) / (float)p.D;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-        const int idx = lane * 2 + i * 128;
+        const int idx = lane * 4 + i * 256;
         if (idx < p.D) {
-            const float a = v[i].x - mean, c = v[i].y - mean;
-            sq += a * a + c * c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = v[i][e] - mean;
+                sq += a * a;
+            }
         }
     }
     const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-        const int idx = lane * 2 + i * 128;
+        const int idx = lane * 4 + i * 256;
         if (idx < p.D) {
-            bf16* out = p.out + a_pos<PLANES>(r, p.ldo, idx);
-            const float2 g = *reinterpret_cast<const float2*>(p.gamma + idx);
-            const float2 be = *reinterpret_cast<const float2*>(p.beta + idx);
-            const float y0 = (v[i].x - mean) * rstd * g.x + be.x;
-            const float y1 = (v[i].y - mean) * rstd * g.y + be.y;
-            bf16 h0, l0, h1, l1;
-            split_bf16(y0, h0, l0);
-            split_bf16(y1, h1, l1);
-            bf16x2 hv = {h0, h1};
-            *reinterpret_cast<bf16x2*>(out) = hv;
-            if constexpr (PLANES == 2) {
-                bf16x2 lv = {l0, l1};
-                *reinterpret_cast<bf16x2*>(out + kLoOffset) = lv;
+            bf16* out = p.out + a_pos<PLANES>(r, p.ldo, idx);  // 4 consecutive k never straddle a 32-k [hi | lo] block
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + idx);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + idx);
+            f32x4 y;
+            bf16x4 hv, lv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (v[i][e] - mean) * rstd * g[e] + be[e];
+                bf16 h, l;
+                split_bf16(y[e], h, l);
+                hv[e] = h;
+                lv[e] = l;
             }
-            if (p.out_f32) *reinterpret_cast<float2*>(p.out_f32 + (size_t)r * p.D + idx) = make_float2(y0, y1);
+            *reinterpret_cast<bf16x4*>(out) = hv;
+            if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(out + kLoOffset) = lv;
+            if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)r * p.D + idx) = y;
         }
     }
 }
 
 int launch_layernorm(const LayerNormParams& p, int planes, hipStream_t stream) {
-    CWM_REQUIRE(p.D % 2 == 0 && p.D <= 1024, "layernorm: D=%d must be even and <= 1024", p.D);
-    CWM_REQUIRE(p.ldx % 2 == 0 && p.ldo % 2 == 0, "layernorm: row strides must be even");
+    CWM_REQUIRE(p.D % 4 == 0 && p.D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", p.D);
+    CWM_REQUIRE(p.ldx % 4 == 0 && p.ldo % 4 == 0, "layernorm: row strides must be multiples of 4");
     const int blocks = (p.rows + 3) / 4;
     if (planes == 1)
         hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, stream, p);
