@@ -15,11 +15,13 @@ class RectangularizeMasks:
     def __init__(self, truncation_mode="min"):
         assert truncation_mode in ["min", "max", "mean", "full", "none", None], truncation_mode
         self._mode = truncation_mode
+        self.last_num_masked = None
 
     def set_mode(self, mode):
         self._mode = mode
 
     def __call__(self, masks: torch.Tensor) -> torch.Tensor:
+        self.last_num_masked = None
         if self._mode in ["none", None]:
             return masks
         assert isinstance(masks, torch.Tensor), type(masks)
@@ -29,7 +31,11 @@ class RectangularizeMasks:
         masks = masks.flatten(1)
         num_masked = masks.float().sum(-1)
         target = {"min": torch.amin, "max": torch.amax, "mean": torch.mean}[self._mode](num_masked).long()
-        num_changes = (num_masked.long() - target).tolist()  # one host sync for the whole batch
+        vals = torch.cat([num_masked.long() - target, target.reshape(1)]).tolist()  # one host sync for the whole batch
+        num_changes = vals[:-1]
+        # every row now has exactly this many masked tokens: callers that need the count (the predictor's n_vis) read it
+        # here instead of paying a second device round trip
+        self.last_num_masked = int(vals[-1])
         for b, nc in enumerate(num_changes):
             if nc > 0:
                 inds = torch.where(masks[b])[0]

@@ -210,11 +210,20 @@ class PredictorBasedGenerator(nn.Module):
             mask = self.generate_mask(x)
         self.set_image_size(x.shape[-2:])
         self.inp_shape = x.shape
-        mask = mask if (x.size(0) == 1) else self.mask_rectangularizer(mask)
+        n_masked = None
+        if x.size(0) > 1:
+            mask = self.mask_rectangularizer(mask)
+            n_masked = getattr(self.mask_rectangularizer, "last_num_masked", None)
 
         fused = isinstance(self.predictor, PretrainVisionTransformer) and self.t_dim == 2 and not args and not kwargs
         if fused:
-            _, y = self.predictor.predict_video(x, mask, normalize=self.imagenet_normalize_inputs)
+            # the rectangularizer has just made every row hold `n_masked` masked tokens (read back in its one host sync), so the
+            # library needs neither the n_vis round trip nor the device-side row check (which would synchronise again)
+            n_tok = mask[0].numel()
+            if n_masked is not None:
+                _, y = self.predictor.predict_video(x, mask, normalize=self.imagenet_normalize_inputs, n_vis=n_tok - n_masked, check=False)
+            else:
+                _, y = self.predictor.predict_video(x, mask, normalize=self.imagenet_normalize_inputs)
         else:
             y = self.predictor(self._preprocess(x), mask, *args, **kwargs)
             if hasattr(self.predictor, "main_stream"):  # padded conjoined predictor: drop the pad rows (prediction.py:424-428)
