@@ -18,13 +18,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define R16(x) R4(R4(x))
 #define R64(x) R16(R4(x))
 
-enum { T_FMA, T_EXP, T_CVT, T_PKMUL, T_MAX3, T_ADD, T_MFMA32, T_MFMA16, T_MFMA32_FMA7, T_MFMA32_FMA6, T_MFMA32_EXP2FMA4, T_MFMA32_DEP, T_MFMA32_FMA4, T_MFMA32_FMA2, T_LSHL, T_M_EXP1, T_M_EXP2, T_M_EXP4, T_M_CVT6, T_M_PKMUL6, T_M_MAX6, T_M_LSHL6, T_M_ADD6, T_M_PKMUL3, T_M16_EXP2, T_COUNT };
+enum { T_FMA, T_EXP, T_CVT, T_PKMUL, T_MAX3, T_ADD, T_MFMA32, T_MFMA16, T_MFMA32_FMA7, T_MFMA32_FMA6, T_MFMA32_EXP2FMA4, T_MFMA32_DEP, T_MFMA32_FMA4, T_MFMA32_FMA2, T_LSHL, T_M_EXP1, T_M_EXP2, T_M_EXP4, T_M_CVT6, T_M_PKMUL6, T_M_MAX6, T_M_LSHL6, T_M_ADD6, T_M_PKMUL3, T_M16_EXP2, T_MFMA32_RND, T_MFMA16_RND, T_COUNT };
 static const char* kNames[T_COUNT] = {"v_fma_f32 x8 indep",        "v_exp_f32 x8 indep",           "v_cvt_pk_bf16_f32 x8",          "v_pk_mul_f32 x8",
                                       "v_max3_f32 x8",             "v_add_f32 dependent chain x8", "mfma 32x32x16 bf16 x2 indep",   "mfma 16x16x32 bf16 x2 indep",
                                       "mfma32 + 7 fma",            "mfma32 + 6 fma",               "mfma32 + 2 exp + 4 fma",        "mfma 32x32x16 dependent chain",
                                       "mfma32 + 4 fma",            "mfma32 + 2 fma",               "v_lshlrev_b32 x8",
-                                      "mfma32 + 1 exp", "mfma32 + 2 exp", "mfma32 + 4 exp", "mfma32 + 6 cvt_pk_bf16", "mfma32 + 6 pk_mul_f32", "mfma32 + 6 max3", "mfma32 + 6 lshl", "mfma32 + 6 add", "mfma32 + 3 pk_mul_f32", "2 x mfma16x16x32 + 2 exp"};
-static const int kInstrPerIter[T_COUNT] = {8, 8, 8, 8, 8, 8, 2, 2, 8, 7, 7, 1, 5, 3, 8, 2, 3, 5, 7, 7, 7, 7, 7, 4, 4};
+                                      "mfma32 + 1 exp", "mfma32 + 2 exp", "mfma32 + 4 exp", "mfma32 + 6 cvt_pk_bf16", "mfma32 + 6 pk_mul_f32", "mfma32 + 6 max3", "mfma32 + 6 lshl", "mfma32 + 6 add", "mfma32 + 3 pk_mul_f32", "2 x mfma16x16x32 + 2 exp", "mfma 32x32x16, random operands", "mfma 16x16x32, random operands"};
+static const int kInstrPerIter[T_COUNT] = {8, 8, 8, 8, 8, 8, 2, 2, 8, 7, 7, 1, 5, 3, 8, 2, 3, 5, 7, 7, 7, 7, 7, 4, 4, 4, 4};
 
 template <int TEST>
 __global__ __launch_bounds__(512) void bench_kernel(unsigned long long* out, int iters, int active_mask) {
@@ -39,6 +39,20 @@ __global__ __launch_bounds__(512) void bench_kernel(unsigned long long* out, int
     for (int i = 0; i < 8; ++i) {
         va[i] = (__bf16)(0.01f * i);
         vb[i] = (__bf16)(0.02f * i);
+    }
+    // four operand sets of pseudo-random bf16 bit patterns (finite values): consecutive MFMAs see different data, as in a GEMM
+    bf16x8 ra[4], rb[4];
+    {
+        unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                h = h * 1664525u + 1013904223u;
+                ra[k][i] = __builtin_bit_cast(__bf16, (unsigned short)(((h >> 9) & 0xBFFF) | 0x3000u >> ((h >> 30) & 1)));
+                h = h * 1664525u + 1013904223u;
+                rb[k][i] = __builtin_bit_cast(__bf16, (unsigned short)((h >> 11) & 0xBF7F));
+            }
     }
     f32x2 pa[8];
 #pragma unroll
@@ -122,6 +136,13 @@ __global__ __launch_bounds__(512) void bench_kernel(unsigned long long* out, int
             else if constexpr (TEST == T_M_PKMUL6) { asm volatile(R8("v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %3\n v_pk_mul_f32 %3, %3, %4\n v_pk_mul_f32 %4, %4, %5\n v_pk_mul_f32 %5, %5, %6\n") : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]), "+v"(pa[5]), "+v"(pa[6]), "+v"(pa[7]), "+v"(acc0), "+v"(acc1) : "v"(va), "v"(vb)); }
             else if constexpr (TEST == T_M_PKMUL3) { asm volatile(R8("v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %3\n") : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]), "+v"(pa[5]), "+v"(pa[6]), "+v"(pa[7]), "+v"(acc0), "+v"(acc1) : "v"(va), "v"(vb)); }
             else if constexpr (TEST == T_M16_EXP2) { asm volatile(R8("v_mfma_f32_16x16x32_bf16 %2, %4, %5, %2\n v_exp_f32 %0, %0\n v_mfma_f32_16x16x32_bf16 %3, %4, %5, %3\n v_exp_f32 %1, %1\n") : "+v"(a[0]), "+v"(a[1]), "+v"(c0), "+v"(c1) : "v"(va), "v"(vb)); }
+            else if constexpr (TEST == T_MFMA32_RND) {
+                asm volatile(R8("v_mfma_f32_32x32x16_bf16 %0, %2, %6, %0\n v_mfma_f32_32x32x16_bf16 %1, %3, %7, %1\n v_mfma_f32_32x32x16_bf16 %0, %4, %8, %0\n v_mfma_f32_32x32x16_bf16 %1, %5, %9, %1\n")
+                             : "+v"(acc0), "+v"(acc1) : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3]));
+            } else if constexpr (TEST == T_MFMA16_RND) {
+                asm volatile(R8("v_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n v_mfma_f32_16x16x32_bf16 %1, %3, %7, %1\n v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n v_mfma_f32_16x16x32_bf16 %1, %5, %9, %1\n")
+                             : "+v"(c0), "+v"(c1) : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3]));
+            }
         }
         asm volatile("s_nop 0" ::: "memory");
         t1 = __builtin_amdgcn_s_memtime();
@@ -167,6 +188,28 @@ void run_all(unsigned long long* d_out) {
     run<TEST>(d_out, "2 waves/SIMD, 512 WGs", 512, 0xff, 512);
 }
 
+// full-chip MFMA throughput (all SIMDs busy, 2 waves each): which MFMA shape does the chip sustain at a higher clock?
+template <int TEST>
+void chip_throughput(unsigned long long* d_out, const char* label, double macs_per_instr) {
+    const int blocks = 256, threads = 512, iters = 20000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(bench_kernel<TEST>, dim3(blocks), dim3(threads), 0, 0, d_out, iters / 10, 0xff);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(bench_kernel<TEST>, dim3(blocks), dim3(threads), 0, 0, d_out, iters, 0xff);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long tt[16];
+    hipMemcpy(tt, d_out, sizeof(tt), hipMemcpyDeviceToHost);
+    const double instr = (double)blocks * (threads / 64) * iters * 8.0 * kInstrPerIter[TEST];
+    printf("%-30s %s: %.2f ms, %.0f TFLOP/s, shader clock %.2f GHz\n", kNames[TEST], label, ms, instr * macs_per_instr * 2.0 / (ms * 1e-3) / 1e12,
+           (double)((tt[8 + 4] > tt[8] ? tt[8 + 4] : tt[8]) - (tt[4] < tt[0] ? tt[4] : tt[0])) / (ms * 1e-3) / 1e9);
+}
+
 int main() {
     unsigned long long* d_out;
     hipMalloc(&d_out, 16384 * sizeof(unsigned long long));
@@ -185,6 +228,12 @@ int main() {
         hipMemcpy(tt, d_out, 72, hipMemcpyDeviceToHost);
         const unsigned long long t = tt[8] - tt[0];
         printf("s_memtime: %.1f ticks/us (kernel %0.3f ms, %llu ticks)\n", t / (ms * 1e3), ms, t);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        chip_throughput<T_MFMA32>(d_out, "256 CUs x 2 waves/SIMD", 32.0 * 32 * 16);
+        chip_throughput<T_MFMA16>(d_out, "256 CUs x 2 waves/SIMD", 16.0 * 16 * 32);
+        chip_throughput<T_MFMA32_RND>(d_out, "256 CUs x 2 waves/SIMD", 32.0 * 32 * 16);
+        chip_throughput<T_MFMA16_RND>(d_out, "256 CUs x 2 waves/SIMD", 16.0 * 16 * 32);
     }
     run_all<T_FMA>(d_out);
     run_all<T_LSHL>(d_out);
