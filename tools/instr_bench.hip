@@ -18,13 +18,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define R16(x) R4(R4(x))
 #define R64(x) R16(R4(x))
 
-enum { T_FMA, T_EXP, T_CVT, T_PKMUL, T_MAX3, T_ADD, T_MFMA32, T_MFMA16, T_MFMA32_FMA7, T_MFMA32_FMA6, T_MFMA32_EXP2FMA4, T_MFMA32_DEP, T_MFMA32_FMA4, T_MFMA32_FMA2, T_LSHL, T_M_EXP1, T_M_EXP2, T_M_EXP4, T_M_CVT6, T_M_PKMUL6, T_M_MAX6, T_M_LSHL6, T_M_ADD6, T_M_PKMUL3, T_M16_EXP2, T_MFMA32_RND, T_MFMA16_RND, T_COUNT };
+enum { T_FMA, T_EXP, T_CVT, T_PKMUL, T_MAX3, T_ADD, T_MFMA32, T_MFMA16, T_MFMA32_FMA7, T_MFMA32_FMA6, T_MFMA32_EXP2FMA4, T_MFMA32_DEP, T_MFMA32_FMA4, T_MFMA32_FMA2, T_LSHL, T_M_EXP1, T_M_EXP2, T_M_EXP4, T_M_CVT6, T_M_PKMUL6, T_M_MAX6, T_M_LSHL6, T_M_ADD6, T_M_PKMUL3, T_M16_EXP2, T_MFMA32_RND, T_MFMA16_RND, T_MFMA16_RND_B4, T_MFMA16_RND_B2, T_COUNT };
 static const char* kNames[T_COUNT] = {"v_fma_f32 x8 indep",        "v_exp_f32 x8 indep",           "v_cvt_pk_bf16_f32 x8",          "v_pk_mul_f32 x8",
                                       "v_max3_f32 x8",             "v_add_f32 dependent chain x8", "mfma 32x32x16 bf16 x2 indep",   "mfma 16x16x32 bf16 x2 indep",
                                       "mfma32 + 7 fma",            "mfma32 + 6 fma",               "mfma32 + 2 exp + 4 fma",        "mfma 32x32x16 dependent chain",
                                       "mfma32 + 4 fma",            "mfma32 + 2 fma",               "v_lshlrev_b32 x8",
-                                      "mfma32 + 1 exp", "mfma32 + 2 exp", "mfma32 + 4 exp", "mfma32 + 6 cvt_pk_bf16", "mfma32 + 6 pk_mul_f32", "mfma32 + 6 max3", "mfma32 + 6 lshl", "mfma32 + 6 add", "mfma32 + 3 pk_mul_f32", "2 x mfma16x16x32 + 2 exp", "mfma 32x32x16, random operands", "mfma 16x16x32, random operands"};
-static const int kInstrPerIter[T_COUNT] = {8, 8, 8, 8, 8, 8, 2, 2, 8, 7, 7, 1, 5, 3, 8, 2, 3, 5, 7, 7, 7, 7, 7, 4, 4, 4, 4};
+                                      "mfma32 + 1 exp", "mfma32 + 2 exp", "mfma32 + 4 exp", "mfma32 + 6 cvt_pk_bf16", "mfma32 + 6 pk_mul_f32", "mfma32 + 6 max3", "mfma32 + 6 lshl", "mfma32 + 6 add", "mfma32 + 3 pk_mul_f32", "2 x mfma16x16x32 + 2 exp", "mfma 32x32x16, random operands", "mfma 16x16x32, random operands", "mfma 16x16x32, random, B kept for 4", "mfma 16x16x32, random, B kept for 2"};
+static const int kInstrPerIter[T_COUNT] = {8, 8, 8, 8, 8, 8, 2, 2, 8, 7, 7, 1, 5, 3, 8, 2, 3, 5, 7, 7, 7, 7, 7, 4, 4, 4, 4, 4, 4};
 
 template <int TEST>
 __global__ __launch_bounds__(512) void bench_kernel(unsigned long long* out, int iters, int active_mask) {
@@ -143,6 +143,15 @@ __global__ __launch_bounds__(512) void bench_kernel(unsigned long long* out, int
                 asm volatile(R8("v_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n v_mfma_f32_16x16x32_bf16 %1, %3, %7, %1\n v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n v_mfma_f32_16x16x32_bf16 %1, %5, %9, %1\n")
                              : "+v"(c0), "+v"(c1) : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3]));
             }
+            else if constexpr (TEST == T_MFMA16_RND_B4) {
+                asm volatile(R4("v_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n v_mfma_f32_16x16x32_bf16 %1, %3, %6, %1\n v_mfma_f32_16x16x32_bf16 %0, %4, %6, %0\n v_mfma_f32_16x16x32_bf16 %1, %5, %6, %1\n"
+                                "v_mfma_f32_16x16x32_bf16 %0, %2, %7, %0\n v_mfma_f32_16x16x32_bf16 %1, %3, %7, %1\n v_mfma_f32_16x16x32_bf16 %0, %4, %7, %0\n v_mfma_f32_16x16x32_bf16 %1, %5, %7, %1\n")
+                             : "+v"(c0), "+v"(c1) : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3]));
+            } else if constexpr (TEST == T_MFMA16_RND_B2) {
+                asm volatile(R4("v_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n v_mfma_f32_16x16x32_bf16 %1, %3, %6, %1\n v_mfma_f32_16x16x32_bf16 %0, %4, %7, %0\n v_mfma_f32_16x16x32_bf16 %1, %5, %7, %1\n"
+                                "v_mfma_f32_16x16x32_bf16 %0, %2, %8, %0\n v_mfma_f32_16x16x32_bf16 %1, %3, %8, %1\n v_mfma_f32_16x16x32_bf16 %0, %4, %9, %0\n v_mfma_f32_16x16x32_bf16 %1, %5, %9, %1\n")
+                             : "+v"(c0), "+v"(c1) : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3]));
+            }
         }
         asm volatile("s_nop 0" ::: "memory");
         t1 = __builtin_amdgcn_s_memtime();
@@ -234,6 +243,8 @@ int main() {
         chip_throughput<T_MFMA16>(d_out, "256 CUs x 2 waves/SIMD", 16.0 * 16 * 32);
         chip_throughput<T_MFMA32_RND>(d_out, "256 CUs x 2 waves/SIMD", 32.0 * 32 * 16);
         chip_throughput<T_MFMA16_RND>(d_out, "256 CUs x 2 waves/SIMD", 16.0 * 16 * 32);
+        chip_throughput<T_MFMA16_RND_B2>(d_out, "256 CUs x 2 waves/SIMD", 16.0 * 16 * 32);
+        chip_throughput<T_MFMA16_RND_B4>(d_out, "256 CUs x 2 waves/SIMD", 16.0 * 16 * 32);
     }
     run_all<T_FMA>(d_out);
     run_all<T_LSHL>(d_out);
