@@ -158,6 +158,8 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
     float mx = sc[0][0];
     float m_new = 0.f, alpha = 1.f, mc = 0.f, rowsum = 0.f;
     bool grew = false;
+    u32x2 vr0[2][PLANES][2], vr1[2][PLANES][2];  // V^T fragments of phase B, k-steps 0 / 1 requested in the last two slots of phase A
+    bf16x8 ph0, pl0, ph1, pl1;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         const int kb = g & 1, sx = g >> 1;
@@ -208,21 +210,20 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
                 for (int v = 32 * j / NE; v < 32 * (j + 1) / NE; ++v) sc[v >> 4][v & 15] = __builtin_amdgcn_exp2f(fmaf(sc[v >> 4][v & 15], kLog2e, -mc));
                 asm volatile("" : "+v"(rowsum));  // keeps the additions in their slot (they otherwise sink behind the last MFMA)
             }
+            // head start for phase B: the P values of k-step 0 were exponentiated long ago -- split one pair in each of the last four
+            // slots -- and the V^T fragments of k-steps 0 / 1 are requested behind the last K-fragment wait
+            if (slot >= NS - 4) split_pair<PLANES>(sc, 0, slot - (NS - 4), ph0, pl0);
+            if (slot == NS - 2) lds_read_v_step<0, PLANES>(vr0, va0, va1);
+            if (slot == NS - 1) lds_read_v_step<1, PLANES>(vr1, va0, va1);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     PROF_T(1);
     // ---- phase B --------------------------------------------------------------------------------------
-    u32x2 vr0[2][PLANES][2], vr1[2][PLANES][2];
-    lds_read_v_step<0, PLANES>(vr0, va0, va1);
-    lds_read_v_step<1, PLANES>(vr1, va0, va1);
 #pragma unroll
     for (int v = 32 * (NE - 1) / NE; v < 32; ++v) rowsum += sc[v >> 4][v & 15];
     w.l_run = w.l_run * alpha + rowsum;
-    bf16x8 ph0, pl0, ph1, pl1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split_pair<PLANES>(sc, 0, j, ph0, pl0);
     __builtin_amdgcn_sched_barrier(0);
     lds_wait_v_step<NRD, PLANES>(vr0);
     pv_step<PLANES, 0>(w, sc, vr0, ph0, pl0, ph1, pl1);
