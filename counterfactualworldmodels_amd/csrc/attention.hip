@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = max_lane_xor32(mx);
         const float m_new = fmaxf(m_run, mx);
         // the running maximum rarely moves after the first tiles: skip the rescale of O and l (alpha would be exactly 1)
         const bool grew = __any(m_new > m_run);
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void attention8_kernel(const AttnParams p) 
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = max_lane_xor32(mx);
             const float m_new = fmaxf(m_run, mx);
             const bool grew = __any(m_new > m_run);
             const float alpha = grew ? __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e) : 1.0f;

@@ -59,4 +59,11 @@ __device__ __forceinline__ void lds_wait_v_step(u32x2 (&v)[2][PLANES][2]) {
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(v[0][0][0]), "+v"(v[0][0][1]), "+v"(v[1][0][0]), "+v"(v[1][0][1]) : "n"(N) : "memory");
 }
 
+// max over the lane pair (l, l ^ 32) -- the two key halves of a query in the 32x32 accumulator layout -- with one v_permlane32_swap
+// (__shfl_xor would be a ds_bpermute round trip through the LDS queue plus five VALU instructions of index arithmetic)
+__device__ __forceinline__ float max_lane_xor32(float x) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+}
+
 }  // namespace cwm

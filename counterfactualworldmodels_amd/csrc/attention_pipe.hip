@@ -183,7 +183,7 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
 #pragma unroll
                 for (int v = 32 * slot / NMAX; v < 32 * (slot + 1) / NMAX; ++v) mx = fmaxf(mx, sc[v >> 4][v & 15]);
             } else if (slot == NMAX) {
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = max_lane_xor32(mx);
                 m_new = fmaxf(w.m_run, mx);
                 // the running maximum rarely moves after the first tiles: skip the rescale of O and l (alpha would be exactly 1)
                 grew = __any(m_new > w.m_run);
