@@ -40,6 +40,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// The same butterfly without the LDS: DPP inside a row of 16 lanes (xor 1, xor 2, then mirrors of quad- / half-row-uniform values),
+// v_permlane16_swap / v_permlane32_swap across rows (gfx950).  __shfl_xor is a ds_bpermute round trip per step -- six dependent LDS
+// latencies per reduction.  Every lane gets the sum; the order of the additions differs from wave_sum (fp32 rounding).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // XCD-aware bijective remap of a linear workgroup id (guide §5.5 T1): blocks b and b+8 share an
 // XCD under round-robin dispatch, so give every XCD a contiguous chunk of the logical tile order.
 // Speed only; any placement is correct.

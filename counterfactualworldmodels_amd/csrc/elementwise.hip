@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
             v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    const float mean = wave_sum(s) / (float)p.D;
+    const float mean = wave_sum_dpp(s) / (float)p.D;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
             }
         }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+    const float rstd = rsqrtf(wave_sum_dpp(sq) / (float)p.D + p.eps);
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
         const int idx = lane * 4 + i * 256;
