@@ -566,11 +566,11 @@ int launch_attention(const AttnParams& p, int planes, hipStream_t stream) {
     //     each wave overlaps the MFMAs of one tile with the softmax of the previous one; under this load the chip settles at
     //     ~1.55-1.6 GHz (s_memtime vs s_memrealtime, tools/attn_prof.py), where both the matrix pipe and the VALU issue port
     //     are ~70 % busy;
-    //   fast mode: one MFMA per product leaves the loop VALU-bound and the kernels tie (1 ahead on the short encoder
-    //     sequences) -> kernel 1;
+    //   fast mode: one MFMA per product leaves the loop VALU-bound: kernel 1 is 1-5 % ahead on the B/8 sequences (792, 1568 tokens),
+    //     kernel 3 2-4 % ahead on the L/4 ones (3168, 6272) -> by sequence length;
     //   the staggered 8-wave kernel (2) ties kernel 1 in parity mode and loses 25-35 % in fast mode.
     // All three produce bit-identical outputs (tests/test_kernels_gpu.py); cwm_debug_set "attn_kernel" forces one.
-    const int kern = g_attn_kernel ? g_attn_kernel : (planes == 2 ? 3 : 1);
+    const int kern = g_attn_kernel ? g_attn_kernel : ((planes == 2 || p.n_tok >= 2048) ? 3 : 1);
     if (kern == 3) return launch_attention_pipe(p, planes, stream);
     if (kern == 2) {
         const dim3 grid((nqb + 1) / 2, p.batch * p.heads);
