@@ -217,9 +217,10 @@ int cwm_flow_map_finish(float* map_dev, int B, int HW, float scale, int normaliz
 int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters, double* avg_us);
 int cwm_bench_attention(int B, int H, int N, int mode, int iters, double* avg_us);
 /* development switches: "gemm_tile" (0 automatic per shape, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase,
- * 5: persistent stream-K 8-phase), "gemm_staged" (0: direct per-fragment epilogue), "gemm_debug" (epilogue ablations),
- * "attn_kernel" (0 automatic, 1: 4-wave, 2: staggered 8-wave); query "sk_error" (non-zero return = a stream-K hand-off
- * wait timed out) */
+ * 5: persistent stream-K 8-phase, 6: 8-phase rounds + 128x128 remainder rows), "gemm_staged" (0: direct per-fragment epilogue),
+ * "gemm_debug" (epilogue ablations), "attn_kernel" (0 automatic, 1: 4-wave, 2: staggered 8-wave, 3: software-pipelined 4-wave),
+ * "prune_last_block" (0: run the last decoder block over all tokens); queries: "sk_error" (non-zero return = a stream-K hand-off
+ * wait timed out), "attn_prof" / "gemm_prof" (per-workgroup timers of builds with -DCWM_ATTN_PROF / -DCWM_GEMM_PROF) */
 int cwm_debug_set(const char* key, int value);
 
 const char* cwm_last_error(void);
