@@ -24,7 +24,7 @@ namespace cwm {
 
 #ifdef CWM_ATTN_PROF
 __device__ unsigned long long g_pipe_prof[8];
-__device__ unsigned long long g_pipe_blocks[8192 * 4];
+__device__ unsigned long long g_pipe_blocks[8192 * 8];
 #define PROF_T(i) do { if (prof) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - tlast; tlast = t_; } } while (0)
 #else
 #define PROF_T(i) do {} while (0)
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
 
 #ifdef CWM_ATTN_PROF
 #define PROF_ARGS , prof, pacc, tlast
-    const bool prof = blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
+    const bool prof = wave == 0;  // every workgroup's wave 0 keeps phase totals (written to g_pipe_blocks)
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin = tlast, r_begin = __builtin_amdgcn_s_memrealtime();
@@ -397,13 +397,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
     {
         const int bid = blockIdx.y * gridDim.x + blockIdx.x;
         if (wave == 0 && lane == 0 && bid < 8192) {
-            g_pipe_blocks[bid * 4 + 0] = r_begin;
-            g_pipe_blocks[bid * 4 + 1] = r_begin + pacc[5];
-            g_pipe_blocks[bid * 4 + 2] = pacc[4];
-            g_pipe_blocks[bid * 4 + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+            g_pipe_blocks[bid * 8 + 0] = r_begin;
+            g_pipe_blocks[bid * 8 + 1] = r_begin + pacc[5];
+            g_pipe_blocks[bid * 8 + 2] = pacc[4];
+            g_pipe_blocks[bid * 8 + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+            for (int i = 0; i < 4; ++i) g_pipe_blocks[bid * 8 + 4 + i] = pacc[i];
         }
     }
-    if (prof && lane == 0)
+    if (prof && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0)
         for (int i = 0; i < 8; ++i) g_pipe_prof[i] = pacc[i];
 #endif
 
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
 #ifdef CWM_ATTN_PROF
 int attention_pipe_prof(int i) {
     if (i >= 1000) {  // dump the per-block records to /tmp/attn_blocks.bin
-        static unsigned long long h[8192 * 4];
+        static unsigned long long h[8192 * 8];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pipe_blocks), sizeof(h)) != hipSuccess) return -1;
         FILE* f = fopen("/tmp/attn_blocks.bin", "wb");
         if (!f) return -1;

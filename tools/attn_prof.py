@@ -25,7 +25,7 @@ print(sys.argv[1:], "%.1f us; ticks per tile: stage %.0f  phase A %.0f  phase B 
 import numpy as np
 if lib.cwm_debug_set(b"attn_prof", 1000) == 0:
     nblk = B * H * ((N + 127) // 128)
-    r = np.fromfile("/tmp/attn_blocks.bin", dtype=np.uint64).reshape(-1, 4)[:nblk].astype(np.int64)
+    r = np.fromfile("/tmp/attn_blocks.bin", dtype=np.uint64).reshape(-1, 8)[:nblk].astype(np.int64)
     t0 = r[:, 0].min()
     start, end, cyc, hw = (r[:, 0] - t0) / 100.0, (r[:, 1] - t0) / 100.0, r[:, 2], r[:, 3]
     dur = end - start
@@ -38,3 +38,6 @@ if lib.cwm_debug_set(b"attn_prof", 1000) == 0:
     ts = np.linspace(0, end.max(), 13)[1:-1]
     print("  alive blocks at", " ".join("%.0fus:%d" % (t, ((start <= t) & (end > t)).sum()) for t in ts))
     print("  distinct (xcc, se, cu) ids:", len(set((int(h) >> 8) & 0xfffff for h in hw)))
+    ph = r[:, 4:8] / float(nkt)
+    print("  per-workgroup phase cycles per tile (wave 0): median stage/DMA %.0f  phase A %.0f  phase B %.0f  wait+barrier %.0f   (p90: %.0f %.0f %.0f %.0f)" % (
+        *np.median(ph, 0), *np.percentile(ph, 90, 0)))
