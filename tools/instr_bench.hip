@@ -18,13 +18,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define R16(x) R4(R4(x))
 #define R64(x) R16(R4(x))
 
-enum { T_FMA, T_EXP, T_CVT, T_PKMUL, T_MAX3, T_ADD, T_MFMA32, T_MFMA16, T_MFMA32_FMA7, T_MFMA32_FMA6, T_MFMA32_EXP2FMA4, T_MFMA32_DEP, T_MFMA32_FMA4, T_MFMA32_FMA2, T_LSHL, T_M_EXP1, T_M_EXP2, T_M_EXP4, T_M_CVT6, T_M_PKMUL6, T_M_MAX6, T_M_LSHL6, T_M_ADD6, T_M_PKMUL3, T_M16_EXP2, T_MFMA32_RND, T_MFMA16_RND, T_MFMA16_RND_B4, T_MFMA16_RND_B2, T_COUNT };
+enum { T_FMA, T_EXP, T_CVT, T_PKMUL, T_MAX3, T_ADD, T_MFMA32, T_MFMA16, T_MFMA32_FMA7, T_MFMA32_FMA6, T_MFMA32_EXP2FMA4, T_MFMA32_DEP, T_MFMA32_FMA4, T_MFMA32_FMA2, T_LSHL, T_M_EXP1, T_M_EXP2, T_M_EXP4, T_M_CVT6, T_M_PKMUL6, T_M_MAX6, T_M_LSHL6, T_M_ADD6, T_M_PKMUL3, T_M16_EXP2, T_MFMA32_RND, T_MFMA16_RND, T_MFMA16_RND_B4, T_MFMA16_RND_B2, T_M_FMA4_EXP2, T_FMA4_EXP2, T_FMA_EXP_ALT, T_COUNT };
 static const char* kNames[T_COUNT] = {"v_fma_f32 x8 indep",        "v_exp_f32 x8 indep",           "v_cvt_pk_bf16_f32 x8",          "v_pk_mul_f32 x8",
                                       "v_max3_f32 x8",             "v_add_f32 dependent chain x8", "mfma 32x32x16 bf16 x2 indep",   "mfma 16x16x32 bf16 x2 indep",
                                       "mfma32 + 7 fma",            "mfma32 + 6 fma",               "mfma32 + 2 exp + 4 fma",        "mfma 32x32x16 dependent chain",
                                       "mfma32 + 4 fma",            "mfma32 + 2 fma",               "v_lshlrev_b32 x8",
-                                      "mfma32 + 1 exp", "mfma32 + 2 exp", "mfma32 + 4 exp", "mfma32 + 6 cvt_pk_bf16", "mfma32 + 6 pk_mul_f32", "mfma32 + 6 max3", "mfma32 + 6 lshl", "mfma32 + 6 add", "mfma32 + 3 pk_mul_f32", "2 x mfma16x16x32 + 2 exp", "mfma 32x32x16, random operands", "mfma 16x16x32, random operands", "mfma 16x16x32, random, B kept for 4", "mfma 16x16x32, random, B kept for 2"};
-static const int kInstrPerIter[T_COUNT] = {8, 8, 8, 8, 8, 8, 2, 2, 8, 7, 7, 1, 5, 3, 8, 2, 3, 5, 7, 7, 7, 7, 7, 4, 4, 4, 4, 4, 4};
+                                      "mfma32 + 1 exp", "mfma32 + 2 exp", "mfma32 + 4 exp", "mfma32 + 6 cvt_pk_bf16", "mfma32 + 6 pk_mul_f32", "mfma32 + 6 max3", "mfma32 + 6 lshl", "mfma32 + 6 add", "mfma32 + 3 pk_mul_f32", "2 x mfma16x16x32 + 2 exp", "mfma 32x32x16, random operands", "mfma 16x16x32, random operands", "mfma 16x16x32, random, B kept for 4", "mfma 16x16x32, random, B kept for 2", "mfma32 + 4 fma then 2 exp (grouped)", "4 fma then 2 exp (grouped, no mfma)", "fma exp fma exp fma fma (no mfma)"};
+static const int kInstrPerIter[T_COUNT] = {8, 8, 8, 8, 8, 8, 2, 2, 8, 7, 7, 1, 5, 3, 8, 2, 3, 5, 7, 7, 7, 7, 7, 4, 4, 4, 4, 4, 4, 7, 6, 6};
 
 template <int TEST>
 __global__ __launch_bounds__(512) void bench_kernel(unsigned long long* out, int iters, int active_mask) {
@@ -152,6 +152,18 @@ __global__ __launch_bounds__(512) void bench_kernel(unsigned long long* out, int
                                 "v_mfma_f32_16x16x32_bf16 %0, %2, %8, %0\n v_mfma_f32_16x16x32_bf16 %1, %3, %8, %1\n v_mfma_f32_16x16x32_bf16 %0, %4, %9, %0\n v_mfma_f32_16x16x32_bf16 %1, %5, %9, %1\n")
                              : "+v"(c0), "+v"(c1) : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3]));
             }
+            else if constexpr (TEST == T_M_FMA4_EXP2) {
+                asm volatile(R8("v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n"
+                                "v_fma_f32 %0, %0, %0, %1\n v_fma_f32 %2, %2, %2, %3\n v_fma_f32 %4, %4, %4, %5\n v_fma_f32 %5, %5, %5, %6\n v_exp_f32 %1, %1\n v_exp_f32 %3, %3\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(acc0), "+v"(acc1)
+                             : "v"(va), "v"(vb));
+            } else if constexpr (TEST == T_FMA4_EXP2) {
+                asm volatile(R8("v_fma_f32 %0, %0, %0, %1\n v_fma_f32 %2, %2, %2, %3\n v_fma_f32 %4, %4, %4, %5\n v_fma_f32 %5, %5, %5, %6\n v_exp_f32 %1, %1\n v_exp_f32 %3, %3\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+            } else if constexpr (TEST == T_FMA_EXP_ALT) {
+                asm volatile(R8("v_fma_f32 %0, %0, %0, %1\n v_exp_f32 %1, %1\n v_fma_f32 %2, %2, %2, %3\n v_exp_f32 %3, %3\n v_fma_f32 %4, %4, %4, %5\n v_fma_f32 %5, %5, %5, %6\n")
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+            }
         }
         asm volatile("s_nop 0" ::: "memory");
         t1 = __builtin_amdgcn_s_memtime();
@@ -261,6 +273,9 @@ int main() {
     run_all<T_MFMA32_FMA6>(d_out);
     run_all<T_MFMA32_FMA7>(d_out);
     run_all<T_MFMA32_EXP2FMA4>(d_out);
+    run_all<T_M_FMA4_EXP2>(d_out);
+    run_all<T_FMA4_EXP2>(d_out);
+    run_all<T_FMA_EXP_ALT>(d_out);
     run_all<T_M_EXP1>(d_out);
     run_all<T_M_EXP2>(d_out);
     run_all<T_M_EXP4>(d_out);
