@@ -79,6 +79,15 @@ def test_rectangularize_empty_and_ragged():
     out = r(ragged.clone())
     assert out.sum(-1).tolist() == [2, 2, 2]
     assert (out & ~ragged).sum() == 0  # only ever un-masks
+    # the common count is kept for the predictor wrapper (it is the n_vis the library needs, read back in the same host sync)
+    assert r.last_num_masked == 2
+    for mode, want in (("max", 10), ("mean", 6)):
+        rr = masking.RectangularizeMasks(mode)
+        assert rr(ragged.clone()).sum(-1).tolist() == [want] * 3 and rr.last_num_masked == want
+    for mode in ("full", None):
+        rr = masking.RectangularizeMasks(mode)
+        rr(ragged.clone())
+        assert rr.last_num_masked is None  # nothing was counted: the wrapper falls back to asking the library
 
 
 def test_upsample_masks():

@@ -244,3 +244,17 @@ def test_two_lanes_match_one_lane_and_report_mask_errors_of_both():
         m.predict_video(x, bad, n_vis=n_vis)
     y3, _ = m.predict_video(x, mask, n_vis=n_vis)            # the model is usable afterwards
     assert torch.equal(y3, y2)
+    # the reference-shaped entry (pre-processed [B,C,T,H,W] in, tokens out) takes the same two-lane path
+    xp = O.preprocess(x.cpu()).cuda()
+    yf2 = m(xp, mask, n_vis=n_vis)
+    m.set_lanes(1)
+    yf1 = m(xp, mask, n_vis=n_vis)
+    m.set_lanes(2)
+    assert (yf2 - yf1).abs().max().item() <= 5e-5 and (yf2 - y2).abs().max().item() <= 5e-5
+    # work queued behind the call on the caller's stream sees both halves finished (the join is stream-ordered, not a host sync)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ys, _ = m.predict_video(x, mask, n_vis=n_vis, check=False)
+        tail = ys[B - 1].clone()                               # last row = end of the second lane
+    s.synchronize()
+    assert torch.equal(tail, y2[B - 1])
