@@ -277,36 +277,39 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
     }
 
     // ---- LDS-DMA bookkeeping: piece = 8 key rows x 128 B; lane l lands at chunk l % 8 of row l / 8 ----
-    int st_row[NP], st_lds[NP], st_kchunk[NP], st_vchunk[NP];
-    const char *st_kp[NP], *st_vp[NP];  // wave-uniform plane bases: the DMA address is base (SGPR pair) + 32-bit lane offset
+    int st_lds[NP], st_koff[NP], st_voff[NP];  // LDS offset of the piece; byte offset of the lane's 16-byte chunk inside a K / V tile
+    const char *st_kp[NP], *st_vp[NP];         // wave-uniform plane bases: the DMA address is base (SGPR pair) + 32-bit lane offset
 #pragma unroll
     for (int jj = 0; jj < NP; ++jj) {
         const int pi = wave * NP + jj, plane = pi >> 3, pc = pi & 7;
         const int r = pc * 8 + (lane >> 3);
-        st_row[jj] = r;
         st_lds[jj] = plane * TILE_BYTES + pc * 1024;
-        st_kchunk[jj] = ((lane & 7) ^ ((r >> 1) & 7)) * 16;         // K image: chunk c of row r at c ^ ((r >> 1) & 7)
-        st_vchunk[jj] = ((lane & 7) ^ (((r >> 1) & 1) << 2)) * 16;  // V image: lds_off_v
+        st_koff[jj] = r * 128 + ((lane & 7) ^ ((r >> 1) & 7)) * 16;         // K image: chunk c of row r at c ^ ((r >> 1) & 7)
+        st_voff[jj] = r * 128 + ((lane & 7) ^ (((r >> 1) & 1) << 2)) * 16;  // V image: lds_off_v
         st_kp[jj] = reinterpret_cast<const char*>(Kb + (size_t)plane * p.qk_plane);
         st_vp[jj] = reinterpret_cast<const char*>(Vb + (size_t)plane * p.qk_plane);
     }
-    auto stage_k1 = [&](int kt, int jj) {
-        const int key = min(kt * 64 + st_row[jj], N - 1);  // rows past the end re-read the last key (P is exactly 0 there)
-        __builtin_amdgcn_global_load_lds((gbl_void*)(st_kp[jj] + (unsigned)(key * 128 + st_kchunk[jj])),
-                                         (lds_void*)(smem + (kt & 1) * SLOT_BYTES + st_lds[jj]), 16, 0, 0);
+    // CLAMP: the tile may be the last one of a ragged sequence -- rows past the end re-read the last key (P is exactly 0 there).
+    // The steady-state loop stages tiles that cannot be the last one and pays a single v_add per piece.
+    auto tile_off = [&](int kt, int toff, auto clamp_c) -> unsigned {
+        if constexpr (decltype(clamp_c)::value) return (unsigned)(min(kt * 64 + (toff >> 7), N - 1) * 128 + (toff & 127));
+        else return (unsigned)(kt * 8192 + toff);
     };
-    auto stage_v1 = [&](int kt, int jj) {
-        const int key = min(kt * 64 + st_row[jj], N - 1);
-        __builtin_amdgcn_global_load_lds((gbl_void*)(st_vp[jj] + (unsigned)(key * 128 + st_vchunk[jj])),
-                                         (lds_void*)(smem + V_BASE + (kt & 1) * SLOT_BYTES + st_lds[jj]), 16, 0, 0);
+    auto stage_k1 = [&](int kt, int jj, auto clamp_c) {
+        __builtin_amdgcn_global_load_lds((gbl_void*)(st_kp[jj] + tile_off(kt, st_koff[jj], clamp_c)), (lds_void*)(smem + (kt & 1) * SLOT_BYTES + st_lds[jj]), 16, 0,
+                                         0);
+    };
+    auto stage_v1 = [&](int kt, int jj, auto clamp_c) {
+        __builtin_amdgcn_global_load_lds((gbl_void*)(st_vp[jj] + tile_off(kt, st_voff[jj], clamp_c)), (lds_void*)(smem + V_BASE + (kt & 1) * SLOT_BYTES + st_lds[jj]),
+                                         16, 0, 0);
     };
     auto stage_k = [&](int kt) {
 #pragma unroll
-        for (int jj = 0; jj < NP; ++jj) stage_k1(kt, jj);
+        for (int jj = 0; jj < NP; ++jj) stage_k1(kt, jj, std::true_type{});
     };
     auto stage_v = [&](int kt) {
 #pragma unroll
-        for (int jj = 0; jj < NP; ++jj) stage_v1(kt, jj);
+        for (int jj = 0; jj < NP; ++jj) stage_v1(kt, jj, std::true_type{});
     };
 
 #pragma unroll
@@ -336,14 +339,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         __builtin_amdgcn_sched_barrier(0);                 \
     } while (0)
 // tile KT of the wave: S accumulators SC (this tile) -> SN (next tile)
-#define CWM_TILE(HAS_NEXT, SC, SN, KT)                                                                                                 \
+#define CWM_TILE(HAS_NEXT, SC, SN, KT, CLAMP)                                                                                              \
     do {                                                                                                                               \
         const bool more_k = (KT) + 2 < nkt;                                                                                            \
         auto dma = [&](int i) {                                                                                                        \
             if (i < NP) {                                                                                                              \
-                if (more_k) stage_k1((KT) + 2, i);                                                                                     \
+                if (more_k) stage_k1((KT) + 2, i, CLAMP);                                                                                   \
             } else if (HAS_NEXT) {                                                                                                     \
-                stage_v1((KT) + 1, i - NP);                                                                                            \
+                stage_v1((KT) + 1, i - NP, CLAMP);                                                                                        \
             }                                                                                                                          \
         };                                                                                                                             \
         PROF_T(0);                                                                                                                     \
@@ -379,15 +382,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
     __builtin_amdgcn_sched_barrier(0);
 
     int kt = 0;
+    for (; kt + 4 < nkt; kt += 2) {  // tiles staged here (up to K(kt + 3)) are never the last one: no row clamp
+        CWM_TILE(true, sa, sb, kt, std::false_type{});
+        CWM_TILE(true, sb, sa, kt + 1, std::false_type{});
+    }
     for (; kt + 2 < nkt; kt += 2) {
-        CWM_TILE(true, sa, sb, kt);
-        CWM_TILE(true, sb, sa, kt + 1);
+        CWM_TILE(true, sa, sb, kt, std::true_type{});
+        CWM_TILE(true, sb, sa, kt + 1, std::true_type{});
     }
     if (kt + 2 == nkt) {
-        CWM_TILE(true, sa, sb, kt);
-        CWM_TILE(false, sb, sa, kt + 1);
+        CWM_TILE(true, sa, sb, kt, std::true_type{});
+        CWM_TILE(false, sb, sa, kt + 1, std::true_type{});
     } else {
-        CWM_TILE(false, sa, sb, kt);
+        CWM_TILE(false, sa, sb, kt, std::true_type{});
     }
 #undef CWM_TILE
 #undef CWM_TILE_END
