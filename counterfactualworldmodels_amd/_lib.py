@@ -160,6 +160,7 @@ SIGNATURES = {
     "cwm_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
     "cwm_last_error": (C.c_char_p, []),
     "cwm_version": (C.c_char_p, []),
+    "cwm_source_hash": (C.c_char_p, []),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -193,13 +194,36 @@ def get_lib() -> C.CDLL:
                     "libcwm_hip.so is missing at %s and could not be built (%s). "
                     "Run `python -m counterfactualworldmodels_amd.build`." % (path, e)
                 )
-        lib = C.CDLL(path)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
-            fn.restype = res
-            fn.argtypes = args
+        lib = _bind(path)
+        if path == _build.LIB_PATH and os.path.isdir(_build.CSRC):
+            # a stale in-tree library (sources changed after it was built) is rebuilt, never silently bound
+            want = _build.source_hash()
+            if lib.cwm_source_hash().decode() != want:
+                try:
+                    _build.build_library(force=False)
+                except Exception as e:
+                    raise RuntimeError("libcwm_hip.so at %s was built from other sources (%s != %s) and could not be rebuilt: %s"
+                                       % (path, lib.cwm_source_hash().decode(), want, e))
+                lib = _bind(path)  # os.replace gave the file a new inode: this maps the new library
+                if lib.cwm_source_hash().decode() != want:
+                    raise RuntimeError("libcwm_hip.so still does not match the sources after a rebuild")
         _lib = lib
         return lib
+
+
+def _bind(path: str) -> C.CDLL:
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)  # a missing symbol fails loudly
+        except AttributeError:
+            if name == "cwm_source_hash":  # a library from before the hash existed: report it as stale
+                lib.cwm_source_hash = lambda: b"pre-hash"
+                continue
+            raise
+        fn.restype = res
+        fn.argtypes = args
+    return lib
 
 
 def check(rc: int) -> None:

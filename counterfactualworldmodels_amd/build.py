@@ -21,38 +21,91 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or add /opt/rocm/bin to PATH)")
 
 
+def source_hash() -> str:
+    """sha1 over every source and header of the library (what `cwm_source_hash()` of a current build returns)."""
+    import hashlib
+
+    h = hashlib.sha1()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _stamp_hash() -> str:
+    try:
+        with open(os.path.join(PKG_DIR, "build", "prod", "source_hash.txt")) as fh:
+            return fh.read().strip()
+    except OSError:
+        return ""
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in deps) or _stamp_hash() != source_hash()
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def _compile_one(args):
+    cmd, obj = args
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    return obj, res.returncode, res.stdout + res.stderr
+
+
+def build_library(force: bool = False, verbose: bool = False, out_path: str = None) -> str:
+    """Compile every source to an object (in parallel, only those older than a dependency) and link.  `out_path` (or the
+    CWM_HIP_LIB_OUT environment variable) builds a side library -- e.g. a -DCWM_ATTN_PROF profiling build -- without replacing
+    the production one."""
+    out_path = out_path or os.environ.get("CWM_HIP_LIB_OUT") or LIB_PATH
+    extra = os.environ.get("CWM_HIPCC_EXTRA", "").split()  # e.g. -DCWM_ATTN_PROF (phase timers in attention_pipe.hip)
+    if extra and out_path == LIB_PATH:
+        raise RuntimeError("CWM_HIPCC_EXTRA builds must not overwrite the production library: set CWM_HIP_LIB_OUT (and load it with CWM_HIP_LIB)")
+    if not force and out_path == LIB_PATH and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [
-        _hipcc(),
-        "--offload-arch=gfx950",
-        "-O3",
-        "-std=c++17",
-        "-fPIC",
-        "-shared",
-        "-Wall",
-        "-Wno-unused-function",
-    ]
-    cmd += os.environ.get("CWM_HIPCC_EXTRA", "").split()  # e.g. -DCWM_ATTN_PROF (phase timers in attention_pipe.hip)
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH + ".tmp"]
+    tag = "prod" if out_path == LIB_PATH else "side_%08x" % (hash(tuple(extra)) & 0xFFFFFFFF)
+    obj_dir = os.path.join(PKG_DIR, "build", tag)
+    os.makedirs(obj_dir, exist_ok=True)
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + extra
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    jobs, objs = [], []
+    stamp = os.path.join(obj_dir, "source_hash.txt")
+    shash = source_hash()
+    try:
+        with open(stamp) as fh:
+            stale_hash = fh.read().strip() != shash
+    except OSError:
+        stale_hash = True
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(obj_dir, s + ".o")
+        objs.append(obj)
+        if s == "engine.hip":  # carries the hash of ALL sources (cwm_source_hash): recompiled whenever anything changed
+            if force or stale_hash or not os.path.exists(obj):
+                jobs.append((base + ['-DCWM_SRC_HASH="%s"' % shash, "-c", src, "-o", obj], obj))
+            continue
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(src)):
+            jobs.append((base + ["-c", src, "-o", obj], obj))
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    res = subprocess.run(cmd, capture_output=True, text=True)
+        print("compiling %d of %d sources" % (len(jobs), len(SOURCES)), file=sys.stderr)
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1))) as ex:
+            for obj, rc, log in ex.map(_compile_one, jobs):
+                if rc != 0:
+                    raise RuntimeError("hipcc failed on %s:\n%s" % (obj, log))
+                if verbose and log.strip():
+                    print(log, file=sys.stderr)
+    res = subprocess.run(base + ["-shared"] + objs + ["-o", out_path + ".tmp"], capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
+    os.replace(out_path + ".tmp", out_path)
+    with open(stamp, "w") as fh:
+        fh.write(shash)
+    return out_path
 
 
 if __name__ == "__main__":

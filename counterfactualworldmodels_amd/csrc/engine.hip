@@ -18,7 +18,11 @@ void cwm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cwm_last_error(void) { return g_err; }
-extern "C" const char* cwm_version(void) { return "cwm_hip 0.2.0 gfx950"; }
+extern "C" const char* cwm_version(void) { return "cwm_hip 0.3.0 gfx950"; }
+#ifndef CWM_SRC_HASH
+#define CWM_SRC_HASH "unknown"
+#endif
+extern "C" const char* cwm_source_hash(void) { return CWM_SRC_HASH; }
 
 namespace cwm {
 

@@ -226,6 +226,9 @@ int cwm_debug_set(const char* key, int value);
 const char* cwm_last_error(void);
 /* "cwm_hip <version> gfx950" */
 const char* cwm_version(void);
+/* Hash of the sources this library was built from (counterfactualworldmodels_amd/build.py: source_hash); the Python
+ * binding compares it at load time so that a stale in-tree .so is rebuilt instead of silently bound. */
+const char* cwm_source_hash(void);
 
 #ifdef __cplusplus
 }

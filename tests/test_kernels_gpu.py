@@ -124,6 +124,14 @@ def test_attention_golden_block(gu):
     o = gu.attention(qkv, 12)
     a = gu.linear(o.reshape(-1, D), W["attn.proj.weight"], W["attn.proj.bias"]).reshape(B, N, D)
     assert (a - torch.from_numpy(g["attn"])).abs().max().item() <= 2e-4
+    # second half of Block.forward (VideoMAE/utils.py:150-152): x1 = x + attn; mlp = fc2(gelu(fc1(LN2 x1))); y = x1 + mlp
+    x1 = gu.linear(o.reshape(-1, D), W["attn.proj.weight"], W["attn.proj.bias"], resid=x.reshape(-1, D))
+    h2 = gu.layernorm(x1, W["norm2.weight"], W["norm2.bias"])
+    f1 = gu.linear(h2, W["mlp.fc1.weight"], W["mlp.fc1.bias"], gelu=True)
+    mlp = gu.linear(f1, W["mlp.fc2.weight"], W["mlp.fc2.bias"]).reshape(B, N, D)
+    assert (mlp - torch.from_numpy(g["mlp"])).abs().max().item() <= 2e-4
+    y = gu.linear(f1, W["mlp.fc2.weight"], W["mlp.fc2.bias"], resid=x1).reshape(B, N, D)
+    assert (y - torch.from_numpy(g["y"])).abs().max().item() <= 2e-4
 
 
 @pytest.mark.parametrize("D", [128, 192, 384, 512, 768, 1024])
