@@ -4,9 +4,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one batch of synthetic frame pairs already resident in HBM:
-raw [B,2,3,224,224] frames + masks -> normalise, tubelet patch embed + mask gather, ViT encoder over
-visible tokens, ViT decoder over the full token set, pixel head, patch un-embed -> predicted frames.
+A step = one call of the wrapper's `predict` (reference: prediction.py:406-454) on one batch of synthetic frame pairs
+already resident in HBM: raw [B,2,3,224,224] frames + masks -> mask rectangulariser (host read-back of the row counts, as
+the reference does for every B > 1), normalise, tubelet patch embed + mask gather, ViT encoder over visible tokens, ViT
+decoder over the full token set, pixel head, patch un-embed -> predicted frames.
 N=1 workload = BASELINE.json configs[1]: ViT-B/8, batch 32.  With N>1 every rank runs the same
 per-GPU batch on its own shard of frame pairs (independent units, no data-path collective): weak
 scaling, value = all ranks' frame pairs / max-over-ranks time.
@@ -40,13 +41,15 @@ WORKLOADS = {
 }
 
 
-def timed_steps(model, x, mask, n_vis, steps, distributed):
+def timed_steps(G, x, mask, n_vis, steps, distributed):
+    """K steps of the reference's `predict` (prediction.py:406-454) on the wrapper `G`: mask rectangulariser (its one host
+    read-back per call included), normalise, forward, un-embed; all frames returned."""
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        model.predict_video(x, mask, normalize=True, n_vis=n_vis, check=False)
+        G.predict(x, mask, frame=None)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -100,45 +103,38 @@ def cpu_baseline(cfg, k_vis, clump, seed, budget_s=20.0):
     }
 
 
-def run_prompts(args, rank, local_rank, world, distributed):
-    """Strong-scaling variant: total work fixed at 256 prompts; value = prompts / max-over-ranks time."""
-    from counterfactualworldmodels_amd import dist as cdist, prediction
+def prompts_measure(args, rank, local_rank, world, distributed, model=None, steps=None, warmup=None):
+    """BASELINE configs[3], strong scaling: 256 prompts on ONE frame pair, sharded over the ranks (dist.py: one packed RCCL
+    broadcast, per-rank prompt construction + 32-row predictor calls with no host sync in between, one all-gather).
+    value = prompts / max-over-ranks time.  Returns the result dict (rank 0 prints it or embeds it)."""
+    from counterfactualworldmodels_amd import dist as cdist, segmentation
 
     cfg = C.CONFIGS[PROMPTS["cfg"]]
     dev = torch.device("cuda", local_rank)
-    model = vmae.PretrainVisionTransformer(cfg, mode=args.mode)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, 0).items()})
-    G = prediction.PredictorBasedGenerator(predictor=model.to(dev).eval(), imagenet_normalize_inputs=True, temporal_dim=2)
-    n = cfg.tokens_per_frame
-    gw = cfg.img_size[1] // cfg.patch
+    steps = steps or args.steps
+    warmup = max(warmup if warmup is not None else args.warmup, 1)
+    if model is None:
+        model = vmae.PretrainVisionTransformer(cfg, mode=args.mode)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, 0).items()})
+        model = model.to(dev).eval()
+    G = segmentation.FlowGenerator(predictor=model, imagenet_normalize_inputs=True, temporal_dim=2)
     x0 = torch.from_numpy(S.synthetic_frames(1, cfg, 0))[:, 0:1] if rank == 0 else None  # one image; frame 2 := frame 1
     table = torch.from_numpy(S.synthetic_prompts(PROMPTS["total"], cfg, 0)) if rank == 0 else None
-
-    def build(xb, pr):  # prompt rows (active_h, active_w, dy, dx) -> shifted frame pairs + masks, on device
-        b = pr.shape[0]
-        active = torch.ones(1, 2 * n, b, dtype=torch.bool, device=dev)
-        active[:, :n] = False
-        idx = (pr[:, 0].long() * gw + pr[:, 1].long()) + n
-        active[0, idx, torch.arange(b, device=dev)] = False
-        passive = torch.ones(1, 2 * n, b, dtype=torch.bool, device=dev)
-        passive[:, :n] = False
-        return G.create_motion_counterfactuals(xb, masks=passive, active_patches=active, shifts=pr[:, 2:4].tolist(), reset_shifts=True)
-
-    def predict(xs, ms):
-        return G.predict(xs, ms, frame=-1)
+    hooks = cdist.prompt_hooks(G, frame=-1)
+    comm = cdist.get_comm(dev)   # N > 1: RCCL through the C ABI (cwm_comm_init); the torch group only hands the id around
+    shapes = ((1, 1, cfg.in_chans) + tuple(cfg.img_size), (PROMPTS["total"], 4), cfg.num_tokens)
 
     def step():
-        return cdist.sharded_counterfactual_predictions(x0, table, build, predict, dev, chunk=PROMPTS["chunk"], gather=True)
+        return cdist.sharded_counterfactual_predictions(x0, table, *hooks, dev, chunk=PROMPTS["chunk"], gather=True, comm=comm, shapes=shapes)
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(warmup):
         y = step()
     assert y.shape[0] == PROMPTS["total"]
-    model.set_lanes(args.lanes)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     if distributed:
@@ -149,13 +145,18 @@ def run_prompts(args, rank, local_rank, world, distributed):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_gpus = world if distributed else 1
-    out = {
-        "metric": "predicted frames/sec (2x224x224, ViT-B/8)", "value": PROMPTS["total"] * args.steps / dt, "unit": "frames/s",
-        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+    return {
+        "metric": "predicted frames/sec (2x224x224, ViT-B/8)", "value": PROMPTS["total"] * steps / dt, "unit": "frames/s",
+        "n_gpus": n_gpus, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": PROMPTS["name"], "predictor": cfg.name, "prompts": PROMPTS["total"], "chunk": PROMPTS["chunk"],
-                   "mode": args.mode, "lanes": args.lanes, "parallelism": "prompts sharded over %d rank(s): broadcast(frame, prompt table) + all_gather(predicted frames)" % n_gpus},
+                   "mode": args.mode, "lanes": args.lanes, "collectives": type(comm).__name__,
+                   "parallelism": "prompts sharded over %d rank(s): one packed broadcast(frame, prompt table, masks) + one all_gather(predicted frames)" % n_gpus},
     }
+
+
+def run_prompts(args, rank, local_rank, world, distributed):
+    out = prompts_measure(args, rank, local_rank, world, distributed)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -228,6 +229,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra fast-mode measurement")
+    ap.add_argument("--no-prompts", action="store_true", help="skip the 256-prompt strong-scaling measurement beside the headline")
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
                     help="2 (library default): the batch runs as two half batches on two HIP streams; 1: one stream")
     args = ap.parse_args()
@@ -259,14 +261,18 @@ def main():
     x = torch.from_numpy(S.synthetic_frames(B, cfg, rank)).to(dev)
     mask = torch.from_numpy(S.synthetic_masks(B, cfg, wl["k_vis"], rank, wl["clump"])).to(dev)
 
+    from counterfactualworldmodels_amd import segmentation
+
+    G = segmentation.FlowGenerator(predictor=model, imagenet_normalize_inputs=True, temporal_dim=2)
     model.sync_weights()
     model.set_lanes(args.lanes)
+    model.predict_video(x, mask, normalize=True, n_vis=n_vis, check=True)  # validates the synthetic masks once (device-side row check)
     for _ in range(max(args.warmup, 1)):
-        model.predict_video(x, mask, normalize=True, n_vis=n_vis, check=True)
+        G.predict(x, mask, frame=None)
     torch.cuda.synchronize()
 
     # ---- timed region: `value` -------------------------------------------------------------------------------------------------
-    dt = timed_steps(model, x, mask, n_vis, args.steps, distributed)
+    dt = timed_steps(G, x, mask, n_vis, args.steps, distributed)
 
     # ---- kernel region: the same K steps on ONE lane with a HIP event pair around every GEMM launch -> `roofline`.  With two lanes a
     # launch shares the chip with whatever the other lane runs, so its duration says nothing about the kernel; here launches are alone.
@@ -274,9 +280,9 @@ def main():
     model.set_lanes(1)
     if args.lanes != 1:
         for _ in range(2):
-            model.predict_video(x, mask, normalize=True, n_vis=n_vis, check=False)
+            G.predict(x, mask, frame=None)
     model.timing_enable(_lib.KCLASS_GEMM, True)
-    dt_one = timed_steps(model, x, mask, n_vis, args.steps, distributed)
+    dt_one = timed_steps(G, x, mask, n_vis, args.steps, distributed)
     gemm = model.timing_collect(_lib.KCLASS_GEMM)                 # every GEMM launch ...
     gemm_wide = model.timing_collect(_lib.KCLASS_GEMM_WIDE)       # ... split by the kernel that ran it
     gemm_narrow = model.timing_collect(_lib.KCLASS_GEMM_NARROW)
@@ -333,13 +339,24 @@ def main():
         other = "fast" if args.mode == "parity" else "parity"
         model.mode = other
         for _ in range(2):
-            model.predict_video(x, mask, normalize=True, n_vis=n_vis, check=False)
-        dt2 = timed_steps(model, x, mask, n_vis, args.steps, distributed)
+            G.predict(x, mask, frame=None)
+        dt2 = timed_steps(G, x, mask, n_vis, args.steps, distributed)
         out["secondary"] = {"mode": other, "value": B * n_gpus * args.steps / dt2, "unit": "frames/s",
                             "ms_per_step": 1e3 * dt2 / args.steps,
                             "note": "plain-bf16 fast mode does NOT meet the 1e-3 parity tolerance (see tests/test_model_gpu.py)"
                             if other == "fast" else "split-bf16 parity mode"}
         model.mode = args.mode
+
+    # ---- BASELINE configs[3] beside the headline, at every N: the >= 6x target of the north star is quoted on this STRONG-scaling
+    # batch (256 prompts in total), while `value` above is the weak-scaling frame-pair throughput.  Measurement plumbing only: a
+    # failure here is reported in the line, it does not take the headline down.
+    if args.workload == "base8" and not args.no_prompts:
+        try:
+            pm = prompts_measure(args, rank, local_rank, world, distributed, model=model, steps=max(3, args.steps // 4), warmup=2)
+            out["prompts256"] = {k: pm[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "steps")}
+            out["prompts256"]["config"] = pm["config"]
+        except Exception as e:  # noqa: BLE001
+            out["prompts256"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, wl["k_vis"], wl["clump"], 0)

@@ -155,6 +155,17 @@ SIGNATURES = {
     "cwm_flow_cov": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 4),
     "cwm_flow_motion_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)] + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cwm_flow_map_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_void_p]),
+    "cwm_comm_load": (C.c_int, [C.c_char_p]),
+    "cwm_comm_version": (C.c_int, []),
+    "cwm_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "cwm_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cwm_comm_destroy": (None, [C.c_void_p]),
+    "cwm_comm_rank": (C.c_int, [C.c_void_p]),
+    "cwm_comm_size": (C.c_int, [C.c_void_p]),
+    "cwm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "cwm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cwm_allgatherv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p]),
+    "cwm_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cwm_bench_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cwm_bench_attention": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cwm_debug_set": (C.c_int, [C.c_char_p, C.c_int]),

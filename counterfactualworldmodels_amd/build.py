@@ -10,7 +10,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcwm_hip.so")
-SOURCES = ["gemm.hip", "gemm_sk.hip", "attention.hip", "attention_pipe.hip", "elementwise.hip", "conj_kernels.hip", "flowstats.hip", "engine.hip", "model.hip", "conj_model.hip"]
+SOURCES = ["gemm.hip", "gemm_sk.hip", "attention.hip", "attention_pipe.hip", "elementwise.hip", "conj_kernels.hip", "flowstats.hip", "engine.hip", "model.hip", "conj_model.hip", "comm.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_device.h", "attention_device.h", "engine.h", os.path.join("..", "..", "include", "cwm_hip.h")]
 
 
@@ -99,7 +99,7 @@ def build_library(force: bool = False, verbose: bool = False, out_path: str = No
                     raise RuntimeError("hipcc failed on %s:\n%s" % (obj, log))
                 if verbose and log.strip():
                     print(log, file=sys.stderr)
-    res = subprocess.run(base + ["-shared"] + objs + ["-o", out_path + ".tmp"], capture_output=True, text=True)
+    res = subprocess.run(base + ["-shared"] + objs + ["-ldl", "-o", out_path + ".tmp"], capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(out_path + ".tmp", out_path)

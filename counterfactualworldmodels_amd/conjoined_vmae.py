@@ -175,10 +175,13 @@ class ConjoinedPaddedVisionTransformer(nn.Module):
         except Exception:
             pass
 
-    def sync_weights(self, device: Optional[torch.device] = None) -> int:
+    def sync_weights(self, device: Optional[torch.device] = None, force: bool = False) -> int:
+        """See `vmae.PretrainVisionTransformer.sync_weights` (in-place `.data` edits need force=True)."""
         device = device or next(self.parameters()).device
         h = self._ensure_handle(device)
         lib = _lib.get_lib()
+        if force:
+            self._loaded = {}
         n = 0
         with torch.cuda.device(device):
             for name, p in self.state_dict(keep_vars=True).items():
@@ -197,7 +200,10 @@ class ConjoinedPaddedVisionTransformer(nn.Module):
     # ---- reference forward: conjoined_vmae.py:852-887 ----------------------------------------------
     @torch.no_grad()
     def forward(self, x, mask, timestamps=None, x_context=None, mask_context=None, output_main=None, output_context=None,
-                *args, normalize: bool = False, check: bool = True, **kwargs):
+                *args, normalize: bool = False, check: bool = True, n_vis: Optional[int] = None, n_vis_context: Optional[int] = None,
+                **kwargs):
+        """`n_vis` / `n_vis_context`: the caller knows that every row of `mask` / `mask_context` has exactly this many visible
+        tokens (a rectangularised batch; `mask_context=None` means all visible): skips the host read-back of the row counts."""
         _lib.require_gpu()
         if output_context or (output_main is False):
             raise NotImplementedError("only the main-stream output (the configuration the demos use) is implemented")
@@ -218,12 +224,19 @@ class ConjoinedPaddedVisionTransformer(nn.Module):
         if mask.shape[1] != Nt:
             raise RuntimeError("mask has %d tokens per row, model expects %d" % (mask.shape[1], Nt))
         ctx = x_context.to(device=dev, dtype=torch.float32).reshape(B, c.ctx_in_chans, c.ctx_seq_len).contiguous()
+        mask_context_given = mask_context is not None
         if mask_context is None:
             mask_context = torch.zeros(B, c.ctx_tokens, dtype=torch.bool, device=dev)
         mc = mask_context.to(device=dev, dtype=torch.bool).reshape(B, c.ctx_tokens).contiguous()
         vis = (~mask).sum(-1)
-        vis_c = (~mc).sum(-1)
-        vmax, vmin, vcmax, vcmin = int(vis.max()), int(vis.min()), int(vis_c.max()), int(vis_c.min())
+        if not mask_context_given:
+            n_vis_context = c.ctx_tokens
+        if n_vis is not None and n_vis_context is not None:
+            vmax = vmin = int(n_vis)
+            vcmax = vcmin = int(n_vis_context)
+        else:
+            vis_c = (~mc).sum(-1)
+            vmax, vmin, vcmax, vcmin = (int(v) for v in torch.stack([vis.max(), vis.min(), vis_c.max(), vis_c.min()]).tolist())
         if vmax - vmin > c.main_max_pad or vcmax - vcmin > c.ctx_max_pad:
             raise RuntimeError("visible-token counts differ by more than max_padding_tokens (%d / %d)" % (c.main_max_pad, c.ctx_max_pad))
         if vmax < 1 or vcmax < 1:
@@ -235,12 +248,18 @@ class ConjoinedPaddedVisionTransformer(nn.Module):
             vcmax, y.data_ptr(), _lib.mode_id(self.mode), int(check), _lib.current_stream_handle(dev))
         with torch.cuda.device(dev):
             _lib.check(_lib.get_lib().cwm_conj_forward(self._handle, C.byref(args_)))
-        # the reference leaves its padding state set until the wrapper resets it (prediction.py:451-452)
-        pad = torch.arange(c.main_max_pad, device=dev)[None] >= (vmax - vis)[:, None]
+        self._record_padding_state(mask, vis, vmax)
+        return y
+
+    def _record_padding_state(self, mask, vis, vmax):
+        """The padding attributes the reference leaves set after a forward until the wrapper resets them (prediction.py:451-452;
+        conjoined_vmae.py:49-116): `padding_mask` (pad slot j of row b is masked unless j < vmax - visible(b)), `full_input_mask`,
+        `null_mask`."""
+        c, B, Nt = self.cfg, mask.shape[0], mask.shape[1]
+        pad = torch.arange(c.main_max_pad, device=mask.device)[None] >= (vmax - vis)[:, None]
         self.main_stream.padding_mask = pad
         self.main_stream.full_input_mask = torch.cat([mask, pad], -1)
-        self.main_stream.null_mask = torch.cat([torch.zeros(B, Nt - vmax, dtype=torch.bool, device=dev), pad], -1)
-        return y
+        self.main_stream.null_mask = torch.cat([torch.zeros(B, Nt - vmax, dtype=torch.bool, device=mask.device), pad], -1)
 
     def set_lanes(self, lanes: int):
         """See `vmae.PretrainVisionTransformer.set_lanes`."""

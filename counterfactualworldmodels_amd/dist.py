@@ -1,24 +1,32 @@
 """Multi-GPU sharding of the batched counterfactual-sampling loop (BASELINE configs[3]).
 
-The S counterfactual prompts over one frame pair are independent forwards (the reference merely
-chunks them: `prediction.py:513-540`, `segmentation.py:423-430`), so they shard across ranks with
-no collective inside the path: one process per GPU, weights replicated.  Around the path there are
-exactly two collectives on `torch.distributed` (backend "nccl" = RCCL over xGMI on GPUs; "gloo" in
-the CPU tests):
+The S counterfactual prompts over one frame pair are independent forwards (the reference merely chunks them on one device:
+`prediction.py:513-540`, `segmentation.py:423-430`), so they shard across ranks with no collective inside the path: one
+process per GPU, weights replicated.  Around the path there are exactly two collectives:
 
-  1. broadcast from rank 0: the frame pair and the prompt table (a few KB)
-  2. all-gather of the per-rank predictions
+  1. ONE broadcast from rank 0 of a packed byte buffer {header | frame pair | prompt table | rectangularised masks}
+     (1.2 MB + 4 KB + S*Nt bytes).  The masks travel because `RectangularizeMasks` is the only cross-row operation before the
+     path: rank 0 applies it once to all S rows -- the same rows, the same torch-RNG draws as the single-process call
+     (segmentation.py:342) -- so sharding cannot change which patches are un-masked.
+  2. ONE all-gather of the per-rank prediction blocks straight into the pre-sized result (blocks may differ by a row:
+     grouped per-root broadcasts, no padding copies).
 
-`predict_fn(x[b,T,C,H,W], mask[b,Nt]) -> y[b,...]` is the HIP predictor in production
-(`PredictorBasedGenerator.predict`); the tests pass a CPU stand-in so the sharding logic is covered
-without a GPU.
+On GPUs the collectives are RCCL called directly through the C ABI (`cwm_comm_*`, `cwm_broadcast`, `cwm_allgatherv` in
+include/cwm_hip.h; `RcclComm`); the launcher's `torch.distributed` group is used only to hand the 128-byte RCCL id to the
+other ranks.  `TorchComm` runs the same logic on any torch.distributed backend -- it is what the world_size > 1 CPU tests
+use (gloo).  Per-rank fixed cost at 8 ranks: prompt build + one host read-back on rank 0, the broadcast, one
+4-byte header read on the other ranks, the gather; the predictor calls in between queue without host synchronisation.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+import ctypes as C
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+_HEADER_WORDS = 16
+_MAGIC = 0x43574D31  # "CWM1"
 
 
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -28,102 +36,280 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _world() -> Tuple[int, int]:
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+# ---- communicators --------------------------------------------------------------------------------------------------------
+class LocalComm:
+    """World of one: every collective is the identity."""
+
+    rank, world = 0, 1
+
+    def broadcast_bytes(self, buf: torch.Tensor, src: int = 0) -> None:
+        pass
+
+    def all_gather_blocks(self, local: torch.Tensor, out: torch.Tensor, counts: Sequence[int]) -> torch.Tensor:
+        out.copy_(local)
+        return out
+
+    def all_reduce_sum(self, t: torch.Tensor) -> None:
+        pass
 
 
-def broadcast_inputs(x: Optional[torch.Tensor], prompts: Optional[torch.Tensor], device, src: int = 0):
-    """Rank `src` holds the frame pair x[1,T,C,H,W] (float32) and the prompt table [S,K] (int32);
-    every rank returns its own copies.  Shapes are sent first so non-src ranks need no metadata."""
-    rank, world = _world()
-    if world == 1:
-        return x.to(device), prompts.to(device)
-    meta = torch.zeros(8, dtype=torch.int64, device=device)
-    if rank == src:
-        meta[:5] = torch.tensor(x.shape, dtype=torch.int64)
-        meta[5:7] = torch.tensor(prompts.shape, dtype=torch.int64)
-    dist.broadcast(meta, src=src)
-    xs, ps = [int(v) for v in meta[:5]], [int(v) for v in meta[5:7]]
-    xb = x.to(device=device, dtype=torch.float32).contiguous() if rank == src else torch.empty(xs, dtype=torch.float32, device=device)
-    pb = prompts.to(device=device, dtype=torch.int32).contiguous() if rank == src else torch.empty(ps, dtype=torch.int32, device=device)
-    dist.broadcast(xb, src=src)
-    dist.broadcast(pb, src=src)
-    return xb, pb
+class TorchComm(LocalComm):
+    """The same three collectives on a torch.distributed process group (gloo in the CPU tests)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def broadcast_bytes(self, buf, src=0):
+        dist.broadcast(buf, src=src, group=self.group)
+
+    def all_gather_blocks(self, local, out, counts):
+        """`out` [sum(counts), ...] receives rank r's `counts[r]` rows at their offset."""
+        if len(set(counts)) == 1:
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+            return out
+        width = max(counts)  # ragged: equal-sized padded blocks through the collective, trimmed into place
+        pad = local.new_zeros((width,) + tuple(local.shape[1:]))
+        pad[: local.shape[0]] = local
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=self.group)
+        lo = 0
+        for r, n in enumerate(counts):
+            out[lo : lo + n] = parts[r][:n]
+            lo += n
+        return out
+
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, group=self.group)
 
 
-def all_gather_rows(y_local: torch.Tensor, total_rows: int) -> torch.Tensor:
-    """Concatenate per-rank row blocks (rank order = prompt order).  Rank slices may differ by one
-    row, so blocks are padded to the largest slice for the collective and trimmed afterwards."""
-    rank, world = _world()
-    if world == 1:
-        return y_local
-    max_rows = (total_rows + world - 1) // world
-    pad = torch.zeros((max_rows,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
-    pad[: y_local.shape[0]] = y_local
-    out = torch.empty((world * max_rows,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
-    dist.all_gather(list(out.chunk(world, 0)), pad)
-    pieces = []
-    for r in range(world):
-        lo, hi = shard_range(total_rows, r, world)
-        pieces.append(out[r * max_rows : r * max_rows + (hi - lo)])
-    return torch.cat(pieces, 0)
+class RcclComm(LocalComm):
+    """RCCL over xGMI through the C ABI (include/cwm_hip.h: cwm_comm_init / cwm_broadcast / cwm_allgatherv / cwm_allreduce_sum_f32),
+    enqueued on the current HIP stream of `device`."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes, device):
+        from . import _lib
+
+        self._lib_mod = _lib
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        ident = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.get_lib().cwm_comm_init(rank, world, ident, C.byref(handle)))
+        self._handle = handle
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        from . import _lib
+
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.get_lib().cwm_comm_unique_id(buf))
+        return bytes(buf)
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib_mod.get_lib().cwm_comm_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return self._lib_mod.current_stream_handle(self.device)
+
+    def broadcast_bytes(self, buf, src=0):
+        assert buf.is_cuda and buf.is_contiguous()
+        with torch.cuda.device(self.device):
+            self._lib_mod.check(self._lib_mod.get_lib().cwm_broadcast(self._handle, buf.data_ptr(), buf.numel() * buf.element_size(), src, self._stream()))
+
+    def all_gather_blocks(self, local, out, counts):
+        assert out.is_cuda and out.is_contiguous() and (local.is_contiguous() or local.numel() == 0)
+        row = out[0].numel() * out.element_size() if out.shape[0] else 0
+        sizes = (C.c_size_t * self.world)(*[n * row for n in counts])
+        offs = (C.c_size_t * self.world)(*[sum(counts[:r]) * row for r in range(self.world)])
+        with torch.cuda.device(self.device):
+            self._lib_mod.check(self._lib_mod.get_lib().cwm_allgatherv(self._handle, local.data_ptr() if local.numel() else None, out.data_ptr(),
+                                                                 offs, sizes, self._stream()))
+        return out
+
+    def all_reduce_sum(self, t):
+        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+        with torch.cuda.device(self.device):
+            self._lib_mod.check(self._lib_mod.get_lib().cwm_allreduce_sum_f32(self._handle, t.data_ptr(), t.numel(), self._stream()))
 
 
+_default: Optional[LocalComm] = None
+
+
+def get_comm(device=None) -> LocalComm:
+    """The process's communicator: `LocalComm` without a launcher; with `torch.distributed` initialised, `RcclComm` for a CUDA/HIP
+    device (the RCCL id is created on rank 0 and handed out through the launcher's group) and `TorchComm` otherwise."""
+    global _default
+    if _default is not None:
+        return _default
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        _default = LocalComm()
+    elif device is not None and torch.device(device).type == "cuda":
+        box = [RcclComm.new_unique_id() if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        _default = RcclComm(dist.get_rank(), dist.get_world_size(), box[0], device)
+    else:
+        _default = TorchComm()
+    return _default
+
+
+def reset_comm():
+    global _default
+    if isinstance(_default, RcclComm):
+        _default.close()
+    _default = None
+
+
+# ---- packed broadcast ---------------------------------------------------------------------------------------------------
+def _aligned(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+def _layout(x_shape: Sequence[int], table_shape: Sequence[int], n_tok: int):
+    """Byte offsets of {header | frame pair fp32 | prompt table int32 | masks uint8} and the total size."""
+    S = table_shape[0]
+    o_x = _aligned(_HEADER_WORDS * 8)
+    o_t = o_x + _aligned(4 * int(torch.Size(x_shape).numel()))
+    o_m = o_t + _aligned(4 * int(torch.Size(table_shape).numel()))
+    return o_x, o_t, o_m, o_m + _aligned(S * n_tok)
+
+
+def pack_inputs(x: torch.Tensor, table: torch.Tensor, masks: torch.Tensor, n_masked: int, device) -> torch.Tensor:
+    """Rank 0: one contiguous uint8 buffer holding everything the other ranks need."""
+    assert x.dim() == 5 and x.shape[0] == 1 and table.dim() == 2 and masks.shape[0] == table.shape[0]
+    o_x, o_t, o_m, total = _layout(x.shape, table.shape, masks.shape[1])
+    buf = torch.zeros(total, dtype=torch.uint8, device=device)
+    head = torch.tensor([_MAGIC, *x.shape, *table.shape, masks.shape[1], n_masked] + [0] * (_HEADER_WORDS - 10), dtype=torch.int64)
+    buf[: _HEADER_WORDS * 8] = head.view(torch.uint8).to(device)
+    buf[o_x : o_x + 4 * x.numel()] = x.to(device=device, dtype=torch.float32).contiguous().view(-1).view(torch.uint8)
+    buf[o_t : o_t + 4 * table.numel()] = table.to(device=device, dtype=torch.int32).contiguous().view(-1).view(torch.uint8)
+    buf[o_m : o_m + masks.numel()] = masks.to(device=device).contiguous().view(-1).view(torch.uint8)
+    return buf
+
+
+def unpack_inputs(buf: torch.Tensor):
+    """Every rank: (x [1,T,C,H,W] fp32, table [S,K] int32, masks [S,Nt] bool, n_masked) as views of the received buffer.  Reads the
+    128-byte header back to the host (the one synchronisation a receiving rank needs)."""
+    head = buf[: _HEADER_WORDS * 8].view(torch.int64).tolist()
+    assert head[0] == _MAGIC, "packed prompt buffer: bad magic"
+    x_shape, t_shape, n_tok, n_masked = head[1:6], head[6:8], head[8], head[9]
+    o_x, o_t, o_m, _ = _layout(x_shape, t_shape, n_tok)
+    n_x, n_t = int(torch.Size(x_shape).numel()), int(torch.Size(t_shape).numel())
+    x = buf[o_x : o_x + 4 * n_x].view(torch.float32).view(*x_shape)
+    table = buf[o_t : o_t + 4 * n_t].view(torch.int32).view(*t_shape)
+    masks = buf[o_m : o_m + t_shape[0] * n_tok].view(torch.bool).view(t_shape[0], n_tok)
+    return x, table, masks, n_masked
+
+
+# ---- the config-4 loop --------------------------------------------------------------------------------------------------
 def sharded_counterfactual_predictions(
     x: Optional[torch.Tensor],
     prompts: Optional[torch.Tensor],
     build_fn: Callable[[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],
-    predict_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
+    rect_fn: Callable[[torch.Tensor], Tuple[torch.Tensor, int]],
+    predict_fn: Callable[[torch.Tensor, torch.Tensor, int, int], torch.Tensor],
     device,
     chunk: int = 32,
     gather: bool = True,
+    comm: Optional[LocalComm] = None,
+    shapes: Optional[Tuple[Sequence[int], Sequence[int], int]] = None,
 ) -> torch.Tensor:
-    """The config-4 loop: S prompts over ONE frame pair, sharded over the ranks.
+    """S prompts over ONE frame pair, sharded over the ranks of `comm`.
 
-    x, prompts: valid on rank 0 (ignored elsewhere).  `build_fn(x, prompts_slice)` turns a slice of
-    the prompt table into per-prompt inputs (x_s[b,T,C,H,W], mask_s[b,Nt]) on `device`;
-    `predict_fn` runs the predictor on at most `chunk` prompts at a time (the reference's
-    `sample_batch_size`).  Returns all S predictions in prompt order on every rank (or only the
-    local slice with gather=False)."""
-    rank, world = _world()
-    xb, pb = broadcast_inputs(x, prompts, device)
-    S = pb.shape[0]
+    x [1,T,C,H,W], prompts [S,K] int32: valid on rank 0 (ignored elsewhere).
+      build_fn(x, prompt_rows) -> (x_rows [n,T,C,H,W], mask_rows [n,Nt])   device-side prompt construction, NOT rectangularised
+      rect_fn(masks [S,Nt])    -> (masks, n_masked)                         rank 0 only, once for all S rows (global RNG order kept)
+      predict_fn(x_rows, mask_rows, n_masked, chunk) -> y [n, ...]          the predictor over `chunk` rows per call, no host sync
+    shapes = (x.shape, prompts.shape, Nt), if known on every rank, lets the receivers size the packed buffer without a
+    metadata collective.  Returns all S predictions in prompt order on every rank (only the local block with gather=False)."""
+    comm = comm or get_comm(device)
+    rank, world = comm.rank, comm.world
+    if rank == 0:
+        xb, table = x.to(device), prompts.to(device)
+        x_all, masks = build_fn(xb, table)
+        masks, n_masked = rect_fn(masks)
+    if world > 1:
+        if rank == 0:
+            buf = pack_inputs(xb, table, masks, n_masked, device)
+        if shapes is None:  # receivers learn the buffer size from a first 8-byte broadcast
+            meta = torch.tensor([buf.numel() if rank == 0 else 0], dtype=torch.int64, device=device).view(torch.uint8)
+            comm.broadcast_bytes(meta, 0)
+            total = int(meta.view(torch.int64).item())
+        else:
+            total = _layout(shapes[0], shapes[1], shapes[2])[3]
+        if rank != 0:
+            buf = torch.empty(total, dtype=torch.uint8, device=device)
+        comm.broadcast_bytes(buf, 0)
+        if rank != 0:
+            xb, table, masks, n_masked = unpack_inputs(buf)
+    S = table.shape[0]
     lo, hi = shard_range(S, rank, world)
-    outs = []
-    for c0 in range(lo, hi, chunk):
-        c1 = min(c0 + chunk, hi)
-        xs, ms = build_fn(xb, pb[c0:c1])
-        outs.append(predict_fn(xs, ms))
-    if outs:
-        y_local = torch.cat(outs, 0)
-    else:  # a rank with an empty slice still has to join the collective with the right trailing shape
-        xs, ms = build_fn(xb, pb[:1])
-        y_local = predict_fn(xs, ms)[:0]
-    return all_gather_rows(y_local, S) if gather else y_local
+    if hi > lo:
+        x_own = x_all[lo:hi] if rank == 0 else build_fn(xb, table[lo:hi])[0]
+        y_local = predict_fn(x_own, masks[lo:hi], n_masked, chunk)
+    else:  # an empty slice still joins the gather with the right trailing shape: predict one row, keep none
+        y_local = predict_fn(build_fn(xb, table[:1])[0], masks[:1], n_masked, chunk)[:0]
+    if not gather or world == 1:
+        return y_local
+    counts = [shard_range(S, r, world)[1] - shard_range(S, r, world)[0] for r in range(world)]
+    out = torch.empty((S,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
+    return comm.all_gather_blocks(y_local.contiguous(), out, counts)
+
+
+def prompt_hooks(G, frame: Optional[int] = -1):
+    """(build_fn, rect_fn, predict_fn) of `sharded_counterfactual_predictions` for a `segmentation.FlowGenerator` and prompt rows
+    (active_h, active_w, dy, dx): one active patch of frame 1 moved by (dy, dx) patches, nothing passive (cfg 4)."""
+    from .prediction import _RectBatch
+
+    def build(xb, rows):
+        n_rows = rows.shape[0]
+        T = 2
+        xb = xb[:, :1]
+        G.inp_shape = (1, T) + tuple(xb.shape[2:])
+        _, gh, gw = G.mask_shape
+        n = gh * gw
+        frame1 = torch.arange(T * n, device=xb.device) >= n
+        passive = frame1[None].expand(n_rows, -1)
+        cell = n + rows[:, 0].long() * gw + rows[:, 1].long()
+        active = passive.clone()
+        active[torch.arange(n_rows, device=xb.device), cell] = False
+        return G._shift_rows(xb.expand(-1, T, -1, -1, -1), passive, active, rows[:, 2:4], 1, True, samples_per_movie=n_rows)
+
+    def rect(masks):
+        masks = G.mask_rectangularizer(masks)
+        return masks, G.mask_rectangularizer.last_num_masked
+
+    def predict(xs, ms, n_masked, chunk):
+        return G._select_frame(G._run_rect_batch(_RectBatch(xs, ms, n_masked), rows_per_call=chunk), frame)
+
+    return build, rect, predict
 
 
 # ---- sample statistics over sharded samples (SURVEY.md §8 f-4) -----------------------------------------------------------
-def all_gather_last_axis(x_local: torch.Tensor) -> torch.Tensor:
+def all_gather_last_axis(x_local: torch.Tensor, comm: Optional[LocalComm] = None) -> torch.Tensor:
     """Concatenate per-rank tensors along the LAST axis (rank order = sample order); sizes may differ (or be 0)."""
-    rank, world = _world()
-    if world == 1:
+    comm = comm or get_comm(x_local.device)
+    if comm.world == 1:
         return x_local
-    n = torch.tensor([x_local.shape[-1]], dtype=torch.int64, device=x_local.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
-    width = max(max(counts), 1)
-    pad = torch.zeros(tuple(x_local.shape[:-1]) + (width,), dtype=x_local.dtype, device=x_local.device)
-    pad[..., : x_local.shape[-1]] = x_local
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad.contiguous())
-    return torch.cat([p[..., :c] for p, c in zip(parts, counts)], -1)
+    n = torch.zeros(comm.world, dtype=torch.float32, device=x_local.device)
+    n[comm.rank] = x_local.shape[-1]
+    comm.all_reduce_sum(n)
+    counts = [int(v) for v in n.tolist()]
+    rows = x_local.movedim(-1, 0).contiguous()  # sample-major blocks: the gather concatenates along dim 0
+    out = torch.empty((sum(counts),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    return comm.all_gather_blocks(rows, out, counts).movedim(0, -1).contiguous()
 
 
 def sharded_flow_corrs(flow_samples_local: torch.Tensor, downsample: int = 1, use_covariance: bool = True, gather: bool = False,
-                       features_fn: Optional[Callable] = None, cov_rows_fn: Optional[Callable] = None) -> torch.Tensor:
+                       features_fn: Optional[Callable] = None, cov_rows_fn: Optional[Callable] = None, comm: Optional[LocalComm] = None) -> torch.Tensor:
     """`FlowGenerator.compute_flow_corrs` (segmentation.py:479-547) when the S flow samples are spread over the ranks
     (`flow_samples_local` [B,C,H,W,S_rank]).  One collective on small data: the pooled features [B,P,S_rank] are all-gathered
     (P*S*4 bytes per frame pair: 12.8 MB at P = 12544, S = 256); then every rank computes rows `shard_range(P, rank, world)`
@@ -134,36 +320,37 @@ def sharded_flow_corrs(flow_samples_local: torch.Tensor, downsample: int = 1, us
 
         features_fn = features_fn or flowstats.flow_features
         cov_rows_fn = cov_rows_fn or flowstats.feature_cov_rows
-    rank, world = _world()
+    comm = comm or get_comm(flow_samples_local.device)
     B, _, H, W, S_local = flow_samples_local.shape
     ds = int(downsample or 1)
     if S_local > 0:
         x_local = features_fn(flow_samples_local, ds)
     else:  # a rank with an empty shard still joins the collective
         x_local = torch.zeros((B, (H // ds) * (W // ds), 0), dtype=torch.float32, device=flow_samples_local.device)
-    x = all_gather_last_axis(x_local)
+    x = all_gather_last_axis(x_local, comm)
     P = x.shape[1]
-    lo, hi = shard_range(P, rank, world)
+    lo, hi = shard_range(P, comm.rank, comm.world)
     slab = cov_rows_fn(x, lo, hi - lo, use_covariance)
-    if not gather or world == 1:
+    if not gather or comm.world == 1:
         return slab
-    return all_gather_rows(slab.transpose(0, 1).contiguous(), P).transpose(0, 1).contiguous()
+    counts = [shard_range(P, r, comm.world)[1] - shard_range(P, r, comm.world)[0] for r in range(comm.world)]
+    rows = slab.transpose(0, 1).contiguous()
+    out = torch.empty((P,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    return comm.all_gather_blocks(rows, out, counts).transpose(0, 1).contiguous()
 
 
 def sharded_mean_motion_map(flows_local: torch.Tensor, normalize_per_sample: bool = False, normalize: bool = True, eps: float = 1e-2,
-                            sum_fn: Optional[Callable] = None, finish_fn: Optional[Callable] = None) -> torch.Tensor:
+                            sum_fn: Optional[Callable] = None, finish_fn: Optional[Callable] = None, comm: Optional[LocalComm] = None) -> torch.Tensor:
     """`FlowGenerator.compute_mean_motion_map` (segmentation.py:257-276) over sharded samples: per-rank sums of the (per-sample
-    normalised) magnitudes, ONE all-reduce of [B,1,H,W] (+ the sample count), then the range normalisation on every rank."""
+    normalised) magnitudes, ONE all-reduce of [B,1,H,W] with the sample count appended, then the range normalisation on every rank."""
     if sum_fn is None or finish_fn is None:
         from . import flowstats
 
         sum_fn = sum_fn or flowstats.motion_map_sum
         finish_fn = finish_fn or flowstats.finish_motion_map
-    rank, world = _world()
+    comm = comm or get_comm(flows_local.device)
     B, _, H, W, S = flows_local.shape
     total = sum_fn(flows_local, normalize_per_sample, eps) if S > 0 else torch.zeros((B, 1, H, W), dtype=torch.float32, device=flows_local.device)
-    n = torch.tensor([S], dtype=torch.int64, device=flows_local.device)
-    if world > 1:
-        dist.all_reduce(total)
-        dist.all_reduce(n)
-    return finish_fn(total, int(n.item()), normalize, eps)
+    packed = torch.cat([total.reshape(-1).float(), torch.tensor([float(S)], device=total.device)])
+    comm.all_reduce_sum(packed)
+    return finish_fn(packed[:-1].view(B, 1, H, W), int(round(packed[-1].item())), normalize, eps)

@@ -6,6 +6,7 @@ input in place, and both behaviours are kept so seeded runs reproduce the refere
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 
@@ -65,3 +66,139 @@ def upsample_masks(masks: torch.Tensor, size) -> torch.Tensor:
     masks = masks.unsqueeze(-2).unsqueeze(-1)
     masks = masks.repeat(*([1] * (len(shape) - 2)), 1, H // h, 1, W // w)
     return masks.view(*shape[:-2], H, W)
+
+
+# ---- mask generators that PRODUCE the prompts' masks (masking.py:267-401, 478-545) ---------------------------------------
+class MaskingGenerator(torch.nn.Module):
+    """Uniformly random masks, one per frame: `num_masks_per_frame = int(mask_ratio * cells)` of the (clumped) grid cells are
+    masked.  Bit-compatible with the reference generator under the same seeds: one `torch.randperm(cells)` on the GLOBAL torch
+    generator per frame and batch row, and -- with clumping -- two draws of the instance's numpy stream per frame for the
+    placement of the leftover rows / columns (which are always masked)."""
+
+    def __init__(self, input_size, mask_ratio, seed=0, visible_frames=0, clumping_factor=1, randomize_num_visible=False,
+                 create_on_cpu=True, always_batch=False):
+        super().__init__()
+        dims = (input_size,) if isinstance(input_size, int) else tuple(input_size)
+        self.frames = dims[0] if len(dims) == 3 else None
+        self.height, self.width = (dims[-2], dims[-1]) if len(dims) >= 2 else (dims[0], dims[0])
+        self.clumping_factor = clumping_factor
+        ch, cw = self.c
+        self.pad_h, self.pad_w = self.height % ch, self.width % cw
+        self.num_patches_per_frame = (self.height // ch) * (self.width // cw)
+        self.mask_ratio = mask_ratio
+        self.visible_frames = visible_frames
+        self.always_batch = always_batch
+        self.create_on_cpu = create_on_cpu
+        self.randomize_num_visible = randomize_num_visible
+        self.seed = seed
+        self.rng = np.random.RandomState(seed=seed)
+        torch.manual_seed(seed)
+
+    @property
+    def c(self):
+        f = self.clumping_factor
+        return (f, f) if isinstance(f, int) else tuple(f[:2])
+
+    @property
+    def mask_ratio(self):
+        return self._mask_ratio
+
+    @mask_ratio.setter
+    def mask_ratio(self, ratio):
+        self._mask_ratio = ratio
+        self._num_masks_per_frame = int(ratio * self.num_patches_per_frame)
+
+    @property
+    def num_masks_per_frame(self):
+        return self._num_masks_per_frame
+
+    @num_masks_per_frame.setter
+    def num_masks_per_frame(self, count):
+        self._num_masks_per_frame = count
+        self._mask_ratio = count / self.num_patches_per_frame
+
+    @property
+    def num_visible(self):
+        return self.num_patches_per_frame - self.num_masks_per_frame
+
+    @num_visible.setter
+    def num_visible(self, count):
+        self.num_masks_per_frame = self.num_patches_per_frame - count
+
+    def __repr__(self):
+        return "%s(cells/frame=%d, masked=%d, visible=%d, mask_ratio=%.3f, randomize_num_visible=%s)" % (
+            type(self).__name__, self.num_patches_per_frame, self.num_masks_per_frame, self.num_visible, self.mask_ratio,
+            self.randomize_num_visible)
+
+    def sample_mask_per_frame(self, *args, **kwargs):
+        n_masked = self.num_masks_per_frame
+        if self.randomize_num_visible:
+            n_masked = self.rng.randint(low=n_masked, high=self.num_patches_per_frame + 1)
+        # cell i is visible iff a random permutation sends it among the first (cells - n_masked) slots
+        cells = torch.randperm(self.num_patches_per_frame) >= self.num_patches_per_frame - n_masked
+        ch, cw = self.c
+        if max(ch, cw) == 1:
+            return cells
+        grid = cells.view(self.height // ch, self.width // cw).repeat_interleave(ch, 0).repeat_interleave(cw, 1)
+        bottom = int(self.rng.choice(range(self.pad_h + 1)))
+        right = int(self.rng.choice(range(self.pad_w + 1)))
+        full = torch.ones(self.height, self.width, dtype=torch.bool)
+        top, left = self.pad_h - bottom, self.pad_w - right
+        full[top : top + grid.shape[0], left : left + grid.shape[1]] = grid
+        return full
+
+    def _one_row(self, num_frames):
+        return torch.cat([self.sample_mask_per_frame() for _ in range(num_frames)], 0).flatten()
+
+    def forward(self, x=None, num_frames=None):
+        num_frames = (num_frames or self.frames) or 1
+        if isinstance(x, torch.Tensor):
+            rows = x.size(0)
+            masks = torch.stack([self._one_row(num_frames) for _ in range(rows)], 0)
+            if not self.create_on_cpu:
+                masks = masks.to(x.device)
+            if rows == 1 and not self.always_batch:
+                masks = masks[0]
+        else:
+            rows = 1
+            masks = self._one_row(num_frames)
+            if self.always_batch:
+                masks = masks[None]
+        if self.visible_frames > 0:
+            lead = torch.zeros(masks.shape[:-1] + (self.visible_frames * self.height * self.width,), dtype=torch.bool, device=masks.device)
+            masks = torch.cat([lead, masks], -1)
+        return masks
+
+
+class RotatedTableUniformMaskingGenerator(MaskingGenerator):
+    """The demos' prompt mask: the first `visible_frames` frames (default: all but the last) fully visible (or masked at
+    `context_mask_ratio`), the remaining frame(s) masked at `mask_ratio` (masking.py:478-545)."""
+
+    def __init__(self, input_size, mask_ratio, visible_frames=None, context_mask_ratio=None, seed=0, clumping_factor=1,
+                 always_batch=True, randomize_num_visible=False, full_mask_prob=0):
+        assert len(input_size) == 3, input_size
+        if visible_frames is None:
+            visible_frames = input_size[0] - 1
+        super().__init__(input_size=(input_size[0] - visible_frames,) + tuple(input_size[1:]), mask_ratio=mask_ratio,
+                         visible_frames=visible_frames, seed=seed, clumping_factor=clumping_factor, always_batch=always_batch,
+                         randomize_num_visible=randomize_num_visible)
+        self.full_mask_prob = full_mask_prob
+        self.context_mask_ratio = context_mask_ratio or 0
+        self.vis_frame_sampler = None
+        if context_mask_ratio is not None:
+            self.vis_frame_sampler = MaskingGenerator(input_size=(1, self.height, self.width), mask_ratio=context_mask_ratio, visible_frames=0,
+                                                      clumping_factor=1, create_on_cpu=self.create_on_cpu, always_batch=self.always_batch)
+
+    def __repr__(self):
+        return super().__repr__() + " visible_frames=%d context_mask_ratio=%s" % (self.visible_frames, self.context_mask_ratio)
+
+    def forward(self, x=None, *args, **kwargs):
+        masks = super().forward(x=x, *args, **kwargs)
+        n_lead = self.visible_frames * self.height * self.width
+        if self.full_mask_prob > 0:
+            hide = (torch.rand((masks.size(0), 1)).to(masks.device) < self.full_mask_prob).expand(-1, masks.size(-1) - n_lead)
+            masks = torch.cat([masks[:, :n_lead], masks[:, n_lead:] | hide], -1)
+        if self.vis_frame_sampler is not None:
+            context = torch.cat([self.vis_frame_sampler(x) for _ in range(self.visible_frames)], -1)
+            masks = torch.cat([context, masks[:, n_lead:]], -1)
+        return masks

@@ -185,12 +185,17 @@ class PretrainVisionTransformer(nn.Module):
         except Exception:
             pass
 
-    def sync_weights(self, device: Optional[torch.device] = None) -> int:
+    def sync_weights(self, device: Optional[torch.device] = None, force: bool = False) -> int:
         """Push every parameter that changed since the last call into the library (packs to bf16
-        hi/lo planes).  Counterpart of `load_state_dict` at the boundary (prediction.py:81-107)."""
+        hi/lo planes).  Counterpart of `load_state_dict` at the boundary (prediction.py:81-107).
+        A change is detected by (storage pointer, version counter): `load_state_dict`, `copy_`, optimizer steps bump the
+        counter, but in-place edits through `.data` (EMA swaps, weight surgery) do NOT -- call `sync_weights(force=True)`
+        (or `invalidate_weights()`) after such an edit, otherwise the library keeps running the old packed weights."""
         device = device or next(self.parameters()).device
         h = self._ensure_handle(device)
         lib = _lib.get_lib()
+        if force:
+            self._loaded = {}
         n = 0
         with torch.cuda.device(device):
             for name, p in self.state_dict(keep_vars=True).items():
@@ -209,7 +214,11 @@ class PretrainVisionTransformer(nn.Module):
                 n += 1
         return n
 
-    def _run(self, x, strides, normalize, mask, n_vis, want_video, xraw=None, check=True):
+    def invalidate_weights(self):
+        """Forget what has been uploaded: the next forward re-packs every parameter (see `sync_weights`)."""
+        self._loaded = {}
+
+    def _run(self, x, strides, normalize, mask, n_vis, want_video, xraw=None, check=True, out_tokens=None, out_video=None):
         _lib.require_gpu()
         if not x.is_cuda:
             raise RuntimeError("PretrainVisionTransformer.forward needs a CUDA/HIP tensor (no CPU fallback); got %s" % x.device)
@@ -226,8 +235,8 @@ class PretrainVisionTransformer(nn.Module):
             n_vis = Nt - int(mask[0].sum().item())
         Nm = Nt - n_vis
         # nothing masked: the reference returns head(norm(x)) for all Nt tokens (vmae.py:250-253)
-        y = torch.empty((B, Nm if Nm > 0 else Nt, c.out_dim), device=dev, dtype=torch.float32)
-        video = torch.empty((B, c.num_frames, c.in_chans, c.img_size[0], c.img_size[1]), device=dev, dtype=torch.float32) if want_video else None
+        y = self._out_buffer(out_tokens, (B, Nm if Nm > 0 else Nt, c.out_dim), dev)
+        video = self._out_buffer(out_video, (B, c.num_frames, c.in_chans, c.img_size[0], c.img_size[1]), dev) if want_video else None
         args = _lib.CwmForwardArgs(
             x.data_ptr(), strides[0], strides[1], strides[2], int(normalize), mask.data_ptr(), B, n_vis, y.data_ptr(),
             _lib.ptr(video), _lib.ptr(xraw), _lib.mode_id(self.mode), int(check), _lib.current_stream_handle(dev),
@@ -235,6 +244,16 @@ class PretrainVisionTransformer(nn.Module):
         with torch.cuda.device(dev):
             _lib.check(lib.cwm_forward(self._handle, C.byref(args)))
         return y, video
+
+    @staticmethod
+    def _out_buffer(given, shape, dev):
+        """The caller's output tensor (a row slice of a larger result: lets a chunked driver assemble its result without a
+        concatenation pass) or a fresh one."""
+        if given is None:
+            return torch.empty(shape, device=dev, dtype=torch.float32)
+        if tuple(given.shape) != tuple(shape) or given.dtype != torch.float32 or given.device != dev or not given.is_contiguous():
+            raise RuntimeError("output buffer must be a contiguous float32 tensor of shape %s on %s" % (tuple(shape), dev))
+        return given
 
     @staticmethod
     def _frame_strides(x: torch.Tensor, c_dim: int, t_dim: int):
@@ -260,14 +279,15 @@ class PretrainVisionTransformer(nn.Module):
         return y
 
     @torch.no_grad()
-    def predict_video(self, x_btchw, mask, normalize: bool = True, n_vis: Optional[int] = None, check: bool = True):
+    def predict_video(self, x_btchw, mask, normalize: bool = True, n_vis: Optional[int] = None, check: bool = True,
+                      out_tokens: Optional[torch.Tensor] = None, out_video: Optional[torch.Tensor] = None):
         """Fused wrapper path: raw [B,T,C,H,W] frames in [0,1] -> (tokens [B,Nm,C*P*P], video
         [B,T,C,H,W]) = `_preprocess` + forward + `pred_patches_to_video`
         (prediction.py:304-312, :419-422, :245-259) in one library call."""
         if x_btchw.dim() != 5 or x_btchw.shape[2] != self.cfg.in_chans or x_btchw.shape[1] != self.cfg.num_frames:
             raise RuntimeError("expected x of shape [B,%d,%d,H,W], got %s" % (self.cfg.num_frames, self.cfg.in_chans, tuple(x_btchw.shape)))
         x, strides = self._frame_strides(x_btchw, 2, 1)
-        return self._run(x, strides, normalize, mask, n_vis, True, xraw=x, check=check)
+        return self._run(x, strides, normalize, mask, n_vis, True, xraw=x, check=check, out_tokens=out_tokens, out_video=out_video)
 
     # ---- execution options ----------------------------------------------------------------------------
     def set_lanes(self, lanes: int):

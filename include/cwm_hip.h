@@ -20,6 +20,7 @@
 #ifndef CWM_HIP_H
 #define CWM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -209,6 +210,33 @@ int cwm_flow_cov(const float* x_dev, int B, int P, int S, int row0, int nrows, i
 int cwm_flow_motion_sum(const float* flows_dev, const int64_t* strides, int B, int C, int H, int W, int S,
                         int normalize_per_sample, float eps, float* minmax_work_dev, float* sum_dev, void* stream);
 int cwm_flow_map_finish(float* map_dev, int B, int HW, float scale, int normalize, float eps, void* stream);
+
+/* ---- collectives around the sharded counterfactual-sampling loop (SURVEY.md 8e / 8b "comm"; BASELINE configs[3]) ----------
+ * The reference has no multi-GPU code: it chunks the S prompts of one frame pair over ONE device (prediction.py:513-540,
+ * segmentation.py:423-430).  Here the prompts are sharded over one process per GPU and these entry points are the only
+ * communication: RCCL (over xGMI) called directly, asynchronous on `stream`, byte counts, device pointers.
+ *   cwm_comm_unique_id   rank 0: a fresh 128-byte id, to be handed to the other ranks by any out-of-band means
+ *                        (counterfactualworldmodels_amd/dist.py uses the torch.distributed store of the launcher)
+ *   cwm_comm_init        collective over all ranks; binds the communicator to the CURRENT HIP device
+ *   cwm_broadcast        in place, from `root`: the packed {frame pair | prompt table | masks} buffer
+ *   cwm_allgather        equal blocks: recv[r*bytes_per_rank ...] = rank r's send block
+ *   cwm_allgatherv       blocks of counts[r] bytes at offsets[r] of recv (host arrays of length nranks); send may alias its own slot
+ *   cwm_allreduce_sum_f32  in place (sample-sharded motion map, segmentation.py:257-276)
+ * cwm_comm_load(path) optionally names the RCCL shared object to bind (default: the copy already mapped into the process --
+ * PyTorch's -- else the ROCm install); cwm_comm_version() returns its NCCL_VERSION_CODE or -1. */
+#define CWM_COMM_ID_BYTES 128
+typedef struct cwm_comm cwm_comm;
+int cwm_comm_load(const char* rccl_path);
+int cwm_comm_version(void);
+int cwm_comm_unique_id(uint8_t* id_out);
+int cwm_comm_init(int rank, int nranks, const uint8_t* id_in, cwm_comm** out);
+void cwm_comm_destroy(cwm_comm* c);
+int cwm_comm_rank(const cwm_comm* c);
+int cwm_comm_size(const cwm_comm* c);
+int cwm_broadcast(cwm_comm* c, void* buf_dev, size_t bytes, int root, void* stream);
+int cwm_allgather(cwm_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+int cwm_allgatherv(cwm_comm* c, const void* send_dev, void* recv_dev, const size_t* offsets, const size_t* counts, void* stream);
+int cwm_allreduce_sum_f32(cwm_comm* c, float* buf_dev, size_t count, void* stream);
 
 /* ---- diagnostics: single-kernel micro-benchmarks on random operands (tools/microbench.py) ---------
  * epi: 0 = fp32 out + bias + in-place residual (proj/fc2 form), 1 = bias + GELU -> bf16 (fc1 form),

@@ -310,6 +310,117 @@ def run_conj_cases(ns, skip_large=False):
     print(f"[golden] conj_imu400_b2.npz {tuple(y.shape)} std {y.std():.4f} ({time.time() - t0:.1f}s)")
 
 
+def run_wrapper_cases(ns):
+    """Wrapper-surface fixtures (SURVEY.md §8b "wrapper surface consumers rely on", §8c-4): mask generators, patch-index masks,
+    masked-patch compositing, the single-prompt counterfactual of the UI's click handler, `predict_error`, and the batch driver
+    `predict_counterfactual_videos_and_flows` incl. the IMU keyword forwarding -- every output produced by the reference classes."""
+    out = {}
+    # ---- mask generators (masking.py:267-401, 478-545); known answer: 3104 masked on (2,56,56) (demo notebook)
+    x2 = torch.zeros(2, 2, 3, 8, 8)
+    gen = ns.masking.RotatedTableUniformMaskingGenerator(input_size=(2, 56, 56), mask_ratio=0.99, clumping_factor=2,
+                                                         randomize_num_visible=False, always_batch=True, seed=0)
+    out["gen_rot56_none"] = gen(None).numpy()
+    out["gen_rot56_b2"] = gen(x2).numpy()
+    assert int(out["gen_rot56_none"].sum()) == 3104
+    gen = ns.masking.RotatedTableUniformMaskingGenerator(input_size=(3, 7, 7), mask_ratio=0.75, clumping_factor=2, seed=1,
+                                                         randomize_num_visible=True)
+    out["gen_rot7_pad_b2"] = np.stack([gen(x2).numpy() for _ in range(3)])
+    gen = ns.masking.RotatedTableUniformMaskingGenerator(input_size=(2, 8, 8), mask_ratio=0.5, seed=4, full_mask_prob=0.5)
+    out["gen_rot8_full_b5"] = np.stack([gen(torch.zeros(5, 1)).numpy() for _ in range(2)])
+    gen = ns.masking.MaskingGenerator(input_size=(1, 7, 7), mask_ratio=0.75, clumping_factor=2, seed=1, visible_frames=1)
+    out["gen_base7_b2"] = gen(x2).numpy()
+    gen = ns.masking.RotatedTableUniformMaskingGenerator(input_size=(2, 28, 28), mask_ratio=0.9, seed=2)
+    gen.num_visible = 3
+    out["gen_rot28_nv3"] = gen(x2).numpy()
+
+    # ---- tiny predictor behind the reference FlowGenerator
+    class DummyFlow(torch.nn.Module):
+        def forward(self, x, backward=False, **k):
+            d = x[:, 1:] - x[:, :-1]
+            return torch.stack([d.mean(2), d.amax(2)], 2)  # [R,T-1,2,H,W]
+
+    cfg = TINY
+    m = build_ref_model(ns, cfg, 3)
+    G = ns.segmentation.FlowGenerator(predictor=m, flow_model=DummyFlow(), imagenet_normalize_inputs=True, temporal_dim=2, seed=0)
+    x = torch.from_numpy(S.synthetic_frames(2, cfg, 41))
+    n = cfg.tokens_per_frame
+    G.set_input(x)
+    # generate_mask_from_patch_idx_list (prediction.py:640-649): image coordinates, (h,w) / (t,h,w) / (b,t,h,w) entries
+    out["idx_hw"] = G.generate_mask_from_patch_idx_list([[9, 17], [31, 2]], b=1, frame=-1).numpy()
+    out["idx_thw"] = G.generate_mask_from_patch_idx_list([[1, 9, 17], [1, 24, 24]], b=0, frame=1).numpy()
+    out["idx_bthw"] = G.generate_mask_from_patch_idx_list([[0, 1, 9, 17], [1, 1, 31, 2]], frame=1, stride=8).numpy()
+    # get_masked_pred_patches (prediction.py:261-283)
+    g = np.random.Generator(np.random.PCG64(3))
+    preds = torch.from_numpy(g.random((2, 1, 3, 32, 32), dtype=np.float32))
+    pmask = torch.from_numpy(g.random((2, n)) < 0.5)
+    out["mpp_preds"], out["mpp_mask"] = preds.numpy(), pmask.numpy()
+    out["mpp_plain"] = G.get_masked_pred_patches(preds, pmask).numpy()
+    out["mpp_invert_fill"] = G.get_masked_pred_patches(preds, pmask, invert=True, fill_value=[0.1, 0.2, 0.3]).numpy()
+    out["mpp_fill_tensor"] = G.get_masked_pred_patches(preds, pmask, fill_value=1 - preds).numpy()
+    # predict_error (prediction.py:331-343)
+    mask = torch.from_numpy(S.synthetic_masks(2, cfg, 4, 41))
+    with torch.no_grad():
+        out["err_frame1"] = G.predict_error(x, mask.clone(), frame=1).numpy()
+        out["err_all"] = G.predict_error(x, mask.clone(), frame=None).numpy()
+    out["err_mask"] = mask.numpy()
+    # get_counterfactual_prediction (prediction.py:781-812): the UI's single prompt (interface.py:273-299)
+    img = x[:1, 0]
+    passive = torch.ones(1, 2 * n, dtype=torch.bool)
+    passive[:, :n] = False
+    passive[0, n + 3] = False
+    active = torch.ones(1, 2 * n, dtype=torch.bool)
+    active[:, :n] = False
+    active[0, n + 6] = False
+    with torch.no_grad():
+        xs = G.make_static_movie(img[:, None], T=2)
+        G.shifts = None
+        x_p, mask_p = G._shift(xs, passive.clone(), active_patches=active.clone(), shift=(1, -1), frame=1)
+        G.shifts = None
+        y_p = G.get_counterfactual_prediction(img, mask=passive.clone(), active_patches=active.clone(), shift=(1, -1))
+    out["cf_img"], out["cf_passive"], out["cf_active"] = img.numpy(), passive.numpy(), active.numpy()
+    out["cf_x_p"], out["cf_mask_p"], out["cf_y"] = x_p.numpy(), mask_p.numpy(), y_p.numpy()
+    out["cf_shifts"] = np.array(G.shifts)
+    # the batch driver with a flow model (segmentation.py:346-432): ordering, shifts list, flow shape
+    S_n = 5
+    act = torch.ones(1, 2 * n, S_n, dtype=torch.bool)
+    act[:, :n] = False
+    for s in range(S_n):
+        act[0, n + (2 + 3 * s) % n, s] = False
+    shifts = [[1, 0], [0, 1], [-1, 0], [0, -1], [1, 1]]
+    torch.manual_seed(5)
+    with torch.no_grad():
+        ys, fs = G.predict_counterfactual_videos_and_flows(img, active_patches=act.clone(), shifts=[list(v) for v in shifts],
+                                                           num_samples=S_n, sample_batch_size=64)
+    out["drv_active"], out["drv_shifts"] = act.numpy(), np.array(shifts, dtype=np.int32)
+    out["drv_ys"], out["drv_flows"], out["drv_shift_list"] = ys.numpy(), fs.numpy(), np.array(G.shifts)
+    np.savez_compressed(os.path.join(HERE, "wrapper_surface.npz"), **out)
+    print("[golden] wrapper_surface.npz", {k: v.shape for k, v in out.items() if k.startswith(("cf_", "drv_"))})
+
+    # ---- IMU-conditioned driver: the reference base class forwards x_context / mask_context per chunk (B = 1)
+    cfgc = TINY_CONJ
+    mc_ = build_ref_conj(ns, cfgc, 5)
+    Gc = ns.segmentation.FlowGenerator(predictor=mc_, flow_model=DummyFlow(), imagenet_normalize_inputs=True, temporal_dim=2, seed=0)
+    nc = cfgc.main.tokens_per_frame
+    g = np.random.Generator(np.random.PCG64(8))
+    imgc = torch.from_numpy(g.random((1, 3, 32, 32), dtype=np.float32))
+    imu = torch.from_numpy((g.standard_normal((1, 6, cfgc.ctx_seq_len)) * 0.1).astype(np.float32))
+    S_n = 4
+    act = torch.ones(1, 2 * nc, S_n, dtype=torch.bool)
+    act[:, :nc] = False
+    for s in range(S_n):
+        act[0, nc + (5 + 11 * s) % nc, s] = False
+    shifts = [[1, 0], [0, 2], [-1, -1], [2, 1]]
+    h_mask = torch.zeros(1, cfgc.ctx_tokens, dtype=torch.bool)
+    torch.manual_seed(6)
+    with torch.no_grad():
+        # sample_batch_size >= 2 * B * S makes the reference run all S prompts in one chunk (prediction.py:504-507)
+        ys, fs = Gc.predict_counterfactual_videos_and_flows(imgc, active_patches=act.clone(), shifts=[list(v) for v in shifts], num_samples=S_n,
+                                                            sample_batch_size=64, x_context=imu, mask_context=h_mask)
+    np.savez_compressed(os.path.join(HERE, "wrapper_conj.npz"), img=imgc.numpy(), imu=imu.numpy(), active=act.numpy(),
+                        shifts=np.array(shifts, dtype=np.int32), ys=ys.numpy(), flows=fs.numpy(), seed=np.array(5))
+    print("[golden] wrapper_conj.npz", tuple(ys.shape), tuple(fs.shape))
+
+
 def flowstats_inputs(seed=0, shape=(2, 2, 16, 16, 12)):
     """Seeded random flow samples [B,2,H,W,S] (one nearly-static sample, one constant sample)."""
     g = torch.Generator().manual_seed(seed)
@@ -383,6 +494,9 @@ def main():
     if args.only == "allvis":
         run_model_case(ns, TINY, batch=2, k_vis=16, clump=1, seed=5, out_name="tiny_8x8_allvis.npz", through_wrapper=False)
         return
+    if args.only == "wrapper":
+        run_wrapper_cases(ns)
+        return
     if args.only == "flowstats":
         run_flowstats_case(ns)
         return
@@ -390,6 +504,7 @@ def main():
     run_flowstats_case(ns)
     run_shift_cases(ns)
     run_conj_cases(ns, args.skip_large)
+    run_wrapper_cases(ns)
     run_index_cases(ns)
     run_block_case(ns)
     run_model_case(ns, TINY, batch=3, k_vis=4, clump=1, seed=3, out_name="tiny_8x8_k4.npz")

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from counterfactualworldmodels_amd import config as C, prediction, synthetic as S, vmae
+from counterfactualworldmodels_amd import config as C, conjoined_vmae as CV, dist as cdist, segmentation, synthetic as S, vmae
 from oracle import vmae_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -17,10 +17,10 @@ TINY = C.VmaeConfig(name="tiny_8x8", img_size=(32, 32), patch=8, enc_dim=128, en
 TINY_SPEC = O.VmaeSpec(img_size=(32, 32), patch=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=1, dec_heads=2)
 
 
-def wrapper(cfg, seed=3):
+def wrapper(cfg, seed=3, **kw):
     m = vmae.PretrainVisionTransformer(cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, seed).items()})
-    return prediction.PredictorBasedGenerator(predictor=m.cuda().eval(), imagenet_normalize_inputs=True, temporal_dim=2)
+    return segmentation.FlowGenerator(predictor=m.cuda().eval(), imagenet_normalize_inputs=True, temporal_dim=2, **kw)
 
 
 @pytest.mark.parametrize("tag", ["tiny", "base8"])
@@ -93,3 +93,151 @@ def test_counterfactual_prediction_driver_chunking_invariance():
     with torch.no_grad():
         ref = O.predict(W, TINY_SPEC, xo, mo, frame=None)
     assert (ya.cpu() - ref).abs().max().item() <= 2e-4
+
+
+class DummyFlow(torch.nn.Module):
+    """The stand-in flow model of tests/golden/make_golden.py `run_wrapper_cases` (the reference plugs RAFT in here)."""
+
+    def forward(self, x, backward=False, **k):
+        d = x[:, 1:] - x[:, :-1]
+        return torch.stack([d.mean(2), d.amax(2)], 2)
+
+
+def test_single_prompt_counterfactual_and_error_maps_vs_reference():
+    """`get_counterfactual_prediction` (the UI's click, interface.py:273-299), `_shift`, `predict_error` against outputs of the
+    reference wrapper (wrapper_surface.npz): prompt frames / masks bit-exact, predictions within tolerance."""
+    g = np.load(os.path.join(GOLDEN, "wrapper_surface.npz"))
+    G = wrapper(TINY, 3)
+    img, passive, active = (torch.from_numpy(g[k]).cuda() for k in ("cf_img", "cf_passive", "cf_active"))
+    xs = G.make_static_movie(img[:, None], T=2)
+    x_p, mask_p = G._shift(xs, passive.clone(), active_patches=active.clone(), shift=(1, -1), frame=1)
+    assert np.array_equal(x_p.cpu().numpy(), g["cf_x_p"]) and np.array_equal(mask_p.cpu().numpy(), g["cf_mask_p"])
+    G.shifts = None
+    y = G.get_counterfactual_prediction(img, mask=passive.clone(), active_patches=active.clone(), shift=(1, -1))
+    assert y.shape == g["cf_y"].shape and np.abs(y.cpu().numpy() - g["cf_y"]).max() <= 2e-4
+    assert np.array_equal(np.array(G.shifts), g["cf_shifts"])
+    x = torch.from_numpy(S.synthetic_frames(2, TINY, 41)).cuda()
+    mask = torch.from_numpy(g["err_mask"]).cuda()
+    e1 = G.predict_error(x, mask.clone(), frame=1)
+    ea = G.predict_error(x, mask.clone(), frame=None)
+    assert e1.shape == g["err_frame1"].shape and np.abs(e1.cpu().numpy() - g["err_frame1"]).max() <= 2e-4
+    assert ea.shape == g["err_all"].shape and np.abs(ea.cpu().numpy() - g["err_all"]).max() <= 2e-4
+
+
+def test_counterfactual_videos_and_flows_vs_reference():
+    """`predict_counterfactual_videos_and_flows` with a plugged flow model (segmentation.py:346-432): '(b s)' ordering, the shifts
+    list, flows [B*S,1,2,H,W], values equal to the reference's own run of the same call; independent of sample_batch_size."""
+    g = np.load(os.path.join(GOLDEN, "wrapper_surface.npz"))
+    G = wrapper(TINY, 3, flow_model=DummyFlow())
+    img = torch.from_numpy(g["cf_img"]).cuda()
+    act = torch.from_numpy(g["drv_active"]).cuda()
+    shifts = [list(int(v) for v in r) for r in g["drv_shifts"]]
+    outs = {}
+    for sbs in (64, 2, None):
+        torch.manual_seed(5)
+        ys, fs = G.predict_counterfactual_videos_and_flows(img, active_patches=act.clone(), shifts=shifts, num_samples=5, sample_batch_size=sbs)
+        outs[sbs] = (ys, fs)
+        assert ys.shape == g["drv_ys"].shape and fs.shape == g["drv_flows"].shape == (5, 1, 2, 32, 32)
+        assert np.abs(ys.cpu().numpy() - g["drv_ys"]).max() <= 2e-4 and np.abs(fs.cpu().numpy() - g["drv_flows"]).max() <= 4e-4
+        assert np.array_equal(np.array(G.shifts), g["drv_shift_list"])
+    assert (outs[64][0] - outs[2][0]).abs().max().item() <= 1e-5 and (outs[64][0] - outs[None][0]).abs().max().item() <= 1e-5
+    with pytest.raises(RuntimeError, match="flow_model"):
+        wrapper(TINY, 3).predict_counterfactual_videos_and_flows(img, active_patches=act.clone(), shifts=shifts, num_samples=5)
+    # tensor form of the shifts argument ([2, S]) and per-sample flow layout helper
+    torch.manual_seed(5)
+    ys_t = G.predict_counterfactual_videos(img, act.clone(), shifts=torch.tensor(g["drv_shifts"]).T, num_samples=5, sample_batch_size=3)
+    assert torch.equal(ys_t, outs[64][0]) or (ys_t - outs[64][0]).abs().max().item() <= 1e-5
+    assert G._batch_to_samples(outs[64][1]).shape == (1, 2, 32, 32, 5)
+
+
+def test_imu_conditioned_driver_vs_reference():
+    """The IMU override (segmentation.py:931-963): head motion forwarded as x_context / mask_context through the batch driver, tiled over
+    the S prompts of its movie; against the reference's run on the tiny conjoined model (wrapper_conj.npz) for several chunkings."""
+    from test_conj_oracle import TINY_CONJ, conj_weights
+
+    g = np.load(os.path.join(GOLDEN, "wrapper_conj.npz"))
+    m = CV.ConjoinedPaddedVisionTransformer(TINY_CONJ)
+    m.load_state_dict(conj_weights(TINY_CONJ, int(g["seed"])))
+    G = segmentation.ImuConditionedFlowGenerator(predictor=m.cuda().eval(), flow_model=DummyFlow(), imagenet_normalize_inputs=True, temporal_dim=2)
+    assert G.num_head_tokens == TINY_CONJ.ctx_tokens and G.head_motion_channels == 6
+    img, imu, act = (torch.from_numpy(g[k]).cuda() for k in ("img", "imu", "active"))
+    shifts = [list(int(v) for v in r) for r in g["shifts"]]
+    for sbs in (64, 3, 1):
+        torch.manual_seed(6)
+        ys, fs = G.predict_counterfactual_videos_and_flows(img, active_patches=act.clone(), shifts=shifts, num_samples=4, sample_batch_size=sbs,
+                                                           head_motion=imu, mask_head_motion=False, static_head_motion=True)
+        assert ys.shape == g["ys"].shape and fs.shape == g["flows"].shape
+        err = np.abs(ys.cpu().numpy() - g["ys"]).max()
+        assert err <= 3e-4, (sbs, err)
+        assert not hasattr(m, "padding_mask")   # padding state reset after the call (prediction.py:451-452)
+    with pytest.raises(RuntimeError, match="head_motion"):
+        G.predict_counterfactual_videos(img, act.clone(), shifts=shifts, num_samples=4)
+    # two movies: each movie's prompts get that movie's IMU
+    img2 = torch.cat([img, img.flip(-1)], 0)
+    imu2 = torch.cat([imu, imu * -1.0], 0)
+    act2 = act.expand(2, -1, -1)
+    torch.manual_seed(6)
+    y2 = G.predict_counterfactual_videos(img2, act2.clone(), shifts=shifts, num_samples=4, sample_batch_size=8, head_motion=imu2)
+    assert y2.shape == (8, 2, 3, 32, 32) and np.abs(y2[:4].cpu().numpy() - g["ys"]).max() <= 3e-4
+    torch.manual_seed(6)
+    y2b = G.predict_counterfactual_videos(img2[1:], act2[1:].clone(), shifts=shifts, num_samples=4, sample_batch_size=8, head_motion=imu2[1:])
+    assert (y2[4:] - y2b).abs().max().item() <= 1e-5
+
+
+def test_256_prompts_sharded_driver_equals_one_unchunked_call():
+    """BASELINE configs[3] at full size on one rank: 256 prompts on one frame pair through `dist.sharded_counterfactual_predictions`
+    (8 library calls of 32 rows, no host sync between them) = ONE 256-row predictor call; plus rows vs the wrapper's own driver."""
+    cfg = C.CONFIGS["base_8x8patch_2frames_1tube"]
+    G = wrapper(cfg, 0)
+    x0 = torch.from_numpy(S.synthetic_frames(1, cfg, 0))[:, 0:1]
+    table = torch.from_numpy(S.synthetic_prompts(256, cfg, 0))
+    hooks = cdist.prompt_hooks(G, frame=-1)
+    torch.manual_seed(3)
+    y = cdist.sharded_counterfactual_predictions(x0, table, *hooks, torch.device("cuda:0"), chunk=32, comm=cdist.LocalComm())
+    assert y.shape == (256, 1, 3, 224, 224) and torch.isfinite(y).all()
+    torch.manual_seed(3)
+    y_one = cdist.sharded_counterfactual_predictions(x0, table, *hooks, torch.device("cuda:0"), chunk=256, comm=cdist.LocalComm())
+    err = (y - y_one).abs().max().item()
+    print(f"[prompts256] 8 x 32 rows vs one 256-row call: {err:.2e}")
+    assert err <= 5e-5
+    # the same prompts through the reference-shaped entry point (active patch masks + shifts)
+    n = cfg.tokens_per_frame
+    gw = cfg.img_size[1] // cfg.patch
+    sub = slice(0, 16)
+    active = torch.ones(1, 2 * n, 16, dtype=torch.bool)
+    active[:, :n] = False
+    cell = n + table[sub, 0].long() * gw + table[sub, 1].long()
+    active[0, cell, torch.arange(16)] = False
+    torch.manual_seed(3)
+    yv = G.predict_counterfactual_videos(x0[:, 0].cuda(), active.cuda(), shifts=table[sub, 2:4].tolist(), num_samples=16, sample_batch_size=32)
+    assert (yv[:, 1:] - y[sub]).abs().max().item() <= 5e-5
+    assert torch.equal(yv[:, 0], x0[0, 0].cuda().expand(16, -1, -1, -1))   # frame 0 is the input image
+
+
+def test_rccl_comm_single_rank_on_device():
+    """The C-ABI collectives (cwm_comm_init / cwm_broadcast / cwm_allgatherv / cwm_allreduce_sum_f32) on a one-rank RCCL communicator:
+    RCCL binds, the communicator initialises on the GPU, and every collective is the identity on the stream."""
+    from counterfactualworldmodels_amd import _lib
+
+    assert _lib.get_lib().cwm_comm_version() >= 22000
+    comm = cdist.RcclComm(0, 1, cdist.RcclComm.new_unique_id(), torch.device("cuda:0"))
+    try:
+        buf = torch.arange(4096, dtype=torch.uint8, device="cuda")
+        ref = buf.clone()
+        comm.broadcast_bytes(buf, 0)
+        local = torch.randn(5, 7, 3, device="cuda")
+        out = torch.empty_like(local)
+        comm.all_gather_blocks(local, out, [5])
+        t = torch.randn(1000, device="cuda")
+        t0 = t.clone()
+        comm.all_reduce_sum(t)
+        torch.cuda.synchronize()
+        assert torch.equal(buf, ref) and torch.equal(out, local) and torch.equal(t, t0)
+        # the sharded driver over this communicator (world 1 short-circuits the collectives but not the plumbing)
+        G = wrapper(TINY, 3)
+        x0 = torch.from_numpy(S.synthetic_frames(1, TINY, 2))[:, 0:1]
+        table = torch.tensor([[1, 2, 1, 0], [3, 3, 0, -1], [0, 0, -1, -1]], dtype=torch.int32)
+        y = cdist.sharded_counterfactual_predictions(x0, table, *cdist.prompt_hooks(G), torch.device("cuda:0"), chunk=2, comm=comm)
+        assert y.shape == (3, 1, 3, 32, 32)
+    finally:
+        comm.close()
