@@ -230,7 +230,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra fast-mode measurement")
     ap.add_argument("--no-prompts", action="store_true", help="skip the 256-prompt strong-scaling measurement beside the headline")
-    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2, 3, 4],
                     help="2 (library default): the batch runs as two half batches on two HIP streams; 1: one stream")
     args = ap.parse_args()
 

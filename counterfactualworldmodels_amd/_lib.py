@@ -167,6 +167,7 @@ SIGNATURES = {
     "cwm_allgatherv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p]),
     "cwm_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cwm_bench_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "cwm_bench_gemm_gapped": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_double)]),
     "cwm_bench_attention": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cwm_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
     "cwm_last_error": (C.c_char_p, []),

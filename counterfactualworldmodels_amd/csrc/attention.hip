@@ -559,6 +559,7 @@ int launch_attention(const AttnParams& p, int planes, hipStream_t stream) {
     CWM_REQUIRE(planes == 1 || planes == 2, "attention: planes must be 1 or 2");
     CWM_REQUIRE(p.n_tok > 0 && p.batch > 0 && p.heads > 0, "attention: empty problem");
     CWM_REQUIRE(p.ldo % 4 == 0, "attention: ldo must be a multiple of 4");
+    CWM_REQUIRE((int64_t)p.n_tok * 128 < (1ll << 31), "attention: %d tokens exceed the 32-bit tile offsets within one (batch, head)", p.n_tok);
     CWM_REQUIRE(p.q_off >= 0 && p.n_q >= 0 && p.q_off + p.n_q <= p.n_tok, "attention: query rows [%d, %d) outside the %d tokens", p.q_off, p.q_off + p.n_q, p.n_tok);
     const int nqb = ((p.n_q > 0 ? p.n_q : p.n_tok) + 127) / 128;
     // Measured (tools/microbench.py attn, MI355X; profiles/r1q_microbench_attn.log):
@@ -578,11 +579,7 @@ int launch_attention(const AttnParams& p, int planes, hipStream_t stream) {
         if (planes == 1) {
             hipLaunchKernelGGL(attention8_kernel<1>, grid, dim3(512), smem, stream, p);
         } else {
-            static bool attr8 = false;
-            if (!attr8) {
-                CWM_HIP_CHECK(hipFuncSetAttribute((const void*)attention8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                attr8 = true;
-            }
+            if (int rc = cwm_set_max_lds((const void*)attention8_kernel<2>, (int)smem)) return rc;
             hipLaunchKernelGGL(attention8_kernel<2>, grid, dim3(512), smem, stream, p);
         }
         CWM_HIP_CHECK(hipGetLastError());
@@ -593,11 +590,7 @@ int launch_attention(const AttnParams& p, int planes, hipStream_t stream) {
     if (planes == 1) {
         hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(256), smem, stream, p);
     } else {
-        static bool attr = false;
-        if (!attr) {
-            CWM_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr = true;
-        }
+        if (int rc = cwm_set_max_lds((const void*)attention_kernel<2>, (int)smem)) return rc;
         hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(256), smem, stream, p);
     }
     CWM_HIP_CHECK(hipGetLastError());

@@ -465,11 +465,8 @@ static int launch_pipe(const AttnParams& p, hipStream_t stream) {
     const int nq = p.n_q > 0 ? p.n_q : p.n_tok;
     const dim3 grid((nq + 32 * NW - 1) / (32 * NW), p.batch * p.heads);
     const size_t smem = (size_t)4 * (64 * 64 * 2) * PLANES;  // 2 K slots + 2 V slots
-    static bool attr = false;
-    if (!attr && smem > 48 * 1024) {
-        CWM_HIP_CHECK(hipFuncSetAttribute((const void*)attention_pipe_kernel<PLANES, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
+    if (smem > 48 * 1024)
+        if (int rc = cwm_set_max_lds((const void*)attention_pipe_kernel<PLANES, NW>, (int)smem)) return rc;
     hipLaunchKernelGGL((attention_pipe_kernel<PLANES, NW>), grid, dim3(64 * NW), smem, stream, p);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;

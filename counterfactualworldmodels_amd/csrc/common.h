@@ -54,6 +54,14 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// Sum over each aligned group of 8 consecutive lanes (every lane of the group gets the total): DPP only, no LDS round trip.
+__device__ __forceinline__ float group8_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    return v;
+}
+
 // XCD-aware bijective remap of a linear workgroup id (guide §5.5 T1): blocks b and b+8 share an
 // XCD under round-robin dispatch, so give every XCD a contiguous chunk of the logical tile order.
 // Speed only; any placement is correct.
@@ -69,6 +77,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // ---- host-side error plumbing (C ABI never throws) ------------------------------------------
 void cwm_set_error(const char* fmt, ...);
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel, once per (device, kernel): the attribute is per device, so a process-wide
+// "done" flag would leave a second device without it (engine.hip; thread-safe).  Returns 0 or CWM_ERR_HIP.
+int cwm_set_max_lds(const void* kernel, int bytes);
 
 #define CWM_HIP_CHECK(expr)                                                                  \
     do {                                                                                     \

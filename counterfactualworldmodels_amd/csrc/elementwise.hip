@@ -77,6 +77,7 @@ int launch_layernorm(const LayerNormParams& p, int planes, hipStream_t stream) {
     CWM_REQUIRE(p.D % 4 == 0 && p.D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", p.D);
     CWM_REQUIRE(p.ldx % 4 == 0 && p.ldo % 4 == 0, "layernorm: row strides must be multiples of 4");
     const int blocks = (p.rows + 3) / 4;
+    if (g_gemm_debug & 8) return 0;  // ablation (cwm_debug_set "gemm_debug" bit 3): what the step would cost without any LayerNorm launch
     if (planes == 1)
         hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, stream, p);
     else
@@ -219,29 +220,58 @@ int launch_patch_gather(const PatchGatherParams& p, int planes, hipStream_t stre
 // decoder input, masked half: x_full[b][n_vis + j] = mask_token + pos[perm[b][n_vis + j]]
 // (vmae.py:556-557).  The visible half is written by the encoder_to_decoder GEMM epilogue.
 // ---------------------------------------------------------------------------------------------
+template <int PLANES>
 __global__ __launch_bounds__(256) void fill_mask_tokens_kernel(float* x_full, const float* mask_token, const float* pos,
-                                                                const int* perm, int Nt, int n_vis, int D, int64_t total4) {
+                                                                const int* perm, int Nt, int n_vis, int D, int64_t total4, bf16* split,
+                                                                float2* stats) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total4) return;
+    const bool live = gid < total4;  // (no early return: the 8-lane sums below need every lane of a live group, and D % 32 == 0 keeps groups whole)
     const int d4 = D / 4;
-    const int64_t row = gid / d4;
-    const int c4 = (int)(gid - row * d4);
+    const int64_t row = live ? gid / d4 : 0;
+    const int c4 = live ? (int)(gid - row * d4) : 0;
     const int nm = Nt - n_vis;
     const int b = (int)(row / nm), j = (int)(row - (int64_t)b * nm);
-    const int tau = perm[(size_t)b * Nt + n_vis + j];
-    const float4 mt = *reinterpret_cast<const float4*>(mask_token + c4 * 4);
-    const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)tau * D + c4 * 4);
-    float4 o = make_float4(mt.x + pe.x, mt.y + pe.y, mt.z + pe.z, mt.w + pe.w);
-    *reinterpret_cast<float4*>(x_full + ((size_t)b * Nt + n_vis + j) * D + c4 * 4) = o;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t orow = (size_t)b * Nt + n_vis + j;
+    if (live) {
+        const int tau = perm[(size_t)b * Nt + n_vis + j];
+        const float4 mt = *reinterpret_cast<const float4*>(mask_token + c4 * 4);
+        const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)tau * D + c4 * 4);
+        o = make_float4(mt.x + pe.x, mt.y + pe.y, mt.z + pe.z, mt.w + pe.w);
+        *reinterpret_cast<float4*>(x_full + orow * D + c4 * 4) = o;
+    }
+    if (split) {  // the same rows as GEMM A operand + their per-32-column (sum, sum of squares): LayerNorm folded into the next GEMM
+        const float ps = group8_sum((o.x + o.y) + (o.z + o.w));
+        const float pq = group8_sum(fmaf(o.x, o.x, o.y * o.y) + fmaf(o.z, o.z, o.w * o.w));
+        if (live) {
+            const float v[4] = {o.x, o.y, o.z, o.w};
+            bf16x4 hv, lv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bf16 hi = (bf16)v[e];
+                hv[e] = hi;
+                lv[e] = (bf16)(v[e] - (float)hi);
+            }
+            bf16* d = split + a_pos<PLANES>(orow, D, c4 * 4);
+            *reinterpret_cast<bf16x4*>(d) = hv;
+            if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(d + kLoOffset) = lv;
+            if ((c4 & 7) == 0) stats[orow * (D / 32) + (c4 >> 3)] = make_float2(ps, pq);
+        }
+    }
 }
 
 int launch_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt,
-                            int n_vis, int D, hipStream_t stream) {
+                            int n_vis, int D, hipStream_t stream, bf16* split, float2* stats, int planes) {
     CWM_REQUIRE(D % 4 == 0, "fill_mask_tokens: D must be a multiple of 4");
+    CWM_REQUIRE(!split || (stats && D % 32 == 0), "fill_mask_tokens: split rows need a stats buffer and D %% 32 == 0");
     const int64_t total4 = (int64_t)B * (Nt - n_vis) * (D / 4);
     if (total4 == 0) return 0;
-    hipLaunchKernelGGL(fill_mask_tokens_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, x_full,
-                       mask_token, pos, perm, Nt, n_vis, D, total4);
+    if (planes == 2)
+        hipLaunchKernelGGL(fill_mask_tokens_kernel<2>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, x_full, mask_token, pos, perm,
+                           Nt, n_vis, D, total4, split, stats);
+    else
+        hipLaunchKernelGGL(fill_mask_tokens_kernel<1>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, x_full, mask_token, pos, perm,
+                           Nt, n_vis, D, total4, split, stats);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }

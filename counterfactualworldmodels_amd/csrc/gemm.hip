@@ -35,7 +35,7 @@ namespace cwm {
 //   256x256, 2x4 waves (128x64 per wave) : 128 KiB LDS, one 512-thread workgroup / CU -- highest FLOP per staged byte
 // The LDS fill (LDS-DMA pieces of 8 rows x 128 B) is the scarce resource (~25 B/clk/CU measured), so bigger
 // tiles raise the MFMA ceiling: per K tile a workgroup stages (BM+BN)*128 B and runs BM*BN/256*{2|3} MFMAs.
-template <int PLANES, int BM, int BN, int WM, int WN>
+template <int PLANES, int BM, int BN, int WM, int WN, bool SPREAD = false, int FUSE = 0>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void gemm_bf16_kernel(const GemmParams p) {
     constexpr int NWAVES = WM * WN;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
@@ -95,6 +95,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
         for (int jj = 0; jj < NIB; ++jj)
             __builtin_amdgcn_global_load_lds((gbl_void*)(wb + w_src[jj]), (lds_void*)(sb + A_BYTES + (wave * NIB + jj) * 1024), 16, 0, 0);
     };
+    // piece q of the NIA + NIB pieces this wave stages per K tile (SPREAD: issued one by one between the MFMA groups of the tile
+    // being computed -- a burst of LDS-DMA instructions holds the wave ~60-150 cycles each with nothing queued on the matrix pipe)
+    auto issue_piece = [&](int stage, int k0, int q) {
+        char* sb = smem + stage * STAGE_BYTES;
+        if (q < NIA)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(p.A + k0 + a_src[q]), (lds_void*)(sb + (wave * NIA + q) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gbl_void*)(p.W + k0 + w_src[q - NIA]), (lds_void*)(sb + A_BYTES + (wave * NIB + q - NIA) * 1024), 16, 0, 0);
+    };
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         __syncthreads();  // hipcc drains vmcnt before the barrier: tile t has landed; stage cur^1 is free
-        if (t + 1 < nk) issue_tile(cur ^ 1, (t + 1) * 64);  // 64 elements = 128 bytes per tile row
+        if (!SPREAD && t + 1 < nk) issue_tile(cur ^ 1, (t + 1) * 64);  // 64 elements = 128 bytes per tile row
         const char* base = smem + cur * STAGE_BYTES;
         // Software-pipelined fragment reads: a "unit" is one 16-row A fragment (hi[, lo]) against all FN column
         // fragments = FN (fast) / 3 FN (parity) MFMAs.  The A fragments of unit u+DIST are requested before the
@@ -157,6 +166,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
                 }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][0][j], afu[u][0], acc[i][j], 0, 0, 0);
             }
+            if constexpr (SPREAD) {
+                constexpr int PER_UNIT = (NIA + NIB + UNITS - 1) / UNITS;
+                if (t + 1 < nk) {
+#pragma unroll
+                    for (int q = u * PER_UNIT; q < (u + 1) * PER_UNIT && q < NIA + NIB; ++q) issue_piece(cur ^ 1, (t + 1) * 64, q);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -169,10 +185,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
     }
     if (p.staged) {
         __syncthreads();  // every wave is done with the operand tiles: LDS becomes the epilogue's staging space
-        int2* tab = reinterpret_cast<int2*>(smem + NWAVES * 8192);
-        epilogue_row_table(p, tab, m0, BM, tid);
+        int4* tab = reinterpret_cast<int4*>(smem + NWAVES * 8192);
+        epilogue_row_table<FUSE>(p, tab, m0, BM, n0, BN, tid);
         __syncthreads();
-        epilogue_staged<PLANES, FM, FN>(p, acc, smem + wave * 8192, tab, wr * (16 * FM), n0 + wc * (16 * FN), lane);
+        epilogue_staged<PLANES, FM, FN, FUSE>(p, acc, smem + wave * 8192, tab, wr * (16 * FM), n0 + wc * (16 * FN), lane, BM, n0, BN);
     } else {
         epilogue_rows<PLANES, FM, FN>(p, acc, m0, n0, wr, wc, lane);
     }
@@ -226,7 +242,7 @@ int gemm_prof_dump() { return -1; }
 #define GEMM_PROF_END() do {} while (0)
 #endif
 
-template <int PLANES>
+template <int PLANES, int FUSE = 0>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
     GEMM_PROF_BEGIN();
     constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 128 B
@@ -401,12 +417,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
     GEMM_PROF_MAIN();
     if (p.staged) {
         // (the balancing barrier above is also the point where every wave is done reading the operand tiles)
-        int2* tab = reinterpret_cast<int2*>(smem + 8 * 8192);
-        epilogue_row_table(p, tab, m0, 256, tid);
+        int4* tab = reinterpret_cast<int4*>(smem + 8 * 8192);
+        epilogue_row_table<FUSE>(p, tab, m0, 256, n0, 256, tid);
         __syncthreads();
-        epilogue_piece_seq<PLANES, 4>(
+        epilogue_piece_seq<PLANES, 4, FUSE>(
             p, [&](int pi, int i, int j) { return acc[pi >> 1][pi & 1][i][j]; }, [&](int pi) { return (pi >> 1) * 128 + wr * 64; },
-            [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, smem + wave * 8192, tab, lane);
+            [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, smem + wave * 8192, tab, lane, 256, n0, 256);
         GEMM_PROF_END();
         return;
     }
@@ -451,16 +467,15 @@ bool gemm_mixed_split(const GemmParams& p, GemmParams* big, GemmParams* rest) {
     return true;
 }
 
-// One launch with a given tile configuration (1 .. 5), after launch_gemm's argument checks
-int launch_gemm_tile(const GemmParams& p_in, int planes, int cfg, hipStream_t stream) {
-    const int saved = g_gemm_tile;
-    g_gemm_tile = cfg;
-    const int rc = launch_gemm(p_in, planes, stream);
-    g_gemm_tile = saved;
-    return rc;
-}
+static int launch_gemm_checked(const GemmParams& p_in, int planes, int forced_cfg, hipStream_t stream);
 
-// Tile configuration for a launch: g_gemm_tile if set, else per shape.
+// One launch with a given tile configuration (1 .. 5), after launch_gemm's argument checks.  (The configuration is an explicit
+// argument all the way down: no process-global is touched, so forwards on two host threads cannot race on it.)
+int launch_gemm_tile(const GemmParams& p_in, int planes, int cfg, hipStream_t stream) { return launch_gemm_checked(p_in, planes, cfg, stream); }
+
+int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) { return launch_gemm_checked(p_in, planes, 0, stream); }
+
+// Tile configuration for a launch: g_gemm_tile (development switch) if set, else per shape.
 int gemm_choose_tile(const GemmParams& p, int planes) {
     (void)planes;
     int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase, 5: stream-K 8-phase, 6: 4 + 1 by rows
@@ -494,7 +509,7 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
     return cfg;
 }
 
-int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) {
+static int launch_gemm_checked(const GemmParams& p_in, int planes, int forced_cfg, hipStream_t stream) {
     GemmParams p = p_in;
     p.debug = g_gemm_debug;
     CWM_REQUIRE(planes == 1 || planes == 2, "gemm: planes must be 1 or 2");
@@ -511,6 +526,12 @@ int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) {
         CWM_REQUIRE(p.ldo % 4 == 0, "gemm: ldo must be a multiple of 4");
         CWM_REQUIRE(planes == 1 || p.ldo % 32 == 0, "gemm: split-bf16 output rows are whole [32 hi | 32 lo] blocks: ldo=%d must be a multiple of 32", p.ldo);
     }
+    if (p.ln_stats || p.split_out) {
+        CWM_REQUIRE(g_gemm_staged, "gemm: the LayerNorm-fold epilogues exist in the LDS-staged form only");
+        CWM_REQUIRE(!p.ln_stats || (p.ln_colsum && p.ln_np > 0), "gemm: ln_stats needs ln_colsum and ln_np");
+        CWM_REQUIRE(!p.split_out || (p.epi == EPI_F32 && p.stats_out && p.N % 32 == 0 && p.split_ld % 32 == 0),
+                    "gemm: split rows need the fp32 epilogue, a stats buffer and N, split_ld multiples of 32 (N=%d)", p.N);
+    }
     // ---- LDS-staged epilogue whenever its 16-byte row segments are aligned (always, for the predictor's widths) ----
     p.staged = 0;
     if (g_gemm_staged) {
@@ -518,7 +539,12 @@ int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) {
         else if (p.epi == EPI_QKV) p.staged = (p.qkv_dim % 32 == 0 && p.head_dim % 32 == 0);
         else p.staged = (p.ldo % 8 == 0);
     }
-    int cfg = gemm_choose_tile(p, planes);
+    // LDS-DMA source addresses are 32-bit element offsets from the operand base pointers (one VGPR per piece): the operands must stay
+    // below 2^32 elements (parity-mode fc2 of ViT-L/4 reaches that at batch ~165: chunk M on the host beyond it)
+    CWM_REQUIRE((int64_t)(p.m_offset + p.M) * p.lda * planes < (1ll << 32) && (int64_t)(((p.N + 255) / 256) * 256) * p.K * planes < (1ll << 32),
+                "gemm: operand too large for 32-bit element offsets (M=%d lda=%d N=%d K=%d planes=%d): split the batch", p.m_offset + p.M, p.lda,
+                p.N, p.K, planes);
+    int cfg = forced_cfg > 0 ? forced_cfg : gemm_choose_tile(p, planes);
     if (cfg == 6) {
         GemmParams a, b;
         if (gemm_mixed_split(p, &a, &b)) {
@@ -532,21 +558,33 @@ int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) {
 
 static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t stream) {
     typedef void (*kern_t)(const GemmParams);
+    const int fuse = (p.ln_stats ? 1 : 0) | (p.split_out ? 2 : 0);  // LayerNorm-fold consumer / split producer (kernels.h)
     if (cfg == 5) {
-        if (sk_shape_ok(p.M, p.N, p.K, planes, sk_grid_size())) return launch_gemm_sk(p, planes, stream);
-        cfg = 1;  // too few tiles for one span per CU
+        if (!fuse && sk_shape_ok(p.M, p.N, p.K, planes, sk_grid_size())) return launch_gemm_sk(p, planes, stream);
+        cfg = fuse ? 4 : 1;  // too few tiles for one span per CU / the stream-K kernel has no LayerNorm-fold epilogue
     }
+    if (fuse && (cfg == 2 || cfg == 3)) cfg = 4;
+    if (fuse == 3) cfg = 1;  // consumer AND producer (encoder_to_decoder): only the 128x128 kernel has the registers for both
     if (cfg == 4) {
-        static const kern_t k8[2] = {gemm8p_kernel<1>, gemm8p_kernel<2>};
-        static bool attr8[2] = {false, false};
+        static const kern_t k8[3][2] = {{gemm8p_kernel<1>, gemm8p_kernel<2>}, {gemm8p_kernel<1, 1>, gemm8p_kernel<2, 1>}, {gemm8p_kernel<1, 2>, gemm8p_kernel<2, 2>}};
         const size_t smem8 = 2 * 4 * 128 * 128;
-        kern_t k = k8[planes - 1];
-        if (!attr8[planes - 1]) {
-            CWM_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
-            attr8[planes - 1] = true;
-        }
+        kern_t k = k8[fuse][planes - 1];
+        if (int rc = cwm_set_max_lds((const void*)k, (int)smem8)) return rc;
         const int tiles8 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         hipLaunchKernelGGL(k, dim3(tiles8), dim3(512), smem8, stream, p);
+        CWM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    static const kern_t spread128[2] = {gemm_bf16_kernel<1, 128, 128, 2, 2, true>, gemm_bf16_kernel<2, 128, 128, 2, 2, true>};
+    static const kern_t fuse128[3][2] = {{gemm_bf16_kernel<1, 128, 128, 2, 2, false, 1>, gemm_bf16_kernel<2, 128, 128, 2, 2, false, 1>},
+                                         {gemm_bf16_kernel<1, 128, 128, 2, 2, false, 2>, gemm_bf16_kernel<2, 128, 128, 2, 2, false, 2>},
+                                         {gemm_bf16_kernel<1, 128, 128, 2, 2, false, 3>, gemm_bf16_kernel<2, 128, 128, 2, 2, false, 3>}};
+    if (fuse || (cfg == 1 && (g_gemm_debug & 4))) {
+        // (LayerNorm-fold launches take the 128x128 kernel whenever the 8-phase kernel was not chosen)
+        const size_t smem = (size_t)2 * (128 + 128) * 128;
+        kern_t k = fuse ? fuse128[fuse - 1][planes - 1] : spread128[planes - 1];
+        if (int rc = cwm_set_max_lds((const void*)k, (int)smem)) return rc;
+        hipLaunchKernelGGL(k, dim3(((p.M + 127) / 128) * ((p.N + 127) / 128)), dim3(256), smem, stream, p);
         CWM_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -556,15 +594,11 @@ static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t strea
         {gemm_bf16_kernel<1, 256, 256, 2, 4>, gemm_bf16_kernel<2, 256, 256, 2, 4>},
     };
     static const int bms[3] = {128, 256, 256}, bns[3] = {128, 128, 256}, threads[3] = {256, 512, 512};
-    static bool attr_done[3][2] = {{false, false}, {false, false}, {false, false}};
     const int ci = cfg - 1;
     const size_t smem = (size_t)2 * (bms[ci] + bns[ci]) * 128;
     const int tiles = ((p.M + bms[ci] - 1) / bms[ci]) * ((p.N + bns[ci] - 1) / bns[ci]);
     kern_t k = kerns[ci][planes - 1];
-    if (!attr_done[ci][planes - 1]) {
-        CWM_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done[ci][planes - 1] = true;
-    }
+    if (int rc = cwm_set_max_lds((const void*)k, (int)smem)) return rc;
     hipLaunchKernelGGL(k, dim3(tiles), dim3(threads[ci]), smem, stream, p);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;

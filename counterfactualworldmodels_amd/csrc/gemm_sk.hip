@@ -572,14 +572,10 @@ int launch_gemm_sk(GemmParams& p, int planes, hipStream_t stream) {
     static const kern_t ks[2][4] = {
         {gemm_sk_kernel<1, EPI_F32>, gemm_sk_kernel<1, EPI_BF16_GELU>, gemm_sk_kernel<1, EPI_BF16>, gemm_sk_kernel<1, EPI_QKV>},
         {gemm_sk_kernel<2, EPI_F32>, gemm_sk_kernel<2, EPI_BF16_GELU>, gemm_sk_kernel<2, EPI_BF16>, gemm_sk_kernel<2, EPI_QKV>}};
-    static bool attr[2][4] = {{false, false, false, false}, {false, false, false, false}};
     CWM_REQUIRE(p.epi >= 0 && p.epi < 4, "gemm_sk: bad epilogue kind %d", p.epi);
     const size_t smem = 2 * 4 * 128 * 128 + 8 * 32 * 128;  // ring + piece buffers = 160 KiB
     kern_t k = ks[planes - 1][p.epi];
-    if (!attr[planes - 1][p.epi]) {
-        CWM_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr[planes - 1][p.epi] = true;
-    }
+    if (int rc = cwm_set_max_lds((const void*)k, (int)smem)) return rc;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, p);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;

@@ -48,6 +48,20 @@ struct GemmParams {
     unsigned* sk_flags;  // [grid] slab published in launch `sk_epoch`
     unsigned* sk_err;    // set to 1 if a hand-off wait timed out
     unsigned sk_epoch;
+    // ---- LayerNorm folded into the GEMMs around it (engine.hip run_block) ----
+    // consumer (qkv, fc1, encoder_to_decoder, head): A is the split of the RAW residual rows and W carries the LayerNorm weight
+    // (W' = W diag(gamma)); the epilogue turns acc = x W'^T into LN(x) W^T + b = r (acc - mu * colsum) + bias', with the row
+    // statistics reduced from the producer's partial sums.  ln_stats == nullptr: plain GEMM.
+    const float2* ln_stats;  // [A rows][ln_np] partial (sum, sum of squares) over 32-column slices of the row
+    int ln_np;
+    const float* ln_colsum;  // [N] sum_k W'[n][k] of the packed (rounded) weights
+    float ln_inv_d, ln_eps;
+    // producer (patch embed, proj, fc2, encoder_to_decoder; EPI_F32 only): besides C also writes the rows in the A-operand
+    // layout of the next GEMM and their partial statistics.  split_out == nullptr: off.
+    bf16* split_out;         // [split rows][split_ld] (x 2, hi/lo interleaved, in parity mode)
+    int split_ld;
+    float2* stats_out;       // [split rows][N / 32]
+    int split_rows_per_b;    // split row = b * split_rows_per_b + tok (rows_in > 0), else the A row; ignored when ln_stats is set (= out row)
     int staged;  // set by launch_gemm: epilogue through LDS with full-line global accesses (gemm.hip)
     int overlapped;  // set by the engine: the launch runs beside another lane's kernels, so a partly filled last round of workgroups is not lost
     int debug;  // development ablations (cwm_debug_set "gemm_debug"): bit 0 skip the epilogue's global stores, bit 1 skip the epilogue
@@ -123,8 +137,10 @@ struct PatchGatherParams {
 int launch_patch_gather(const PatchGatherParams& p, int planes, hipStream_t stream);
 
 // x_full[b][n_vis + j][:] = mask_token + pos[perm[b][n_vis + j]]   (vmae.py:556-557)
+// split / stats (optional): the same rows in the A-operand layout of the mode + their (sum, sum of squares) partials per
+// 32-column slice, as the GEMM producers write them (LayerNorm folded into the consuming GEMM)
 int launch_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt,
-                            int n_vis, int D, hipStream_t stream);
+                            int n_vis, int D, hipStream_t stream, bf16* split = nullptr, float2* stats = nullptr, int planes = 2);
 
 struct UnembedParams {
     const float* y;  // [B][Nm][P*P*C], feature order (ph, pw, c)

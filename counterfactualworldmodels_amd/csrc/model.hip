@@ -22,15 +22,21 @@ struct cwm_model {
     bf16* patches = nullptr;
     float *x_enc = nullptr, *x_dec = nullptr;
     StreamBuffers sb;
+    bf16* xsplit[2] = {nullptr, nullptr};   // [0] encoder stream, [1] decoder stream (LayerNorm fold, engine.h StreamBuffers)
+    float2* xstats[2] = {nullptr, nullptr};
+    int stats_per_lane_row = 0;
     // batch lanes (cwm_model_set_lanes): a batch whose halves keep >= kMinLaneRows encoder rows runs as two half batches, the first on the
     // caller's stream and the second on `lane_stream`, joined by events before cwm_forward returns control of the stream
     int lanes = 2;
-    hipStream_t lane_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static constexpr int kMaxLanes = 4;
+    hipStream_t lane_stream[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
     ~cwm_model() {
-        if (lane_stream) (void)hipStreamDestroy(lane_stream);
+        for (auto s : lane_stream)
+            if (s) (void)hipStreamDestroy(s);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
+        for (auto e : ev_join)
+            if (e) (void)hipEventDestroy(e);
     }
 };
 
@@ -41,6 +47,8 @@ struct LaneWs {
     bf16* patches;
     float *x_enc, *x_dec;
     StreamBuffers sb;
+    bf16* xsplit[2];
+    float2* xstats[2];
 };
 constexpr int kMinLaneRows = 6000;  // encoder rows (batch elements x visible tokens) a lane must have: below, the GEMM grids no longer fill the chip
 
@@ -62,6 +70,10 @@ int ensure_workspace(cwm_model* m, int B, int n_vis) {
         (rc = E.ws(&m->sb.kbuf, 2 * act)))
         return rc;
     if ((rc = E.ws(&m->sb.vbuf, 2 * act))) return rc;
+    // LayerNorm fold: residual rows in operand layout + partial statistics, one set per token stream (encoder / decoder)
+    m->stats_per_lane_row = std::max(c.enc_dim, c.dec_dim) / 32;
+    for (int i = 0; i < 2; ++i)
+        if ((rc = E.ws(&m->xsplit[i], 2 * act)) || (rc = E.ws(&m->xstats[i], std::max(rows_e, rows_d) * m->stats_per_lane_row))) return rc;
     m->ws_batch = Bc;
     m->ws_nvis = Nv;
     return 0;
@@ -84,6 +96,10 @@ LaneWs lane_ws(const cwm_model* m, int lane, int b0) {
     w.sb.qbuf += 2 * act;
     w.sb.kbuf += 2 * act;
     w.sb.vbuf += 2 * act;
+    for (int i = 0; i < 2; ++i) {
+        w.xsplit[i] = m->xsplit[i] + 2 * act;
+        w.xstats[i] = m->xstats[i] + std::max(rows_e, rows_d) * m->stats_per_lane_row;
+    }
     return w;
 }
 
@@ -106,6 +122,7 @@ extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
     m->cfg = c;
     Engine& E = m->eng;
     E.ln_eps = c.ln_eps;
+    E.enable_folds = (c.enc_dim % 64 == 0 && c.dec_dim % 64 == 0);
     CWM_HIP_CHECK(hipGetDevice(&E.device));
     m->n_per_frame = (c.img_h / c.patch) * (c.img_w / c.patch);
     m->Nt = m->n_per_frame * c.num_frames;
@@ -127,6 +144,7 @@ extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
         E.add_vec_slot("encoder.norm.bias", m->enc_norm_b, {c.enc_dim});
         if ((rc = E.make_linear(m->e2d, c.dec_dim, c.enc_dim, false))) break;
         E.add_matrix_slot("encoder_to_decoder.weight", &m->e2d, {c.dec_dim, c.enc_dim});
+        if (c.enc_dim % 64 == 0 && c.dec_dim % 64 == 0 && (rc = E.set_fold(m->e2d, m->enc_norm_g, m->enc_norm_b))) break;  // encoder.norm folds in
         if ((rc = E.make_vec(&m->mask_token, c.dec_dim))) break;
         E.add_vec_slot("mask_token", m->mask_token, {1, 1, c.dec_dim});
         for (int i = 0; i < c.dec_depth && !rc; ++i)
@@ -137,6 +155,7 @@ extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
         E.add_vec_slot("decoder.norm.bias", m->dec_norm_b, {c.dec_dim});
         if ((rc = E.make_linear(m->head, m->out_dim, c.dec_dim, true))) break;
         E.add_matrix_slot("decoder.head.weight", &m->head, {m->out_dim, c.dec_dim});
+        if (m->e2d.raw && (rc = E.set_fold(m->head, m->dec_norm_g, m->dec_norm_b))) break;  // decoder.norm folds into the head
         E.add_vec_slot("decoder.head.bias", m->head.bias, {m->out_dim});
         if ((rc = E.make_sinusoid(&m->pos_enc, m->Nt, c.enc_dim))) break;  // vmae.py:75
         if ((rc = E.make_sinusoid(&m->pos_dec, m->Nt, c.dec_dim))) break;  // vmae.py:366
@@ -159,6 +178,10 @@ extern "C" int cwm_model_load_weight(cwm_model* m, const char* key, const float*
 extern "C" int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen) { return m->eng.missing_weights(buf, buflen); }
 
 static int g_prune_last_block = 1;
+// LayerNorm folded into the GEMMs around it (engine.h).  Implemented, parity-tested and selectable (cwm_debug_set "ln_fuse" = 1), but NOT
+// the default: measured on MI355X the extra 4 bytes/element a producer GEMM must store (its rows in operand layout) inside its
+// store-bound epilogue cost as much as the LayerNorm launch they replace (B/8 batch 32: +75 us per block vs 64 us).
+static int g_ln_fuse = 0;
 
 // One lane: batch elements [b0, b0 + B) of the call, on stream s, in the workspace slice w.
 static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, LaneWs w, hipStream_t s) {
@@ -184,39 +207,60 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
     pg.out = w.patches; pg.out_plane = (int64_t)B * Nv * m->patch_kpad; pg.ld = m->patch_kpad;
     if ((rc = launch_patch_gather(pg, planes, s))) return rc;
 
+    // LayerNorm folded into the GEMMs around it (engine.h): no LayerNorm launch anywhere on the path.  Needs the LDS-staged epilogues.
+    const bool fold = g_ln_fuse && g_gemm_staged && m->e2d.raw != nullptr;
+    StreamBuffers sb_enc = w.sb, sb_dec = w.sb;
+    if (fold) {
+        sb_enc.xsplit = w.xsplit[0]; sb_enc.xstats = w.xstats[0];
+        sb_dec.xsplit = w.xsplit[1]; sb_dec.xstats = w.xstats[1];
+    }
     GemmParams g = gemm_base(w.patches, m->patch_kpad, m->patch, B * Nv, planes);
     g.epi = EPI_F32; g.C = w.x_enc; g.ldc = c.enc_dim;
     g.resid = m->pos_enc; g.ldr = c.enc_dim; g.resid_rowmap = w.perm; g.rows_in = Nv; g.rows_out = Nv; g.map_stride = Nt;
+    if (fold) { g.split_out = sb_enc.xsplit; g.split_ld = c.enc_dim; g.stats_out = sb_enc.xstats; g.split_rows_per_b = Nv; }
     if ((rc = E.run_gemm(g, planes, s))) return rc;
 
     // a4-a6: encoder blocks over the visible tokens
     for (int i = 0; i < c.enc_depth; ++i)
-        if ((rc = E.run_block(m->enc[i], w.x_enc, B, Nv, c.enc_dim, c.enc_heads, planes, w.sb, s))) return rc;
+        if ((rc = E.run_block(m->enc[i], w.x_enc, B, Nv, c.enc_dim, c.enc_heads, planes, sb_enc, s))) return rc;
 
     // a7: encoder.norm, encoder_to_decoder (no bias); a8: + pos[vis] written straight into x_full rows [0,Nv)
     LayerNormParams ln;
-    memset(&ln, 0, sizeof(ln));
-    ln.x = w.x_enc; ln.ldx = c.enc_dim; ln.gamma = m->enc_norm_g; ln.beta = m->enc_norm_b; ln.eps = c.ln_eps; ln.D = c.enc_dim;
-    ln.rows = B * Nv; ln.out = w.sb.hbuf; ln.out_plane = (int64_t)B * Nv * c.enc_dim; ln.ldo = c.enc_dim;
-    if ((rc = launch_layernorm(ln, planes, s))) return rc;
-    g = gemm_base(w.sb.hbuf, c.enc_dim, m->e2d, B * Nv, planes);
+    if (fold) {
+        g = E.fold_gemm(sb_enc.xsplit, sb_enc.xstats, m->e2d, B * Nv, planes);
+        g.split_out = sb_dec.xsplit; g.split_ld = c.dec_dim; g.stats_out = sb_dec.xstats;  // (split row = out row for a fold consumer)
+    } else {
+        memset(&ln, 0, sizeof(ln));
+        ln.x = w.x_enc; ln.ldx = c.enc_dim; ln.gamma = m->enc_norm_g; ln.beta = m->enc_norm_b; ln.eps = c.ln_eps; ln.D = c.enc_dim;
+        ln.rows = B * Nv; ln.out = w.sb.hbuf; ln.out_plane = (int64_t)B * Nv * c.enc_dim; ln.ldo = c.enc_dim;
+        if ((rc = launch_layernorm(ln, planes, s))) return rc;
+        g = gemm_base(w.sb.hbuf, c.enc_dim, m->e2d, B * Nv, planes);
+    }
     g.epi = EPI_F32; g.C = w.x_dec; g.ldc = c.dec_dim;
     g.resid = m->pos_dec; g.ldr = c.dec_dim; g.resid_rowmap = w.perm; g.rows_in = Nv; g.rows_out = Nt; g.map_stride = Nt;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
-    if (Nm > 0 && (rc = launch_fill_mask_tokens(w.x_dec, m->mask_token, m->pos_dec, w.perm, B, Nt, Nv, c.dec_dim, s))) return rc;
+    if (Nm > 0 && (rc = launch_fill_mask_tokens(w.x_dec, m->mask_token, m->pos_dec, w.perm, B, Nt, Nv, c.dec_dim, s, fold ? sb_dec.xsplit : nullptr,
+                                                fold ? sb_dec.xstats : nullptr, planes)))
+        return rc;
 
     // a9: decoder blocks over the full token set, norm + head on the last Nm tokens
     // (the last block only has to produce the Nm rows the head reads: debug key "prune_last_block" = 0 runs it in full)
+    const bool pruned = Nm > 0 && g_prune_last_block;
     for (int i = 0; i < c.dec_depth; ++i) {
-        const int keep = (i == c.dec_depth - 1 && Nm > 0 && g_prune_last_block) ? Nm : 0;
-        if ((rc = E.run_block(m->dec[i], w.x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, w.sb, s, keep))) return rc;
+        const int keep = (i == c.dec_depth - 1 && pruned) ? Nm : 0;
+        if ((rc = E.run_block(m->dec[i], w.x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, sb_dec, s, keep))) return rc;
     }
-    memset(&ln, 0, sizeof(ln));
-    ln.x = w.x_dec; ln.ldx = c.dec_dim; ln.gamma = m->dec_norm_g; ln.beta = m->dec_norm_b; ln.eps = c.ln_eps; ln.D = c.dec_dim;
-    ln.rows = B * Nret; ln.rows_out_per_b = Nret; ln.rows_in_per_b = Nt; ln.in_offset = Nt - Nret;
-    ln.out = w.sb.hbuf; ln.out_plane = (int64_t)B * Nret * c.dec_dim; ln.ldo = c.dec_dim;
-    if ((rc = launch_layernorm(ln, planes, s))) return rc;
-    g = gemm_base(w.sb.hbuf, c.dec_dim, m->head, B * Nret, planes);
+    if (fold && (pruned || Nm == 0)) {
+        // the last block left exactly the B * Nret rows the head reads, compact, in operand layout: decoder.norm folds into the head GEMM
+        g = E.fold_gemm(sb_dec.xsplit, sb_dec.xstats, m->head, B * Nret, planes);
+    } else {
+        memset(&ln, 0, sizeof(ln));
+        ln.x = w.x_dec; ln.ldx = c.dec_dim; ln.gamma = m->dec_norm_g; ln.beta = m->dec_norm_b; ln.eps = c.ln_eps; ln.D = c.dec_dim;
+        ln.rows = B * Nret; ln.rows_out_per_b = Nret; ln.rows_in_per_b = Nt; ln.in_offset = Nt - Nret;
+        ln.out = w.sb.hbuf; ln.out_plane = (int64_t)B * Nret * c.dec_dim; ln.ldo = c.dec_dim;
+        if ((rc = launch_layernorm(ln, planes, s))) return rc;
+        g = gemm_base(w.sb.hbuf, c.dec_dim, m->head, B * Nret, planes);
+    }
     g.epi = EPI_F32; g.C = y_tokens; g.ldc = m->out_dim;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
 
@@ -254,39 +298,45 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     }
     if (int rc = ensure_workspace(m, B, Nv)) return rc;
     hipStream_t s = (hipStream_t)a->stream;
+    if (int rc = m->eng.finalize_folds(s)) return rc;  // (before the lanes fork: they wait on an event recorded after it)
 
-    // Two lanes: between two dependent kernels the queue idles ~6 us (x 136 kernels = 5 % of a batch-32 step) and every kernel ends in a
-    // partially filled round of workgroups; a second, independent half batch on another queue fills both.
-    const bool two = m->lanes >= 2 && B >= 2 && (int64_t)(B / 2) * Nv >= kMinLaneRows;
-    const int B0 = two ? (B + 1) / 2 : B;
+    // Batch lanes: between two dependent kernels the queue idles ~6 us (x 136 kernels = 5 % of a batch-32 step) and every kernel ends in a
+    // partially filled round of workgroups; further, independent slices of the batch on other queues fill both.
     int n_lanes = 1;
+    while (n_lanes < m->lanes && n_lanes < B && (int64_t)(B / (n_lanes + 1)) * Nv >= kMinLaneRows) ++n_lanes;
+    const bool two = n_lanes >= 2;
+    int first[cwm_model::kMaxLanes + 1];
+    for (int l = 0; l <= n_lanes; ++l) first[l] = (int)(((int64_t)B * l + n_lanes - 1) / n_lanes);  // lane l owns batch elements [first[l], first[l+1])
     if (two) {
-        if (!m->lane_stream) {
-            CWM_HIP_CHECK(hipStreamCreateWithFlags(&m->lane_stream, hipStreamNonBlocking));
-            CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-            CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+        if (!m->ev_fork) CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+        CWM_HIP_CHECK(hipEventRecord(m->ev_fork, s));  // inputs written on the caller's stream are complete for the other lanes
+        for (int l = 1; l < n_lanes; ++l) {
+            if (!m->lane_stream[l - 1]) {
+                CWM_HIP_CHECK(hipStreamCreateWithFlags(&m->lane_stream[l - 1], hipStreamNonBlocking));
+                CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join[l - 1], hipEventDisableTiming));
+            }
+            CWM_HIP_CHECK(hipStreamWaitEvent(m->lane_stream[l - 1], m->ev_fork, 0));
         }
-        CWM_HIP_CHECK(hipEventRecord(m->ev_fork, s));  // inputs written on the caller's stream are complete for the second lane
-        CWM_HIP_CHECK(hipStreamWaitEvent(m->lane_stream, m->ev_fork, 0));
-        n_lanes = 2;
     }
     m->eng.overlapped = two;
-    int rc = forward_lane(m, a, 0, B0, lane_ws(m, 0, 0), s);
-    if (two) {
-        const int rc1 = rc ? rc : forward_lane(m, a, B0, B - B0, lane_ws(m, 1, B0), m->lane_stream);
-        m->eng.overlapped = 0;
-        // join even after a failed launch: the caller's stream must not run ahead of work already queued on the lane
-        CWM_HIP_CHECK(hipEventRecord(m->ev_join, m->lane_stream));
-        CWM_HIP_CHECK(hipStreamWaitEvent(s, m->ev_join, 0));
-        rc = rc1;
+    int rc = 0;
+    // launch order: one lane after the other (each lane's ~136 launches are queued before the next lane's; the queues drain concurrently)
+    for (int l = 0; l < n_lanes; ++l) {
+        if (!rc) rc = forward_lane(m, a, first[l], first[l + 1] - first[l], lane_ws(m, l, first[l]), l == 0 ? s : m->lane_stream[l - 1]);
+    }
+    m->eng.overlapped = 0;
+    // join even after a failed launch: the caller's stream must not run ahead of work already queued on a lane
+    for (int l = 1; l < n_lanes; ++l) {
+        CWM_HIP_CHECK(hipEventRecord(m->ev_join[l - 1], m->lane_stream[l - 1]));
+        CWM_HIP_CHECK(hipStreamWaitEvent(s, m->ev_join[l - 1], 0));
     }
     if (rc) return rc;
 
     if (a->check) {
-        int herr[2] = {0, 0};
+        int herr[cwm_model::kMaxLanes] = {0, 0, 0, 0};
         CWM_HIP_CHECK(hipMemcpyAsync(herr, m->err, n_lanes * sizeof(int), hipMemcpyDeviceToHost, s));
         CWM_HIP_CHECK(hipStreamSynchronize(s));
-        if (herr[0] || herr[1]) {
+        if (herr[0] || herr[1] || herr[2] || herr[3]) {
             cwm_set_error("mask rows do not all have n_vis=%d visible tokens (shape '[%d, -1, %d]' is invalid for the gathered input)", Nv, B,
                           c.enc_dim);
             return CWM_ERR_MASK;
@@ -296,7 +346,7 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
 }
 
 extern "C" int cwm_model_set_lanes(cwm_model* m, int lanes) {
-    CWM_REQUIRE(m && (lanes == 1 || lanes == 2), "cwm_model_set_lanes: lanes must be 1 or 2");
+    CWM_REQUIRE(m && lanes >= 1 && lanes <= cwm_model::kMaxLanes, "cwm_model_set_lanes: lanes must be 1 .. %d", cwm_model::kMaxLanes);
     m->lanes = lanes;
     return CWM_OK;
 }
@@ -562,6 +612,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
         g_prune_last_block = value;
         return CWM_OK;
     }
+    if (!strcmp(key, "ln_fuse")) {
+        g_ln_fuse = value;
+        return CWM_OK;
+    }
     if (!strcmp(key, "attn_kernel")) {
         g_attn_kernel = value;
         return CWM_OK;
@@ -583,6 +637,9 @@ extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters,
     CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_bench_gemm: bad mode");
     const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
     const int Kp = round_up(K, 64), Np = round_up(N, 256);
+    // epi + 10: the LayerNorm-fold form of the same epilogue (0 -> split producer, 1 / 3 -> fold consumer)
+    const bool fold = epi >= 10;
+    epi = epi % 10;
     Scratch sc;
     bf16* A = sc.get<bf16>((size_t)2 * M * Kp);
     bf16* W = sc.get<bf16>((size_t)2 * Np * Kp);
@@ -591,11 +648,15 @@ extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters,
     bf16* G = sc.get<bf16>((size_t)2 * M * N + 64 * 1024);
     bf16* G2 = sc.get<bf16>((size_t)2 * M * N + 64 * 1024);
     bf16* G3 = sc.get<bf16>((size_t)2 * M * N + 64 * 1024 * 64);
-    CWM_REQUIRE(A && W && bias && Cm && G && G2 && G3, "cwm_bench_gemm: out of device memory");
+    float2* stats = sc.get<float2>((size_t)M * (std::max(N, Kp) / 32 + 1));
+    float* colsum = sc.get<float>(Np);
+    CWM_REQUIRE(A && W && bias && Cm && G && G2 && G3 && stats && colsum, "cwm_bench_gemm: out of device memory");
     fill_bf16(A, (int64_t)2 * M * Kp, 1, 1.0f);
     fill_bf16(W, (int64_t)2 * Np * Kp, 2, 0.05f);
     fill_f32(bias, Np, 3, 0.1f);
     fill_f32(Cm, (int64_t)M * N, 4, 1.0f);
+    fill_f32((float*)stats, (int64_t)2 * M * (std::max(N, Kp) / 32 + 1), 5, 1.0f);
+    fill_f32(colsum, Np, 6, 0.1f);
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = Kp; p.W = W;
@@ -605,11 +666,19 @@ extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters,
     } else if (epi == 3) {
         CWM_REQUIRE(N % 192 == 0, "cwm_bench_gemm: QKV epilogue needs N = 3*64*heads");
         const int D = N / 3, H = D / 64, n_tok = 792 <= M && M % 792 == 0 ? 792 : M, B = M / n_tok;
+        (void)B;
         p.epi = EPI_QKV; p.rows_in = n_tok; p.rows_out = n_tok; p.map_stride = n_tok;
         p.q_out = G; p.k_out = G2; p.v_out = G3; p.qk_plane = (int64_t)M * D;
         p.qkv_dim = D; p.heads = H; p.head_dim = 64; p.n_tok = n_tok; p.q_scale = 0.125f;
     } else {
         p.epi = EPI_F32; p.C = Cm; p.ldc = N; p.resid = Cm; p.ldr = N;
+    }
+    if (fold) {
+        if (epi == 0) {
+            p.split_out = G; p.split_ld = N; p.stats_out = stats;
+        } else {
+            p.ln_stats = stats; p.ln_np = Kp / 32; p.ln_colsum = colsum; p.ln_inv_d = 1.0f / Kp; p.ln_eps = 1e-6f;
+        }
     }
     hipEvent_t e0, e1;
     CWM_HIP_CHECK(hipEventCreate(&e0));
@@ -626,6 +695,59 @@ extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters,
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *avg_us = 1e3 * ms / iters;
+    return CWM_OK;
+}
+
+// One wave idling for `us` microseconds (100 MHz s_memrealtime): a low-power gap between two launches of the duty-cycle probe.
+__global__ void idle_kernel(int us) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(64);
+}
+
+// Duty-cycle probe (tools/power_probe.py): `iters` launches of one GEMM with an idle gap of gap_us after each; returns the mean
+// duration of the GEMM launches alone (one HIP event pair per launch, the first quarter discarded as warm-up).
+extern "C" int cwm_bench_gemm_gapped(int M, int N, int K, int mode, int epi, int iters, int gap_us, double* avg_us) {
+    CWM_REQUIRE(avg_us && M > 0 && N > 0 && K > 0 && iters >= 4 && gap_us >= 0, "cwm_bench_gemm_gapped: bad argument");
+    const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
+    const int Kp = round_up(K, 64), Np = round_up(N, 256);
+    Scratch sc;
+    bf16* A = sc.get<bf16>((size_t)2 * M * Kp);
+    bf16* W = sc.get<bf16>((size_t)2 * Np * Kp);
+    float* bias = sc.get<float>(Np);
+    float* Cm = sc.get<float>((size_t)M * N);
+    bf16* G = sc.get<bf16>((size_t)2 * M * N + 64 * 1024);
+    CWM_REQUIRE(A && W && bias && Cm && G, "cwm_bench_gemm_gapped: out of device memory");
+    fill_bf16(A, (int64_t)2 * M * Kp, 1, 1.0f);
+    fill_bf16(W, (int64_t)2 * Np * Kp, 2, 0.05f);
+    fill_f32(bias, Np, 3, 0.1f);
+    fill_f32(Cm, (int64_t)M * N, 4, 1.0f);
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = Kp; p.W = W;
+    p.M = M; p.N = N; p.K = Kp; p.bias = bias;
+    if (epi == 1) {
+        p.epi = EPI_BF16_GELU; p.out_hi = G; p.ldo = N;
+    } else {
+        p.epi = EPI_F32; p.C = Cm; p.ldc = N; p.resid = Cm; p.ldr = N;
+    }
+    std::vector<hipEvent_t> ev(2 * iters);
+    for (auto& e : ev) CWM_HIP_CHECK(hipEventCreate(&e));
+    for (int i = 0; i < iters; ++i) {
+        CWM_HIP_CHECK(hipEventRecord(ev[2 * i], 0));
+        if (int rc = launch_gemm(p, planes, 0)) return rc;
+        CWM_HIP_CHECK(hipEventRecord(ev[2 * i + 1], 0));
+        if (gap_us > 0) hipLaunchKernelGGL(idle_kernel, dim3(1), dim3(64), 0, 0, gap_us);
+    }
+    CWM_HIP_CHECK(hipDeviceSynchronize());
+    double tot = 0;
+    int n = 0;
+    for (int i = iters / 4; i < iters; ++i, ++n) {
+        float ms = 0.f;
+        CWM_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        tot += ms;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    *avg_us = 1e3 * tot / n;
     return CWM_OK;
 }
 

@@ -244,10 +244,15 @@ int cwm_allreduce_sum_f32(cwm_comm* c, float* buf_dev, size_t count, void* strea
  * Runs `iters` back-to-back launches after 3 warm-up launches and returns the mean launch time. */
 int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters, double* avg_us);
 int cwm_bench_attention(int B, int H, int N, int mode, int iters, double* avg_us);
-/* development switches: "gemm_tile" (0 automatic per shape, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase,
+/* duty-cycle probe: the same GEMM with an idle gap of gap_us after every launch; mean duration of the GEMM launches alone
+ * (is the chip's clock under MFMA load set by the instantaneous or by the time-averaged power?  tools/power_probe.py) */
+int cwm_bench_gemm_gapped(int M, int N, int K, int mode, int epi, int iters, int gap_us, double* avg_us);
+/* development switches (PROCESS-WIDE, not per model handle: for tests and measurements, never for production use -- a second
+ * model in the same process sees the same values): "gemm_tile" (0 automatic per shape, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase,
  * 5: persistent stream-K 8-phase, 6: 8-phase rounds + 128x128 remainder rows), "gemm_staged" (0: direct per-fragment epilogue),
  * "gemm_debug" (epilogue ablations), "attn_kernel" (0 automatic, 1: 4-wave, 2: staggered 8-wave, 3: software-pipelined 4-wave),
- * "prune_last_block" (0: run the last decoder block over all tokens); queries: "sk_error" (non-zero return = a stream-K hand-off
+ * "prune_last_block" (0: run the last decoder block over all tokens), "ln_fuse" (1: LayerNorm folded into the GEMMs around it instead of the
+ * stand-alone LayerNorm kernels -- measured slower, off by default); queries: "sk_error" (non-zero return = a stream-K hand-off
  * wait timed out), "attn_prof" / "gemm_prof" (per-workgroup timers of builds with -DCWM_ATTN_PROF / -DCWM_GEMM_PROF) */
 int cwm_debug_set(const char* key, int value);
 
