@@ -33,9 +33,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qcol = lane & 31, hh = lane >> 5;
     const int N = p.n_tok;
-    const int bh = blockIdx.y;
+    int qt, bh;
+    attn_tile_of_block(p.n_q > 0 ? p.n_q : p.n_tok, 128, p.remap != 0, qt, bh);
     const int b = bh / p.heads, h = bh - b * p.heads;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qt * 128 + wave * 32;
     // a wave whose 32 query rows all lie past the sequence end (N = 792: three of the 28 wave slots per head) only helps to
     // stage the K / V tiles: its MFMA / softmax work is skipped, leaving the matrix pipe to the co-resident workgroup
     const int NQ = p.n_q > 0 ? p.n_q : p.n_tok;  // queries are rows [q_off, q_off + NQ) (last decoder block: the masked tokens only)
@@ -555,7 +556,11 @@ __global__ __launch_bounds__(512, 2) void attention8_kernel(const AttnParams p) 
 
 int g_attn_kernel = 0;  // 0 auto, 1: 4-wave kernel, 2: 8-wave staggered kernel, 3: software-pipelined kernel (attention_pipe.hip)
 
-int launch_attention(const AttnParams& p, int planes, hipStream_t stream) {
+int g_attn_remap = 1;
+
+int launch_attention(const AttnParams& p_in, int planes, hipStream_t stream) {
+    AttnParams p = p_in;
+    p.remap = g_attn_remap;
     CWM_REQUIRE(planes == 1 || planes == 2, "attention: planes must be 1 or 2");
     CWM_REQUIRE(p.n_tok > 0 && p.batch > 0 && p.heads > 0, "attention: empty problem");
     CWM_REQUIRE(p.ldo % 4 == 0, "attention: ldo must be a multiple of 4");

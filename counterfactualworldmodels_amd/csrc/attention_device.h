@@ -7,6 +7,29 @@
 
 namespace cwm {
 
+// Query tile / (batch, head) of this workgroup for a grid of (nqb, nbh) workgroups of `rows` query rows.  Speed only -- the mapping
+// is a bijection, any placement is correct:
+//  * all query tiles of one (batch, head) go to ONE XCD (workgroups are dealt round-robin over the 8 XCDs by their linear id), so its
+//    K / V tiles are fetched into one L2 instead of up to eight (ViT-B/8 encoder: 7 tiles per head, 405 KB of K / V per head)
+//  * inside an XCD the ragged last query tile of every head (N = 792: 24 of 128 rows, one active wave) is dispatched after all full
+//    tiles, so that those light workgroups fill the tail of the launch instead of being spread through it
+__device__ __forceinline__ void attn_tile_of_block(int nq, int rows, bool remap, int& qt, int& bh) {
+    const int nqb = gridDim.x, nbh = gridDim.y;
+    qt = blockIdx.x;
+    bh = blockIdx.y;
+    if (nbh % 8 != 0 || !remap) return;
+    const int L = blockIdx.y * nqb + blockIdx.x, xcd = L & 7, idx = L >> 3, per = nbh >> 3;
+    const int light = (nqb > 1 && (nq - (nqb - 1) * rows) * 2 <= rows) ? 1 : 0;  // last tile at most half full
+    const int heavy = nqb - light;
+    if (idx < per * heavy) {
+        bh = xcd * per + idx / heavy;
+        qt = idx - (idx / heavy) * heavy;
+    } else {
+        bh = xcd * per + (idx - per * heavy);
+        qt = nqb - 1;
+    }
+}
+
 __device__ __forceinline__ int lds_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 // V tile image: key row of 128 bytes, 16-byte chunk c (8 d) stored at c ^ 4 on key rows with bit 1 set
 __device__ __forceinline__ int lds_off_v(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }

@@ -255,10 +255,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qcol = lane & 31, hh = lane >> 5;
     const int N = p.n_tok;
-    const int bh = blockIdx.y;
-    const int b = bh / p.heads, h = bh - b * p.heads;
-    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
     const int NQ = p.n_q > 0 ? p.n_q : N;
+    int qt, bh;
+    attn_tile_of_block(NQ, 32 * NW, p.remap != 0, qt, bh);
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const int q0 = qt * (32 * NW) + wave * 32;
     const bool active = q0 < NQ;  // idle waves (query rows past the end) only stage tiles and keep the barrier count
 
     const bf16* Qb = p.q + (size_t)bh * N * 64;

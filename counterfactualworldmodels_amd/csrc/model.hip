@@ -616,6 +616,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
         g_ln_fuse = value;
         return CWM_OK;
     }
+    if (!strcmp(key, "attn_remap")) {
+        g_attn_remap = value;
+        return CWM_OK;
+    }
     if (!strcmp(key, "attn_kernel")) {
         g_attn_kernel = value;
         return CWM_OK;

@@ -251,6 +251,7 @@ int cwm_bench_gemm_gapped(int M, int N, int K, int mode, int epi, int iters, int
  * model in the same process sees the same values): "gemm_tile" (0 automatic per shape, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase,
  * 5: persistent stream-K 8-phase, 6: 8-phase rounds + 128x128 remainder rows), "gemm_staged" (0: direct per-fragment epilogue),
  * "gemm_debug" (epilogue ablations), "attn_kernel" (0 automatic, 1: 4-wave, 2: staggered 8-wave, 3: software-pipelined 4-wave),
+ * "attn_remap" (0: plain workgroup order instead of one XCD per (batch, head) with the ragged query tiles last),
  * "prune_last_block" (0: run the last decoder block over all tokens), "ln_fuse" (1: LayerNorm folded into the GEMMs around it instead of the
  * stand-alone LayerNorm kernels -- measured slower, off by default); queries: "sk_error" (non-zero return = a stream-K hand-off
  * wait timed out), "attn_prof" / "gemm_prof" (per-workgroup timers of builds with -DCWM_ATTN_PROF / -DCWM_GEMM_PROF) */
