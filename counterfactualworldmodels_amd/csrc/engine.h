@@ -85,6 +85,11 @@ struct Engine {
     bool fold_dirty = false;       // a state-dict tensor was (re-)loaded since the folds were computed
     bool enable_folds = false;     // set by the model that runs the fused path BEFORE it creates its blocks (make_block)
     KernelTimer timers[CWM_KCLASS_COUNT];
+    struct SplitKWs {
+        float* slabs;
+        unsigned* counts;
+    };
+    std::map<hipStream_t, SplitKWs> splitk_ws;  // one split-K workspace per stream this engine launches on (batch lanes run concurrently)
 
     ~Engine();
     int alloc(void** p, size_t bytes, bool zero, bool workspace);

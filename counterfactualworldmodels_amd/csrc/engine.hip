@@ -365,6 +365,18 @@ static int timer_end(EventPair* e, hipStream_t s) {
 int Engine::run_gemm(const GemmParams& p_in, int planes, hipStream_t s) {
     GemmParams p = p_in;
     p.overlapped = overlapped;
+    if ((int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) <= 256) {  // a launch small enough for the split-K kernel: hand it this stream's workspace
+        auto it = splitk_ws.find(s);
+        if (it == splitk_ws.end()) {
+            SplitKWs w = {nullptr, nullptr};
+            if (int rc = splitk_workspace_alloc(&w.slabs, &w.counts)) return rc;
+            allocs.push_back(w.slabs);
+            allocs.push_back(w.counts);
+            it = splitk_ws.emplace(s, w).first;
+        }
+        p.sk2_slabs = it->second.slabs;
+        p.sk2_count = it->second.counts;
+    }
     const int cfg = gemm_choose_tile(p, planes);
     GemmParams part[2];
     int cfgs[2] = {cfg, 0}, nparts = 1;

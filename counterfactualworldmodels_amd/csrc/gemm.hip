@@ -35,7 +35,7 @@ namespace cwm {
 //   256x256, 2x4 waves (128x64 per wave) : 128 KiB LDS, one 512-thread workgroup / CU -- highest FLOP per staged byte
 // The LDS fill (LDS-DMA pieces of 8 rows x 128 B) is the scarce resource (~25 B/clk/CU measured), so bigger
 // tiles raise the MFMA ceiling: per K tile a workgroup stages (BM+BN)*128 B and runs BM*BN/256*{2|3} MFMAs.
-template <int PLANES, int BM, int BN, int WM, int WN, bool SPREAD = false, int FUSE = 0>
+template <int PLANES, int BM, int BN, int WM, int WN, int STAGES = 2, int FUSE = 0>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void gemm_bf16_kernel(const GemmParams p) {
     constexpr int NWAVES = WM * WN;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
@@ -58,7 +58,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;
-    const int id = xcd_remap(blockIdx.x, ntiles);
+    // split-K (deep-ring variants only): blockIdx.x = tile * splitk + part
+    const int nsplit = (STAGES > 2 && p.splitk > 1) ? p.splitk : 1;
+    const int part = (STAGES > 2) ? (int)blockIdx.x % nsplit : 0;
+    const int id = xcd_remap((STAGES > 2) ? (int)blockIdx.x / nsplit : (int)blockIdx.x, ntiles);
     constexpr int GROUP_M = (BM == 128) ? 8 : 4;
     const int group_sz = GROUP_M * tiles_n;
     const int g = id / group_sz;
@@ -95,16 +98,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
         for (int jj = 0; jj < NIB; ++jj)
             __builtin_amdgcn_global_load_lds((gbl_void*)(wb + w_src[jj]), (lds_void*)(sb + A_BYTES + (wave * NIB + jj) * 1024), 16, 0, 0);
     };
-    // piece q of the NIA + NIB pieces this wave stages per K tile (SPREAD: issued one by one between the MFMA groups of the tile
-    // being computed -- a burst of LDS-DMA instructions holds the wave ~60-150 cycles each with nothing queued on the matrix pipe)
-    auto issue_piece = [&](int stage, int k0, int q) {
-        char* sb = smem + stage * STAGE_BYTES;
-        if (q < NIA)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(p.A + k0 + a_src[q]), (lds_void*)(sb + (wave * NIA + q) * 1024), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds((gbl_void*)(p.W + k0 + w_src[q - NIA]), (lds_void*)(sb + A_BYTES + (wave * NIB + q - NIA) * 1024), 16, 0, 0);
-    };
-
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -122,12 +115,33 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
         b_base[half] = A_BYTES + lds_off<64>(wc * (16 * FN) + frow, half * 4 + fq);
     }
 
-    const int nk = p.K / BK;
-    issue_tile(0, 0);
+    const int nk_all = p.K / BK;
+    const int kt0 = (STAGES > 2) ? (int)((int64_t)nk_all * part / nsplit) : 0;           // this workgroup's K tiles: [kt0, kt0 + nk)
+    const int nk = (STAGES > 2) ? (int)((int64_t)nk_all * (part + 1) / nsplit) - kt0 : nk_all;
+    // STAGES == 2: double buffer, the co-resident second workgroup of the CU covers the staging latency.
+    // STAGES  > 2 (launches with fewer tiles than CUs, e.g. batch 1: ONE workgroup per CU and nothing to cover for it): a ring of
+    // STAGES K tiles with STAGES - 1 tiles of LDS-DMA in flight, counted vmcnt waits and raw barriers; a K tile then costs its MFMA
+    // time instead of a full L2 / HBM round trip (ViT-B/8 batch 1, fc2: 88 -> 40 us).
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < nk) issue_tile(st, (kt0 + st) * 64);
     for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        __syncthreads();  // hipcc drains vmcnt before the barrier: tile t has landed; stage cur^1 is free
-        if (!SPREAD && t + 1 < nk) issue_tile(cur ^ 1, (t + 1) * 64);  // 64 elements = 128 bytes per tile row
+        const int cur = STAGES == 2 ? (t & 1) : t % STAGES;
+        if constexpr (STAGES == 2) {
+            __syncthreads();  // hipcc drains vmcnt before the barrier: tile t has landed; stage cur^1 is free
+            if (t + 1 < nk) issue_tile(cur ^ 1, (t + 1) * 64);  // 64 elements = 128 bytes per tile row
+        } else {
+            // tiles t .. min(t + STAGES - 2, nk - 1) are in flight; tile t must have landed: allow the younger ones to stay outstanding
+            constexpr int PER = NIA + NIB;
+            const int younger = min(nk - 1 - t, STAGES - 2);
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();  // every wave's pieces of tile t have landed; every wave is done reading tile t - 1
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + STAGES - 1 < nk) issue_tile((t + STAGES - 1) % STAGES, (kt0 + t + STAGES - 1) * 64);  // into the stage tile t - 1 occupied
+        }
         const char* base = smem + cur * STAGE_BYTES;
         // Software-pipelined fragment reads: a "unit" is one 16-row A fragment (hi[, lo]) against all FN column
         // fragments = FN (fast) / 3 FN (parity) MFMAs.  The A fragments of unit u+DIST are requested before the
@@ -166,13 +180,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
                 }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][0][j], afu[u][0], acc[i][j], 0, 0, 0);
             }
-            if constexpr (SPREAD) {
-                constexpr int PER_UNIT = (NIA + NIB + UNITS - 1) / UNITS;
-                if (t + 1 < nk) {
-#pragma unroll
-                    for (int q = u * PER_UNIT; q < (u + 1) * PER_UNIT && q < NIA + NIB; ++q) issue_piece(cur ^ 1, (t + 1) * 64, q);
-                }
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -182,6 +189,50 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void g
 #pragma unroll
             for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
+    }
+    static_assert(STAGES <= 4, "the counted waits above cover at most 3 tiles in flight");
+    if constexpr (STAGES > 2) {
+        if (nsplit > 1) {
+            // ---- split-K: every part writes its fp32 accumulators to its slab; the part that arrives LAST adds all slabs of the tile
+            // in part order (its own included, read back: the sum does not depend on who was last -> deterministic) and runs the epilogue.
+            // Hand-off (MI355X guide, Guideline 16): plain stores -> every storing wave's vmcnt(0) -> workgroup barrier -> one lane:
+            // agent-scope release, returning agent-scope atomic add; last part: agent-scope acquire, vmcnt(0), barrier, plain loads.
+            const int tile_id = (int)blockIdx.x / nsplit;
+            float* slab = p.sk2_slabs + ((size_t)tile_id * nsplit + part) * (BM * BN) + (size_t)wave * (FM * FN * 256) + lane * 4;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4*>(slab + (i * FN + j) * 256) = acc[i][j];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(smem);  // (the operand ring is dead: every wave passed the barrier after its last MFMA)
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned prev = __hip_atomic_fetch_add(p.sk2_count + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool last = prev == (unsigned)(nsplit - 1);
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(p.sk2_count + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                }
+                *flag = last ? 1 : 0;
+            }
+            __syncthreads();
+            if (*flag == 0) return;
+            const float* base_slab = p.sk2_slabs + (size_t)tile_id * nsplit * (BM * BN) + (size_t)wave * (FM * FN * 256) + lane * 4;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = *reinterpret_cast<const f32x4*>(base_slab + (i * FN + j) * 256);
+            for (int q = 1; q < nsplit; ++q) {
+                const float* sl = base_slab + (size_t)q * (BM * BN);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(sl + (i * FN + j) * 256);
+            }
+        }
     }
     if (p.staged) {
         __syncthreads();  // every wave is done with the operand tiles: LDS becomes the epilogue's staging space
@@ -445,6 +496,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
         }
 }
 
+// Split-K workspace of the deep-ring kernel: kSplitKSlots fp32 slabs of one 128x128 tile + arrival counters (zeroed once; the kernel
+// leaves them at zero).  One workspace serves ONE stream at a time: the engine keeps one per stream it launches on (engine.hip).
+int splitk_workspace_alloc(float** slabs, unsigned** counts) {
+    CWM_HIP_CHECK(hipMalloc((void**)slabs, (size_t)kSplitKSlots * 128 * 128 * sizeof(float)));
+    CWM_HIP_CHECK(hipMalloc((void**)counts, kSplitKSlots * sizeof(unsigned)));
+    CWM_HIP_CHECK(hipMemset(*counts, 0, kSplitKSlots * sizeof(unsigned)));
+    return 0;
+}
+
 int g_gemm_tile = 0;  // 0 = automatic choice per shape
 static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t stream);
 int g_gemm_debug = 0;
@@ -575,16 +635,48 @@ static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t strea
         CWM_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    static const kern_t spread128[2] = {gemm_bf16_kernel<1, 128, 128, 2, 2, true>, gemm_bf16_kernel<2, 128, 128, 2, 2, true>};
-    static const kern_t fuse128[3][2] = {{gemm_bf16_kernel<1, 128, 128, 2, 2, false, 1>, gemm_bf16_kernel<2, 128, 128, 2, 2, false, 1>},
-                                         {gemm_bf16_kernel<1, 128, 128, 2, 2, false, 2>, gemm_bf16_kernel<2, 128, 128, 2, 2, false, 2>},
-                                         {gemm_bf16_kernel<1, 128, 128, 2, 2, false, 3>, gemm_bf16_kernel<2, 128, 128, 2, 2, false, 3>}};
-    if (fuse || (cfg == 1 && (g_gemm_debug & 4))) {
+    static const kern_t deep128[2] = {gemm_bf16_kernel<1, 128, 128, 2, 2, 4>, gemm_bf16_kernel<2, 128, 128, 2, 2, 4>};
+    static const kern_t deep128w8[2] = {gemm_bf16_kernel<1, 128, 128, 2, 4, 4>, gemm_bf16_kernel<2, 128, 128, 2, 4, 4>};  // 8 waves of 64x32
+    static const kern_t fuse128[3][2] = {{gemm_bf16_kernel<1, 128, 128, 2, 2, 2, 1>, gemm_bf16_kernel<2, 128, 128, 2, 2, 2, 1>},
+                                         {gemm_bf16_kernel<1, 128, 128, 2, 2, 2, 2>, gemm_bf16_kernel<2, 128, 128, 2, 2, 2, 2>},
+                                         {gemm_bf16_kernel<1, 128, 128, 2, 2, 2, 3>, gemm_bf16_kernel<2, 128, 128, 2, 2, 2, 3>}};
+    // 128x128 tiles, at most one workgroup per CU (fewer tiles than CUs): the 4-stage ring hides the staging latency that the second
+    // co-resident workgroup hides in bigger launches ("gemm_debug" bit 2 switches it off for A/B runs)
+    const int tiles128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
+    const bool deep = cfg == 1 && !fuse && !(g_gemm_debug & 4) && tiles128 <= cus;
+    p.splitk = 1;
+    if (deep && !(g_gemm_debug & 32)) {
+        // fill the idle CUs of a latency-bound launch by cutting K: only where it pays (measured, ViT-B/8 batch 1: fc2 65 -> 32 us with
+        // 6 parts, decoder fc2 36 -> 26 us; two parts of a K = 768 qkv projection LOSE 6 us to the hand-off) -- at least three parts of at
+        // least 12 K tiles each; the parts of a tile are reduced in a fixed order (deterministic)
+        const int nk_all = p.K / (64 / planes);
+        int sk = std::min(std::min(cus / tiles128, nk_all / 12), 8);
+        if (sk >= 3) {
+            if (!p.sk2_slabs) {
+                // callers without a workspace of their own (the stand-alone entry points: one stream, one thread at a time)
+                static float* slabs = nullptr;
+                static unsigned* counts = nullptr;
+                static int slabs_dev = -1;
+                int dev = 0;
+                CWM_HIP_CHECK(hipGetDevice(&dev));
+                if (!slabs || slabs_dev != dev) {
+                    if (int rc = splitk_workspace_alloc(&slabs, &counts)) return rc;
+                    slabs_dev = dev;
+                }
+                p.sk2_slabs = slabs;
+                p.sk2_count = counts;
+            }
+            p.splitk = sk;
+        }
+    }
+    if (fuse || deep) {
         // (LayerNorm-fold launches take the 128x128 kernel whenever the 8-phase kernel was not chosen)
-        const size_t smem = (size_t)2 * (128 + 128) * 128;
-        kern_t k = fuse ? fuse128[fuse - 1][planes - 1] : spread128[planes - 1];
+        const size_t smem = (size_t)(deep ? 4 : 2) * (128 + 128) * 128;
+        const bool w8 = deep && !(g_gemm_debug & 16);  // 8 waves of 64x32 (two per SIMD cover each other's LDS / barrier latency); bit 4: 4 waves
+        kern_t k = fuse ? fuse128[fuse - 1][planes - 1] : w8 ? deep128w8[planes - 1] : deep128[planes - 1];
         if (int rc = cwm_set_max_lds((const void*)k, (int)smem)) return rc;
-        hipLaunchKernelGGL(k, dim3(((p.M + 127) / 128) * ((p.N + 127) / 128)), dim3(256), smem, stream, p);
+        hipLaunchKernelGGL(k, dim3(tiles128 * p.splitk), dim3(w8 ? 512 : 256), smem, stream, p);
         CWM_HIP_CHECK(hipGetLastError());
         return 0;
     }

@@ -62,11 +62,17 @@ struct GemmParams {
     int split_ld;
     float2* stats_out;       // [split rows][N / 32]
     int split_rows_per_b;    // split row = b * split_rows_per_b + tok (rows_in > 0), else the A row; ignored when ln_stats is set (= out row)
+    // split-K of the latency-bound small launches (gemm.hip, deep-ring 128x128 kernel); filled in by launch_gemm
+    int splitk;              // K is cut into this many ranges, one workgroup each (1: off)
+    float* sk2_slabs;        // [tiles * splitk][128 * 128] fp32 partial accumulators
+    unsigned* sk2_count;     // [tiles] arrival counters (0 between launches)
     int staged;  // set by launch_gemm: epilogue through LDS with full-line global accesses (gemm.hip)
     int overlapped;  // set by the engine: the launch runs beside another lane's kernels, so a partly filled last round of workgroups is not lost
     int debug;  // development ablations (cwm_debug_set "gemm_debug"): bit 0 skip the epilogue's global stores, bit 1 skip the epilogue
 };
 
+constexpr int kSplitKSlots = 512;  // >= CUs: a split launch has at most one part per CU
+int splitk_workspace_alloc(float** slabs, unsigned** counts);
 int launch_gemm(const GemmParams& p, int planes, hipStream_t stream);
 int gemm_choose_tile(const GemmParams& p, int planes);
 bool gemm_mixed_split(const GemmParams& p, GemmParams* big, GemmParams* rest);  // tile configuration 6

@@ -220,6 +220,7 @@ def test_gemm_8phase_is_bitwise_equal_to_simple_kernel_under_repetition(gu):
     lib = _lib.get_lib()
     shapes = [(256, 256, 64), (300, 272, 128), (1000, 1152, 192), (513, 512, 384), (2049, 768, 768), (4096, 1024, 3072)]
     try:
+        _lib.check(lib.cwm_debug_set(b"gemm_debug", 32))  # (no split-K in the reference kernel: a split re-associates the fp32 sums)
         for mode in ("parity", "fast"):
             for (M, N, K) in shapes:
                 a, w, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13)
@@ -231,6 +232,39 @@ def test_gemm_8phase_is_bitwise_equal_to_simple_kernel_under_repetition(gu):
                     assert torch.equal(out, ref), (mode, M, N, K, rep, (out - ref).abs().max().item())
     finally:
         _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
+        _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
+
+
+def test_gemm_deep_ring_and_split_k_small_launches(gu):
+    """Launches with fewer 128x128 tiles than CUs (batch 1) run the 4-stage-ring kernel (8 waves, counted vmcnt) and, for long K, split K
+    over the idle CUs with a last-arriver reduction in fixed part order: bit-identical to the double-buffered kernel without a split,
+    deterministic under repetition with it (a stale slab or a re-staged tile read too early shows up as a mismatch), every epilogue."""
+    lib = _lib.get_lib()
+    shapes = [(792, 768, 3072), (1568, 384, 1536), (792, 2304, 768), (300, 272, 2048), (130, 48, 4096), (1000, 256, 64)]
+    try:
+        for mode in ("parity", "fast"):
+            for (M, N, K) in shapes:
+                a, w, b, r = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5), rnd(N, seed=33), rnd(M, N, seed=34)
+                _lib.check(lib.cwm_debug_set(b"gemm_tile", 1))
+                _lib.check(lib.cwm_debug_set(b"gemm_debug", 4))          # double-buffered kernel, no deep ring, no split
+                ref = (gu.linear(a, w, b, resid=r, mode=mode), gu.linear(a, w, b, gelu=True, mode=mode))
+                _lib.check(lib.cwm_debug_set(b"gemm_debug", 32))         # deep ring (8 waves), no split: same product sequence
+                for rep in range(3):
+                    out = (gu.linear(a, w, b, resid=r, mode=mode), gu.linear(a, w, b, gelu=True, mode=mode))
+                    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), (mode, M, N, K, rep)
+                _lib.check(lib.cwm_debug_set(b"gemm_debug", 32 + 16))    # deep ring, 4 waves
+                out = (gu.linear(a, w, b, resid=r, mode=mode), gu.linear(a, w, b, gelu=True, mode=mode))
+                assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), (mode, M, N, K, "4 waves")
+                _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))          # default: + split-K where the heuristic takes it
+                first = (gu.linear(a, w, b, resid=r, mode=mode), gu.linear(a, w, b, gelu=True, mode=mode))
+                for rep in range(6):
+                    out = (gu.linear(a, w, b, resid=r, mode=mode), gu.linear(a, w, b, gelu=True, mode=mode))
+                    assert torch.equal(out[0], first[0]) and torch.equal(out[1], first[1]), (mode, M, N, K, rep, "split-K not deterministic")
+                assert (first[0] - ref[0]).abs().max().item() <= (2e-5 if mode == "parity" else 2e-3), (mode, M, N, K)
+                assert (first[0] - (F.linear(a, w, b) + r)).abs().max().item() <= TOL[mode]
+    finally:
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
+        _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
 
 
 @pytest.mark.parametrize("tile", [1, 3, 4])

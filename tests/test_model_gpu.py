@@ -119,7 +119,8 @@ def test_bench_batch_properties():
     yp = m(xp[perm], mask[perm], n_vis=792)
     assert (yp - y[perm]).abs().max().item() <= 1e-5  # batch-permutation equivariance
     ys = m(xp[5:6], mask[5:6], n_vis=792)
-    assert (ys - y[5:6]).abs().max().item() <= 1e-5   # batch-size invariance
+    # batch-size invariance (batch 1 takes other GEMM tilings and splits the long-K GEMMs over idle CUs: fp32 sums re-associate)
+    assert (ys - y[5:6]).abs().max().item() <= 5e-5
 
 
 def test_error_behaviour():
@@ -246,11 +247,13 @@ def test_nothing_masked_returns_all_tokens():
 def test_last_decoder_block_pruning_is_exact():
     """The last decoder block computes queries / proj / MLP only for the Nm rows the head reads (vmae.py:250-251 discards the rest):
     outputs are bit-identical to running the block in full, for the tiny model and for B/8 (both modes).  (Bitwise with the stand-alone
-    LayerNorm kernels; with the LayerNorm fold the un-pruned run normalises its non-compact final rows with the stand-alone kernel,
-    so there the two agree to rounding.)"""
+    LayerNorm kernels and without split-K -- the pruned GEMMs have fewer rows, so the small-launch heuristic may split K differently and
+    re-associate the fp32 sums; with the LayerNorm fold the un-pruned run normalises its non-compact final rows with the stand-alone
+    kernel.  In those configurations the two agree to rounding.)"""
     lib = _lib.get_lib()
     cases = [(TINY, "tiny_8x8_k4.npz"), (C.CONFIGS["base_8x8patch_2frames_1tube"], "base8_k8_b2.npz")]
     try:
+        _lib.check(lib.cwm_debug_set(b"gemm_debug", 32))
         for cfg, name in cases:
             g = np.load(os.path.join(GOLDEN, name))
             seed, x, mask = case_inputs(g, cfg)
@@ -268,9 +271,22 @@ def test_last_decoder_block_pruning_is_exact():
                         assert torch.equal(outs[0], outs[1]), (name, mode, diff)
                     else:
                         assert diff <= (1e-4 if mode == "parity" else 3e-2), (name, mode, diff)
+        _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
+        _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
+        for cfg, name in cases:  # library defaults (split-K where the heuristic takes it): equal to rounding
+            g = np.load(os.path.join(GOLDEN, name))
+            seed, x, mask = case_inputs(g, cfg)
+            m = build(cfg, seed, "parity")
+            G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+            outs = []
+            for prune in (1, 0):
+                _lib.check(lib.cwm_debug_set(b"prune_last_block", prune))
+                outs.append(m(G._preprocess(x.cuda()), mask.cuda()).cpu())
+            assert (outs[0] - outs[1]).abs().max().item() <= 5e-5
     finally:
         _lib.check(lib.cwm_debug_set(b"prune_last_block", 1))
         _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
+        _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
 
 
 def test_two_lanes_match_one_lane_and_report_mask_errors_of_both():

@@ -7,13 +7,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from counterfactualworldmodels_amd import _lib  # noqa: E402
-from tools.microbench import GEMM_SHAPES, MID_SHAPES, L4_SHAPES  # noqa: E402
+from tools.microbench import GEMM_SHAPES, MID_SHAPES, L4_SHAPES, B1_SHAPES  # noqa: E402
 
 torch.cuda.init()
 lib = _lib.get_lib()
 us = C.c_double()
 variants = [tuple(int(x) for x in v.split(":")) for v in os.environ.get("VARIANTS", "0:0,1:0,1:4,4:0").split(",")]
-shapes = {"b8": GEMM_SHAPES, "mid": MID_SHAPES, "l4": L4_SHAPES}[os.environ.get("SHAPES", "b8")]
+shapes = {"b8": GEMM_SHAPES, "mid": MID_SHAPES, "l4": L4_SHAPES, "b1": B1_SHAPES}[os.environ.get("SHAPES", "b8")]
 modes = os.environ.get("MODES", "parity").split(",")
 for name, M, N, K, epi in shapes:
     for mode in modes:

@@ -47,6 +47,16 @@ L4_SHAPES = [
     ("l4.dec.fc1", 50176, 2048, 512, 1),
     ("l4.dec.fc2", 50176, 512, 2048, 0),
 ]
+B1_SHAPES = [  # ViT-B/8 at batch 1 (latency-bound launches: fewer tiles than CUs)
+    ("b1.enc.qkv", 792, 2304, 768, 3),
+    ("b1.enc.proj", 792, 768, 768, 0),
+    ("b1.enc.fc1", 792, 3072, 768, 1),
+    ("b1.enc.fc2", 792, 768, 3072, 0),
+    ("b1.dec.qkv", 1568, 1152, 384, 3),
+    ("b1.dec.proj", 1568, 384, 384, 0),
+    ("b1.dec.fc1", 1568, 1536, 384, 1),
+    ("b1.dec.fc2", 1568, 384, 1536, 0),
+]
 ATTN_SHAPES = [("b8.enc", 32, 12, 792), ("b8.dec", 32, 6, 1568), ("l4.enc", 8, 16, 3168), ("l4.dec", 8, 8, 6272)]
 
 
