@@ -311,8 +311,8 @@ def main():
     }
     planes = 2 if args.mode == "parity" else 1
     kernels = {
-        "cwm::gemm8p_kernel<%d>" % planes: gemm_wide,                       # 256x256 8-phase: qkv, fc1
-        "cwm::gemm_bf16_kernel<%d, 128, 128, 2, 2>" % planes: gemm_narrow,  # proj, fc2, head, patch embed
+        "cwm::gemm8p_kernel<%d, 0>" % planes: gemm_wide,                           # 256x256 8-phase: encoder qkv, fc1, fc2 rounds
+        "cwm::gemm_bf16_kernel<%d, 128, 128, 2, 4, 2, 0>" % planes: gemm_narrow,  # 128x128, 8 waves: proj, every K < 512 GEMM, remainders
     }
 
     def tflops(st):

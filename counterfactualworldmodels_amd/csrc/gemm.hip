@@ -36,7 +36,7 @@ namespace cwm {
 // The LDS fill (LDS-DMA pieces of 8 rows x 128 B) is the scarce resource (~25 B/clk/CU measured), so bigger
 // tiles raise the MFMA ceiling: per K tile a workgroup stages (BM+BN)*128 B and runs BM*BN/256*{2|3} MFMAs.
 template <int PLANES, int BM, int BN, int WM, int WN, int STAGES = 2, int FUSE = 0>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 == 256) ? 2 : 2) void gemm_bf16_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN == 8 && STAGES == 2) ? 4 : 2) void gemm_bf16_kernel(const GemmParams p) {
     constexpr int NWAVES = WM * WN;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     // every K tile row is one 128-byte line in LDS and in memory: 64 k of the single plane (fast), or
@@ -549,8 +549,10 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
         //    short-K launches (proj of B/8), which stay on 128x128 tiles with two workgroups per CU
         //  * N < 512 or ragged narrow N (N = 384, head, patch embed): 128x128
         // (The persistent stream-K form (5) is never selected: it is no faster than (6) and its split tiles re-associate fp32 sums.)
+        //  * K < 512 (the B/8 decoder: K = 384): the 8-wave 128x128 kernel wins at every batch (its epilogues overlap the co-resident
+        //    workgroup's main loop, and with 12 K tiles the epilogue is a third of a 256x256 tile's time): qkv 150 -> 136 us, fc1 214 -> 208
         cfg = 1;
-        if (p.M >= 512 && (p.N >= 1024 || (p.N >= 512 && p.N % 256 == 0))) {
+        if (p.K >= 512 && p.M >= 512 && (p.N >= 1024 || (p.N >= 512 && p.N % 256 == 0))) {
             const int64_t tiles = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
             const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
             if (tiles < cus) {
@@ -680,16 +682,28 @@ static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t strea
         CWM_HIP_CHECK(hipGetLastError());
         return 0;
     }
+    // cfg 1 = 128x128 tiles as 8-wave workgroups (64x32 per wave), two per CU = FOUR waves per SIMD: measured 5-25 % faster than the
+    // 4-wave form (two waves per SIMD) on every model shape -- the extra waves cover the per-K-tile barrier + LDS-DMA latency that the
+    // simple loop exposes ("gemm_debug" bit 6 selects the 4-wave form for A/B runs)
     static const kern_t kerns[3][2] = {
-        {gemm_bf16_kernel<1, 128, 128, 2, 2>, gemm_bf16_kernel<2, 128, 128, 2, 2>},
+        {gemm_bf16_kernel<1, 128, 128, 2, 4>, gemm_bf16_kernel<2, 128, 128, 2, 4>},
         {gemm_bf16_kernel<1, 256, 128, 4, 2>, gemm_bf16_kernel<2, 256, 128, 4, 2>},
         {gemm_bf16_kernel<1, 256, 256, 2, 4>, gemm_bf16_kernel<2, 256, 256, 2, 4>},
     };
-    static const int bms[3] = {128, 256, 256}, bns[3] = {128, 128, 256}, threads[3] = {256, 512, 512};
+    static const kern_t narrow4[2] = {gemm_bf16_kernel<1, 128, 128, 2, 2>, gemm_bf16_kernel<2, 128, 128, 2, 2>};
+    static const int bms[3] = {128, 256, 256}, bns[3] = {128, 128, 256};
+    int threads[3] = {512, 512, 512};
     const int ci = cfg - 1;
-    const size_t smem = (size_t)2 * (bms[ci] + bns[ci]) * 128;
+    // (8-wave 128x128 workgroups: the epilogue's eight 8-KiB wave buffers fill the 64-KiB operand ring; the row table sits behind them)
+    const size_t smem = (size_t)2 * (bms[ci] + bns[ci]) * 128 + (ci == 0 ? 4096 : 0);
     const int tiles = ((p.M + bms[ci] - 1) / bms[ci]) * ((p.N + bns[ci] - 1) / bns[ci]);
     kern_t k = kerns[ci][planes - 1];
+    if (ci == 0 && (g_gemm_debug & 64)) {
+        k = narrow4[planes - 1];
+        threads[0] = 256;
+    }
+    CWM_REQUIRE(smem >= (size_t)(threads[ci] / 64) * 8192 + (size_t)bms[ci] * 16 + (size_t)bns[ci] * 8,
+                "gemm: dynamic LDS too small for the staged epilogue (wave buffers + row table)");
     if (int rc = cwm_set_max_lds((const void*)k, (int)smem)) return rc;
     hipLaunchKernelGGL(k, dim3(tiles), dim3(threads[ci]), smem, stream, p);
     CWM_HIP_CHECK(hipGetLastError());

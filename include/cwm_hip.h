@@ -144,8 +144,8 @@ int cwm_conj_timing_collect(cwm_conj_model* m, int kclass, struct cwm_kernel_sta
 /* ---- timing hooks (bench.py roofline): HIP events around every launch of one kernel class ------ */
 #define CWM_KCLASS_GEMM 0        /* every GEMM launch */
 #define CWM_KCLASS_ATTENTION 1
-#define CWM_KCLASS_GEMM_WIDE 2   /* the GEMM launches that ran the 256x256 8-phase kernel (N >= 1024: qkv, fc1); enabled and */
-#define CWM_KCLASS_GEMM_NARROW 3 /* ... the 128x128 kernel (proj, fc2, head, patch embed)      collected together with class 0 */
+#define CWM_KCLASS_GEMM_WIDE 2   /* the GEMM launches that ran the 256x256 8-phase kernel (K >= 512, wide N: encoder qkv, fc1, fc2) */
+#define CWM_KCLASS_GEMM_NARROW 3 /* ... the 128x128 kernels (proj, K < 512, head, patch embed); both enabled / collected with class 0 */
 #define CWM_KCLASS_COUNT 4
 typedef struct cwm_kernel_stats {
     int64_t launches;
