@@ -216,7 +216,12 @@ def get_lib() -> C.CDLL:
                 except Exception as e:
                     raise RuntimeError("libcwm_hip.so at %s was built from other sources (%s != %s) and could not be rebuilt: %s"
                                        % (path, lib.cwm_source_hash().decode(), want, e))
-                lib = _bind(path)  # os.replace gave the file a new inode: this maps the new library
+                # the dynamic loader returns the already-mapped object for a path it knows: unmap the stale library first (nothing was
+                # created through it yet), then map the rebuilt file
+                import _ctypes
+
+                _ctypes.dlclose(lib._handle)
+                lib = _bind(path)
                 if lib.cwm_source_hash().decode() != want:
                     raise RuntimeError("libcwm_hip.so still does not match the sources after a rebuild")
         _lib = lib

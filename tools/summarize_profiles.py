@@ -23,6 +23,9 @@ for mode in ("parity", "fast", "parity_default"):
     f = one("stats_%s/runc/*kernel_stats.csv" % mode)
     if f:
         shutil.copy(f, os.path.join(dst, "%s_kernel_stats_bench_base8_%s.csv" % (tag, mode)))
+f = one("stats_b1/runc/*kernel_stats.csv")
+if f:
+    shutil.copy(f, os.path.join(dst, "%s_kernel_stats_latency_b1_parity.csv" % tag))
 
 
 def counters(d, kfilter):
@@ -38,7 +41,7 @@ def counters(d, kfilter):
     return agg, dur
 
 
-out = {"tag": tag, "command": "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --lanes 1 (parity mode, B/8 batch 32; *_parity_default.csv: the same without --lanes 1)"}
+out = {"tag": tag, "command": "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --no-prompts --lanes 1 (parity mode, B/8 batch 32; *_parity_default.csv: the same without --lanes 1)"}
 # HBM traffic of the GEMM kernels: FETCH_SIZE / WRITE_SIZE are in KiB-units of 1024 B; on gfx950 FETCH_SIZE reports
 # half of the bytes of a wide coalesced stream (MI355X_MICROARCH.md HBM section) -> doubled here.
 traffic = {}
