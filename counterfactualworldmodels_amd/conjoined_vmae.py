@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from .config import CONJ_CONFIGS, LN_EPS, ConjConfig, conj_state_dict_schema
+from .vmae import WeightSync
 
 
 class _Params(nn.Module):
@@ -54,7 +55,7 @@ def _build_tree(root: nn.Module, schema) -> None:
         node.register_parameter(parts[-1], p)
 
 
-class ConjoinedPaddedVisionTransformer(nn.Module):
+class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
     def __init__(self, cfg: ConjConfig, mode: str = "parity", **unused):
         super().__init__()
         self.cfg = cfg
@@ -86,6 +87,7 @@ class ConjoinedPaddedVisionTransformer(nn.Module):
         self._handle: Optional[int] = None
         self._handle_device: Optional[torch.device] = None
         self._loaded: Dict[str, Tuple[int, int]] = {}
+        self._init_weight_sync()
 
     # ---- reference attribute surface ---------------------------------------------------------------
     @staticmethod
@@ -177,7 +179,10 @@ class ConjoinedPaddedVisionTransformer(nn.Module):
 
     def sync_weights(self, device: Optional[torch.device] = None, force: bool = False) -> int:
         """See `vmae.PretrainVisionTransformer.sync_weights` (in-place `.data` edits need force=True)."""
-        device = device or next(self.parameters()).device
+        if device is None:
+            device = self._plist[0].device if self._plist else next(self.parameters()).device
+        if not force and self._handle is not None and self._handle_device == device and self._params_unchanged():
+            return 0
         h = self._ensure_handle(device)
         lib = _lib.get_lib()
         if force:
@@ -195,6 +200,7 @@ class ConjoinedPaddedVisionTransformer(nn.Module):
                 _lib.check(lib.cwm_conj_load_weight(h, name.encode(), t.data_ptr(), 1 if t.is_cuda else 0, shape, t.dim()))
                 self._loaded[name] = tag
                 n += 1
+        self._remember_params()
         return n
 
     # ---- reference forward: conjoined_vmae.py:852-887 ----------------------------------------------

@@ -184,7 +184,11 @@ static int g_prune_last_block = 1;
 static int g_ln_fuse = 0;
 
 // One lane: batch elements [b0, b0 + B) of the call, on stream s, in the workspace slice w.
-static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, LaneWs w, hipStream_t s) {
+// Stages [stage_lo, stage_hi) of the lane's launch sequence: 0 = mask -> permutation, patch gather + embed; 1 .. Le = encoder blocks;
+// Le + 1 = encoder norm + encoder_to_decoder + mask tokens; Le + 2 .. Le + 1 + Ld = decoder blocks; Le + Ld + 2 = norm + head + un-embed.
+// (cwm_forward issues stage by stage over all lanes, so that after a host synchronisation every lane's queue starts filling at once
+// instead of lane 1 waiting behind lane 0's ~136 launches.)
+static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, LaneWs w, hipStream_t s, int stage_lo, int stage_hi) {
     const cwm_config& c = m->cfg;
     const int Nt = m->Nt, Nv = a->n_vis, Nm = Nt - Nv;
     const int Nret = Nm > 0 ? Nm : Nt;
@@ -194,7 +198,12 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
     const uint8_t* mask_in = a->mask_dev + (size_t)b0 * Nt;
     float* y_tokens = a->y_tokens_dev + (size_t)b0 * Nret * m->out_dim;
     int rc;
+    auto in_range = [&](int st) { return st >= stage_lo && st < stage_hi; };
+    const int st_e2d = c.enc_depth + 1, st_head = c.enc_depth + c.dec_depth + 2;
+    GemmParams g;
+    LayerNormParams ln;
 
+    if (in_range(0)) {
     CWM_HIP_CHECK(hipMemsetAsync(w.err, 0, sizeof(int), s));
     if ((rc = launch_mask_to_perm(mask_in, B, Nt, Nv, w.perm, w.err, s))) return rc;
 
@@ -206,6 +215,7 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
     pg.C = c.in_chans; pg.H = c.img_h; pg.W = c.img_w; pg.P = c.patch; pg.perm = w.perm; pg.Nt = Nt; pg.n_rows = Nv; pg.B = B;
     pg.out = w.patches; pg.out_plane = (int64_t)B * Nv * m->patch_kpad; pg.ld = m->patch_kpad;
     if ((rc = launch_patch_gather(pg, planes, s))) return rc;
+    }
 
     // LayerNorm folded into the GEMMs around it (engine.h): no LayerNorm launch anywhere on the path.  Needs the LDS-staged epilogues.
     const bool fold = g_ln_fuse && g_gemm_staged && m->e2d.raw != nullptr;
@@ -214,18 +224,20 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
         sb_enc.xsplit = w.xsplit[0]; sb_enc.xstats = w.xstats[0];
         sb_dec.xsplit = w.xsplit[1]; sb_dec.xstats = w.xstats[1];
     }
-    GemmParams g = gemm_base(w.patches, m->patch_kpad, m->patch, B * Nv, planes);
+    if (in_range(0)) {
+    g = gemm_base(w.patches, m->patch_kpad, m->patch, B * Nv, planes);
     g.epi = EPI_F32; g.C = w.x_enc; g.ldc = c.enc_dim;
     g.resid = m->pos_enc; g.ldr = c.enc_dim; g.resid_rowmap = w.perm; g.rows_in = Nv; g.rows_out = Nv; g.map_stride = Nt;
     if (fold) { g.split_out = sb_enc.xsplit; g.split_ld = c.enc_dim; g.stats_out = sb_enc.xstats; g.split_rows_per_b = Nv; }
     if ((rc = E.run_gemm(g, planes, s))) return rc;
+    }
 
     // a4-a6: encoder blocks over the visible tokens
     for (int i = 0; i < c.enc_depth; ++i)
-        if ((rc = E.run_block(m->enc[i], w.x_enc, B, Nv, c.enc_dim, c.enc_heads, planes, sb_enc, s))) return rc;
+        if (in_range(1 + i) && (rc = E.run_block(m->enc[i], w.x_enc, B, Nv, c.enc_dim, c.enc_heads, planes, sb_enc, s))) return rc;
 
     // a7: encoder.norm, encoder_to_decoder (no bias); a8: + pos[vis] written straight into x_full rows [0,Nv)
-    LayerNormParams ln;
+    if (in_range(st_e2d)) {
     if (fold) {
         g = E.fold_gemm(sb_enc.xsplit, sb_enc.xstats, m->e2d, B * Nv, planes);
         g.split_out = sb_dec.xsplit; g.split_ld = c.dec_dim; g.stats_out = sb_dec.xstats;  // (split row = out row for a fold consumer)
@@ -242,14 +254,16 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
     if (Nm > 0 && (rc = launch_fill_mask_tokens(w.x_dec, m->mask_token, m->pos_dec, w.perm, B, Nt, Nv, c.dec_dim, s, fold ? sb_dec.xsplit : nullptr,
                                                 fold ? sb_dec.xstats : nullptr, planes)))
         return rc;
+    }
 
     // a9: decoder blocks over the full token set, norm + head on the last Nm tokens
     // (the last block only has to produce the Nm rows the head reads: debug key "prune_last_block" = 0 runs it in full)
     const bool pruned = Nm > 0 && g_prune_last_block;
     for (int i = 0; i < c.dec_depth; ++i) {
         const int keep = (i == c.dec_depth - 1 && pruned) ? Nm : 0;
-        if ((rc = E.run_block(m->dec[i], w.x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, sb_dec, s, keep))) return rc;
+        if (in_range(st_e2d + 1 + i) && (rc = E.run_block(m->dec[i], w.x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, sb_dec, s, keep))) return rc;
     }
+    if (!in_range(st_head)) return CWM_OK;
     if (fold && (pruned || Nm == 0)) {
         // the last block left exactly the B * Nret rows the head reads, compact, in operand layout: decoder.norm folds into the head GEMM
         g = E.fold_gemm(sb_dec.xsplit, sb_dec.xstats, m->head, B * Nret, planes);
@@ -320,10 +334,11 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     }
     m->eng.overlapped = two;
     int rc = 0;
-    // launch order: one lane after the other (each lane's ~136 launches are queued before the next lane's; the queues drain concurrently)
-    for (int l = 0; l < n_lanes; ++l) {
-        if (!rc) rc = forward_lane(m, a, first[l], first[l + 1] - first[l], lane_ws(m, l, first[l]), l == 0 ? s : m->lane_stream[l - 1]);
-    }
+    // launch order: stage by stage (one transformer block at a time) over all lanes, so that every lane's queue starts filling at once
+    const int n_stages = c.enc_depth + c.dec_depth + 3;
+    for (int st = 0; st < n_stages && !rc; ++st)
+        for (int l = 0; l < n_lanes && !rc; ++l)
+            rc = forward_lane(m, a, first[l], first[l + 1] - first[l], lane_ws(m, l, first[l]), l == 0 ? s : m->lane_stream[l - 1], st, st + 1);
     m->eng.overlapped = 0;
     // join even after a failed launch: the caller's stream must not run ahead of work already queued on a lane
     for (int l = 1; l < n_lanes; ++l) {

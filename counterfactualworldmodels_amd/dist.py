@@ -20,6 +20,7 @@ use (gloo).  Per-rank fixed cost at 8 ranks: prompt build + one 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -146,15 +147,24 @@ _default: Optional[LocalComm] = None
 
 def get_comm(device=None) -> LocalComm:
     """The process's communicator: `LocalComm` without a launcher; with `torch.distributed` initialised, `RcclComm` for a CUDA/HIP
-    device (the RCCL id is created on rank 0 and handed out through the launcher's group) and `TorchComm` otherwise."""
+    device (the RCCL id is created on rank 0 and handed out through the launcher's group) and `TorchComm` otherwise
+    (CWM_COMM=torch selects `TorchComm` on GPUs too: the launcher's own NCCL/RCCL group)."""
     global _default
     if _default is not None:
         return _default
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         _default = LocalComm()
-    elif device is not None and torch.device(device).type == "cuda":
-        box = [RcclComm.new_unique_id() if dist.get_rank() == 0 else None]
+    elif device is not None and torch.device(device).type == "cuda" and os.environ.get("CWM_COMM", "rccl") != "torch":
+        # rank 0 creates the RCCL id; a failure there is broadcast too, so that every rank raises instead of waiting for an id
+        box = [None]
+        if dist.get_rank() == 0:
+            try:
+                box[0] = RcclComm.new_unique_id()
+            except Exception as e:  # noqa: BLE001
+                box[0] = RuntimeError("rank 0 could not create an RCCL id: %s" % e)
         dist.broadcast_object_list(box, src=0)
+        if isinstance(box[0], Exception):
+            raise box[0]
         _default = RcclComm(dist.get_rank(), dist.get_world_size(), box[0], device)
     else:
         _default = TorchComm()

@@ -30,25 +30,26 @@ class RectangularizeMasks:
             return torch.ones_like(masks)
         shape = masks.shape
         masks = masks.flatten(1)
-        num_masked = masks.float().sum(-1)
-        target = {"min": torch.amin, "max": torch.amax, "mean": torch.mean}[self._mode](num_masked).long()
-        vals = torch.cat([num_masked.long() - target, target.reshape(1)]).tolist()  # one host sync for the whole batch
-        num_changes = vals[:-1]
-        # every row now has exactly this many masked tokens: callers that need the count (the predictor's n_vis) read it
-        # here instead of paying a second device round trip
-        self.last_num_masked = int(vals[-1])
-        for b, nc in enumerate(num_changes):
-            if nc > 0:
-                inds = torch.where(masks[b])[0]
-                inds = inds[torch.randperm(inds.size(0))[:nc].to(inds.device)]
-                masks[b, inds] = 0
-            elif nc < 0:
-                inds = torch.where(~masks[b])[0]
-                inds = inds[torch.randperm(inds.size(0))[:-nc].to(inds.device)]
-                masks[b, inds] = 1
-        if list(masks.shape) != list(shape):
-            masks = masks.view(*shape)
-        return masks
+        # ONE reduction kernel and one device -> host copy for the whole batch: the per-row masked counts
+        counts = masks.sum(-1).tolist()
+        if self._mode == "min":
+            target = min(counts)
+        elif self._mode == "max":
+            target = max(counts)
+        else:  # "mean": the reference takes torch.mean of the float32 counts and truncates (masking.py:108-111)
+            target = int(torch.tensor(counts, dtype=torch.float32).mean().long())
+        # every row now gets exactly `target` masked tokens: callers that need the count (the predictor's n_vis) read it here
+        # instead of paying a second device round trip
+        self.last_num_masked = int(target)
+        for b, n_b in enumerate(counts):
+            surplus = n_b - target
+            if surplus > 0:    # un-mask `surplus` random masked positions (global torch RNG, one randperm per changed row)
+                where = torch.where(masks[b])[0]
+                masks[b, where[torch.randperm(where.size(0))[:surplus].to(where.device)]] = 0
+            elif surplus < 0:  # mask random visible positions
+                where = torch.where(~masks[b])[0]
+                masks[b, where[torch.randperm(where.size(0))[:-surplus].to(where.device)]] = 1
+        return masks if list(masks.shape) == list(shape) else masks.view(*shape)
 
 
 def upsample_masks(masks: torch.Tensor, size) -> torch.Tensor:
