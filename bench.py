@@ -282,11 +282,14 @@ def main():
         for _ in range(2):
             G.predict(x, mask, frame=None)
     model.timing_enable(_lib.KCLASS_GEMM, True)
+    model.timing_enable(_lib.KCLASS_ATTENTION, True)
     dt_one = timed_steps(G, x, mask, n_vis, args.steps, distributed)
     gemm = model.timing_collect(_lib.KCLASS_GEMM)                 # every GEMM launch ...
     gemm_wide = model.timing_collect(_lib.KCLASS_GEMM_WIDE)       # ... split by the kernel that ran it
     gemm_narrow = model.timing_collect(_lib.KCLASS_GEMM_NARROW)
+    attn = model.timing_collect(_lib.KCLASS_ATTENTION)            # softmax(q k^T) v: 4 N^2 64 FLOP per (batch, head)
     model.timing_enable(_lib.KCLASS_GEMM, False)
+    model.timing_enable(_lib.KCLASS_ATTENTION, False)
     model.set_lanes(args.lanes)
 
     value = B * n_gpus * args.steps / dt
@@ -331,8 +334,9 @@ def main():
                 + ("; parity mode executes 3x these FLOPs on the MFMA pipe" if args.mode == "parity" else ""),
         "all_gemm": {"achieved": tflops(gemm), "launches": gemm["launches"], "avg_launch_us": 1e3 * gemm["total_ms"] / max(gemm["launches"], 1),
                      "share_of_step": gemm["total_ms"] / (1e3 * dt_one) if dt_one > 0 else None},
-        "other_kernel": {k: {"achieved": tflops(v), "launches": v["launches"], "avg_launch_us": 1e3 * v["total_ms"] / max(v["launches"], 1)}
-                         for k, v in kernels.items() if k != dom},
+        "other_kernel": {k: {"achieved": tflops(v), "launches": v["launches"], "avg_launch_us": 1e3 * v["total_ms"] / max(v["launches"], 1),
+                             "share_of_step": v["total_ms"] / (1e3 * dt_one) if dt_one > 0 else None}
+                         for k, v in list(kernels.items()) + [("cwm::attention_%s" % ("pipe_kernel<2, 4>" if planes == 2 else "kernel<1>"), attn)] if k != dom},
     }
 
     if not args.no_secondary:

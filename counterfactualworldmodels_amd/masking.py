@@ -21,6 +21,15 @@ class RectangularizeMasks:
     def set_mode(self, mode):
         self._mode = mode
 
+    def _to_host(self, masks):
+        """Device masks -> a persistent pinned staging buffer (one synchronous copy; no allocation, no page faults per call)."""
+        n = masks.numel()
+        if getattr(self, "_stage", None) is None or self._stage.numel() < n:
+            self._stage = torch.empty(max(n, 1 << 16), dtype=torch.bool, pin_memory=True)
+        host = self._stage[:n].view(masks.shape)
+        host.copy_(masks)
+        return host
+
     def __call__(self, masks: torch.Tensor) -> torch.Tensor:
         self.last_num_masked = None
         if self._mode in ["none", None]:
@@ -30,8 +39,12 @@ class RectangularizeMasks:
             return torch.ones_like(masks)
         shape = masks.shape
         masks = masks.flatten(1)
-        # ONE reduction kernel and one device -> host copy for the whole batch: the per-row masked counts
-        counts = masks.sum(-1).tolist()
+        # Device masks: ONE device -> host copy of the whole (tiny: B x Nt bytes) tensor replaces the per-row device round trips of the
+        # reference loop -- the row edits below then run on the host copy and go back in one copy.  The random choices are unchanged:
+        # `torch.randperm(n)` draws from the global CPU generator wherever the mask lives, and `torch.where` lists the same positions.
+        work = self._to_host(masks) if masks.is_cuda else masks
+        rows = work.numpy()  # (shares memory with `work`; the row edits are index arithmetic on <= Nt bytes: numpy, no thread-pool spin-up)
+        counts = np.count_nonzero(rows, axis=1).tolist()
         if self._mode == "min":
             target = min(counts)
         elif self._mode == "max":
@@ -41,14 +54,19 @@ class RectangularizeMasks:
         # every row now gets exactly `target` masked tokens: callers that need the count (the predictor's n_vis) read it here
         # instead of paying a second device round trip
         self.last_num_masked = int(target)
+        changed = False
         for b, n_b in enumerate(counts):
             surplus = n_b - target
-            if surplus > 0:    # un-mask `surplus` random masked positions (global torch RNG, one randperm per changed row)
-                where = torch.where(masks[b])[0]
-                masks[b, where[torch.randperm(where.size(0))[:surplus].to(where.device)]] = 0
+            if surplus > 0:    # un-mask `surplus` random masked positions (one randperm per changed row, in row order)
+                where = np.flatnonzero(rows[b])
+                rows[b, where[torch.randperm(where.size)[:surplus].numpy()]] = False
+                changed = True
             elif surplus < 0:  # mask random visible positions
-                where = torch.where(~masks[b])[0]
-                masks[b, where[torch.randperm(where.size(0))[:-surplus].to(where.device)]] = 1
+                where = np.flatnonzero(~rows[b])
+                rows[b, where[torch.randperm(where.size)[:-surplus].numpy()]] = True
+                changed = True
+        if changed and work is not masks:
+            masks.copy_(work)  # in place, like the reference
         return masks if list(masks.shape) == list(shape) else masks.view(*shape)
 
 
