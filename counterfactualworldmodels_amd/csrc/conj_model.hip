@@ -223,6 +223,8 @@ int ensure_workspace(cwm_conj_model* m, int B, int vmain, int vctx) {
     m->ws_batch = Bc;
     m->ws_vmain = vm;
     m->ws_vctx = vc;
+    // (the zero fills above ran on the null stream; the lane streams are non-blocking and would not wait for them)
+    CWM_HIP_CHECK(hipDeviceSynchronize());
     return 0;
 }
 

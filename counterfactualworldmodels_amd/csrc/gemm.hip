@@ -502,6 +502,9 @@ int splitk_workspace_alloc(float** slabs, unsigned** counts) {
     CWM_HIP_CHECK(hipMalloc((void**)slabs, (size_t)kSplitKSlots * 128 * 128 * sizeof(float)));
     CWM_HIP_CHECK(hipMalloc((void**)counts, kSplitKSlots * sizeof(unsigned)));
     CWM_HIP_CHECK(hipMemset(*counts, 0, kSplitKSlots * sizeof(unsigned)));
+    // the memset runs on the null stream; the kernels that use the counters run on non-blocking streams (batch lanes), which do
+    // not wait for it: make it complete here (allocation happens once per stream)
+    CWM_HIP_CHECK(hipDeviceSynchronize());
     return 0;
 }
 

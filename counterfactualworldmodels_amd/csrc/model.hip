@@ -76,6 +76,8 @@ int ensure_workspace(cwm_model* m, int B, int n_vis) {
         if ((rc = E.ws(&m->xsplit[i], 2 * act)) || (rc = E.ws(&m->xstats[i], std::max(rows_e, rows_d) * m->stats_per_lane_row))) return rc;
     m->ws_batch = Bc;
     m->ws_nvis = Nv;
+    // (the zero fills above ran on the null stream; the lane streams are non-blocking and would not wait for them)
+    CWM_HIP_CHECK(hipDeviceSynchronize());
     return 0;
 }
 

@@ -156,6 +156,27 @@ def test_weight_reload_is_picked_up():
     assert (y1 - y2).abs().max().item() > 1e-2
 
 
+def test_weight_edits_are_detected_without_walking_the_state_dict():
+    """`sync_weights` compares parameter version counters (vmae.WeightSync): optimiser-style in-place updates, `load_state_dict`, `.to()`
+    and `sync_weights(force=True)` after a `.data` edit must all reach the library; an unchanged model uploads nothing."""
+    m = build(TINY, 3)
+    x = torch.from_numpy(S.synthetic_frames(2, TINY, 3)).cuda()
+    mask = torch.from_numpy(S.synthetic_masks(2, TINY, 4, 3)).cuda()
+    xp = O.preprocess(x.cpu()).cuda()
+    y0 = m(xp, mask)
+    assert m.sync_weights() == 0 and m._params_unchanged()
+    with torch.no_grad():
+        m.decoder.head.bias.add_(0.5)                      # in-place update: bumps the version counter
+    y1 = m(xp, mask)
+    assert ((y1 - y0) - 0.5).abs().max().item() <= 1e-5   # the head bias shifts every output by exactly 0.5
+    m.decoder.head.bias.data.sub_(0.5)                     # `.data` edit: invisible to the counters ...
+    assert torch.equal(m(xp, mask), y1)
+    assert m.sync_weights(force=True) > 0                  # ... until the caller says so
+    assert (m(xp, mask) - y0).abs().max().item() <= 1e-6
+    m2 = m.cpu().cuda()                                    # `.to()` replaces the parameter tensors: the list is rebuilt
+    assert (m2(xp, mask) - y0).abs().max().item() <= 1e-6
+
+
 def test_qkv_epilogue_variants_agree_end_to_end():
     """Direct vs LDS-staged GEMM epilogues (QKV head scatter included) and every tile configuration: same forward output,
     bit for bit (all of them apply the same product sequence to every accumulator)."""

@@ -214,6 +214,25 @@ def test_256_prompts_sharded_driver_equals_one_unchunked_call():
     assert torch.equal(yv[:, 0], x0[0, 0].cuda().expand(16, -1, -1, -1))   # frame 0 is the input image
 
 
+def test_rectangulariser_on_device_masks_is_bit_exact_and_in_place():
+    """`RectangularizeMasks` on device masks (pinned host staging, numpy row edits, one copy back): same result as on the CPU tensor with the
+    same torch seed (the reference's randperm order, masking.py:100-132), input mutated in place, `last_num_masked` reported."""
+    from counterfactualworldmodels_amd.masking import RectangularizeMasks
+
+    g = torch.Generator().manual_seed(4)
+    for mode in ("min", "max", "mean"):
+        for rows in (1, 5, 64):
+            m = torch.rand(rows, 200, generator=g) < 0.7
+            torch.manual_seed(77)
+            ref = RectangularizeMasks(mode)(m.clone())
+            torch.manual_seed(77)
+            md = m.cuda()
+            r = RectangularizeMasks(mode)
+            out = r(md)
+            assert out.data_ptr() == md.data_ptr() and torch.equal(out.cpu(), ref)
+            assert r.last_num_masked == int(ref[0].sum()) and (ref.sum(-1) == r.last_num_masked).all()
+
+
 def test_rccl_comm_single_rank_on_device():
     """The C-ABI collectives (cwm_comm_init / cwm_broadcast / cwm_allgatherv / cwm_allreduce_sum_f32) on a one-rank RCCL communicator:
     RCCL binds, the communicator initialises on the GPU, and every collective is the identity on the stream."""
