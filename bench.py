@@ -238,10 +238,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    # Test hooks (tools/run_bench_2ranks_1gpu.sh): CWM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and CWM_BENCH_BACKEND=gloo replaces the
+    # launcher's RCCL group, so that the multi-rank control flow (sharding, packed broadcast, gather, max-over-ranks clock) can be run
+    # on a one-GPU box; RCCL itself refuses two ranks on one device.  Never set for measurements.
+    if os.environ.get("CWM_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("CWM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world if distributed else 1
     if args.workload == "prompts256":
         return run_prompts(args, rank, local_rank, world, distributed)
