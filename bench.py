@@ -156,9 +156,13 @@ def prompts_measure(args, rank, local_rank, world, distributed, model=None, step
 
 
 def run_prompts(args, rank, local_rank, world, distributed):
+    from counterfactualworldmodels_amd import dist as cdist
+
     out = prompts_measure(args, rank, local_rank, world, distributed)
     if distributed:
+        torch.cuda.synchronize()
         dist.barrier()
+        cdist.reset_comm()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
@@ -374,7 +378,11 @@ def main():
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, wl["k_vis"], wl["clump"], 0)
     if distributed:
+        from counterfactualworldmodels_amd import dist as cdist
+
+        torch.cuda.synchronize()
         dist.barrier()
+        cdist.reset_comm()  # destroys the RCCL communicator of the data path (every rank, after the last collective)
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
