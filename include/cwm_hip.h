@@ -95,7 +95,7 @@ int cwm_forward(cwm_model* m, const cwm_forward_args* args);
  * batch >= 2 whose halves keep >= 6000 encoder rows (ViT-B/8: batch >= 16; ViT-L/4: batch >= 4) runs as two half batches, the first on args->stream and the second on a stream owned by the model, forked and joined
  * with events inside cwm_forward, so the caller sees ordinary stream semantics; results are those of the single-lane call up to the
  * kernel choice per GEMM shape (fp32 re-association, < 1e-5).  lanes = 1: everything on args->stream. */
-int cwm_model_set_lanes(cwm_model* m, int lanes);
+int cwm_model_set_lanes(cwm_model* m, int lanes); /* 1 .. 4; more than two lanes measured slower on MI355X */
 
 /* ---- IMU-conditioned conjoined padded predictor (BASELINE configs[4]) ------------------------------
  * replaces: ConjoinedPaddedVisionTransformer.forward for the `imu400_base_4x4patch_2frames_1tube` family
