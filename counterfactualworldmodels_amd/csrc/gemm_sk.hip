@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_kernel(const GemmParams p) {
                     } else {
                         if constexpr (EPI == EPI_BF16_GELU) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                            for (int e = 0; e < 4; e += 4) v = gelu_erf4(v);
                         } else if constexpr (EPI == EPI_QKV) {
                             if (which[qn] == 0) v *= p.q_scale;
                         }
