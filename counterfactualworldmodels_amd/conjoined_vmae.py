@@ -235,13 +235,13 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
             mask_context = torch.zeros(B, c.ctx_tokens, dtype=torch.bool, device=dev)
         mc = mask_context.to(device=dev, dtype=torch.bool).reshape(B, c.ctx_tokens).contiguous()
         vis = (~mask).sum(-1)
+        vis_c = (~mc).sum(-1)
         if not mask_context_given:
             n_vis_context = c.ctx_tokens
         if n_vis is not None and n_vis_context is not None:
             vmax = vmin = int(n_vis)
             vcmax = vcmin = int(n_vis_context)
         else:
-            vis_c = (~mc).sum(-1)
             vmax, vmin, vcmax, vcmin = (int(v) for v in torch.stack([vis.max(), vis.min(), vis_c.max(), vis_c.min()]).tolist())
         if vmax - vmin > c.main_max_pad or vcmax - vcmin > c.ctx_max_pad:
             raise RuntimeError("visible-token counts differ by more than max_padding_tokens (%d / %d)" % (c.main_max_pad, c.ctx_max_pad))
@@ -254,18 +254,23 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
             vcmax, y.data_ptr(), _lib.mode_id(self.mode), int(check), _lib.current_stream_handle(dev))
         with torch.cuda.device(dev):
             _lib.check(_lib.get_lib().cwm_conj_forward(self._handle, C.byref(args_)))
-        self._record_padding_state(mask, vis, vmax)
+        self._record_padding_state(mask, vis, vmax, mc, vis_c, vcmax)
         return y
 
-    def _record_padding_state(self, mask, vis, vmax):
-        """The padding attributes the reference leaves set after a forward until the wrapper resets them (prediction.py:451-452;
-        conjoined_vmae.py:49-116): `padding_mask` (pad slot j of row b is masked unless j < vmax - visible(b)), `full_input_mask`,
-        `null_mask`."""
-        c, B, Nt = self.cfg, mask.shape[0], mask.shape[1]
-        pad = torch.arange(c.main_max_pad, device=mask.device)[None] >= (vmax - vis)[:, None]
-        self.main_stream.padding_mask = pad
-        self.main_stream.full_input_mask = torch.cat([mask, pad], -1)
-        self.main_stream.null_mask = torch.cat([torch.zeros(B, Nt - vmax, dtype=torch.bool, device=mask.device), pad], -1)
+    def _record_padding_state(self, mask, vis, vmax, mask_ctx=None, vis_ctx=None, vmax_ctx=None):
+        """The padding attributes the reference leaves set on BOTH streams after a forward until the wrapper resets them
+        (prediction.py:451-452; conjoined_vmae.py:49-116): `padding_mask` (pad slot j of row b is masked unless
+        j < max visible - visible(b)), `full_input_mask` = [mask | padding_mask], `null_mask` = [zeros(min masked) | padding_mask]."""
+        def record(stream, m, v, vm, max_pad):
+            B, N = m.shape
+            pad = torch.arange(max_pad, device=m.device)[None] >= (vm - v)[:, None]
+            stream.padding_mask = pad
+            stream.full_input_mask = torch.cat([m, pad], -1)
+            stream.null_mask = torch.cat([torch.zeros(B, N - vm, dtype=torch.bool, device=m.device), pad], -1)
+
+        record(self.main_stream, mask, vis, vmax, self.cfg.main_max_pad)
+        if mask_ctx is not None:
+            record(self.context_stream, mask_ctx, vis_ctx, vmax_ctx, self.cfg.ctx_max_pad)
 
     def set_lanes(self, lanes: int):
         """See `vmae.PretrainVisionTransformer.set_lanes`."""

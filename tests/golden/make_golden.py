@@ -280,12 +280,18 @@ def run_conj_cases(ns, skip_large=False):
     with torch.no_grad():
         m._reset_padding_mask()
         out["y_tokens"] = m(G._preprocess(x), mask.clone(), x_context=imu, mask_context=mc).numpy()
+        # the padding state the reference leaves behind until the wrapper resets it (conjoined_vmae.py:49-116): SURVEY.md 8c-4
+        pad = {"padding_mask": m.main_stream.padding_mask.numpy(), "full_input_mask": m.main_stream.full_input_mask.numpy(),
+               "null_mask": m.main_stream.null_mask.numpy(), "ctx_padding_mask": m.context_stream.padding_mask.numpy()}
         m._reset_padding_mask()
         # equal visible counts (the normal case after RectangularizeMasks): no visible pads, last P rows are zero
         mask_eq = torch.from_numpy(S.synthetic_masks(2, cfg.main, 3, 9))
         mc_eq = torch.zeros(2, cfg.ctx_tokens, dtype=torch.bool)
         out["mask_eq"] = mask_eq.numpy()
         out["y_tokens_eq"] = m(G._preprocess(x[:2]), mask_eq.clone(), x_context=imu[:2], mask_context=mc_eq).numpy()
+        pad.update({"padding_mask_eq": m.main_stream.padding_mask.numpy(), "full_input_mask_eq": m.main_stream.full_input_mask.numpy(),
+                    "null_mask_eq": m.main_stream.null_mask.numpy()})
+        np.savez_compressed(os.path.join(HERE, "conj_padding.npz"), **pad)
         m._reset_padding_mask()
         torch.manual_seed(3)
         video = G.predict(x[:2], mask_eq.clone(), frame=None, x_context=imu[:2], mask_context=mc_eq)

@@ -29,14 +29,22 @@ def test_tiny_conj_golden_ragged_and_wrapper():
     assert y.shape == g["y_tokens"].shape
     assert np.abs(y - g["y_tokens"]).max() <= 3e-4
     assert hasattr(m, "padding_mask")
+    # the padding state of both streams equals what the reference model leaves behind (conj_padding.npz; conjoined_vmae.py:49-116)
+    pad = np.load(os.path.join(GOLDEN, "conj_padding.npz"))
+    assert np.array_equal(m.main_stream.padding_mask.cpu().numpy(), pad["padding_mask"])
+    assert np.array_equal(m.main_stream.full_input_mask.cpu().numpy(), pad["full_input_mask"])
+    assert np.array_equal(m.main_stream.null_mask.cpu().numpy(), pad["null_mask"])
+    assert np.array_equal(m.context_stream.padding_mask.cpu().numpy(), pad["ctx_padding_mask"])
     G.reset_padding_masks()
-    assert not hasattr(m, "padding_mask")
+    assert not hasattr(m, "padding_mask") and m.context_stream.padding_mask is None
     # zero rows exactly where the reference has them (masked pad slots)
     assert np.array_equal(np.abs(y).sum(-1) == 0, np.abs(g["y_tokens"]).sum(-1) == 0)
     mask_eq = torch.from_numpy(g["mask_eq"]).cuda()
     mc_eq = torch.zeros(2, TINY_CONJ.ctx_tokens, dtype=torch.bool, device="cuda")
     y_eq = m(G._preprocess(x[:2]), mask_eq, x_context=imu[:2], mask_context=mc_eq).cpu().numpy()
     assert np.abs(y_eq - g["y_tokens_eq"]).max() <= 3e-4
+    for k in ("padding_mask", "full_input_mask", "null_mask"):
+        assert np.array_equal(getattr(m.main_stream, k).cpu().numpy(), pad[k + "_eq"]), k
     video = G.predict(x[:2], mask_eq.clone(), frame=None, x_context=imu[:2], mask_context=mc_eq).cpu().numpy()
     assert video.shape == g["video_eq"].shape and np.abs(video - g["video_eq"]).max() <= 3e-4
     # fast mode stays close on this shallow model
