@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from counterfactualworldmodels_amd import _lib, config as C, synthetic as S, vmae  # noqa: E402
+from counterfactualworldmodels_amd import _lib, config as C, synthetic as S, vmae  # noqa: E402  (loading the library makes no HIP call)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
@@ -103,6 +103,10 @@ def cpu_baseline(cfg, k_vis, clump, seed, budget_s=20.0):
     }
 
 
+def n_gpus_expected(world, distributed):
+    return world if distributed else 1
+
+
 def prompts_measure(args, rank, local_rank, world, distributed, model=None, steps=None, warmup=None):
     """BASELINE configs[3], strong scaling: 256 prompts on ONE frame pair, sharded over the ranks (dist.py: one packed RCCL
     broadcast, per-rank prompt construction + 32-row predictor calls with no host sync in between, one all-gather).
@@ -130,6 +134,7 @@ def prompts_measure(args, rank, local_rank, world, distributed, model=None, step
     for _ in range(warmup):
         y = step()
     assert y.shape[0] == PROMPTS["total"]
+    assert comm.world == n_gpus_expected(world, distributed), (comm.world, world)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -150,7 +155,8 @@ def prompts_measure(args, rank, local_rank, world, distributed, model=None, step
         "n_gpus": n_gpus, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": PROMPTS["name"], "predictor": cfg.name, "prompts": PROMPTS["total"], "chunk": PROMPTS["chunk"],
-                   "mode": args.mode, "lanes": args.lanes, "collectives": type(comm).__name__,
+                   "mode": args.mode, "lanes": args.lanes, "collectives": type(comm).__name__, "comm_world": comm.world,
+                   "gather": comm.last_collective,
                    "parallelism": "prompts sharded over %d rank(s): one packed broadcast(frame, prompt table, masks) + one all_gather(predicted frames)" % n_gpus},
     }
 
@@ -223,6 +229,26 @@ def run_imu(args, rank, local_rank, world, distributed):
         print(json.dumps(out))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks with torch.distributed.run as a CHILD
+    process -- nothing in this process has touched the GPU yet (counting devices does not initialise it), and the parent only relays
+    the child's output and exit code.  Fails loudly when the box has fewer than N GPUs: a line must never claim more GPUs than it ran on."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("CWM_BENCH_ONE_DEVICE") != "1":
+        sys.stderr.write("bench.py: --gpus %d requested but this box has %d GPU(s); refusing to measure fewer GPUs than asked for\n" % (args.gpus, have))
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,10 +264,15 @@ def main():
                     help="2 (library default): the batch runs as two half batches on two HIP streams; 1: one stream")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    if world != args.gpus:  # the line reports n_gpus = the launcher's world size: it must be what was asked for
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)\n" % (args.gpus, world))
+        sys.exit(2)
     # Test hooks (tools/run_bench_2ranks_1gpu.sh): CWM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and CWM_BENCH_BACKEND=gloo replaces the
     # launcher's RCCL group, so that the multi-rank control flow (sharding, packed broadcast, gather, max-over-ranks clock) can be run
     # on a one-GPU box; RCCL itself refuses two ranks on one device.  Never set for measurements.
@@ -372,7 +403,10 @@ def main():
             pm = prompts_measure(args, rank, local_rank, world, distributed, model=model, steps=max(3, args.steps // 4), warmup=2)
             out["prompts256"] = {k: pm[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "steps")}
             out["prompts256"]["config"] = pm["config"]
+            out["rccl_ranks"], out["collectives"] = pm["config"]["comm_world"], pm["config"]["collectives"]
         except Exception as e:  # noqa: BLE001
+            if distributed:  # the multi-rank path IS what N > 1 is run for: a broken broadcast / gather must not exit 0
+                raise
             out["prompts256"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

@@ -37,17 +37,32 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _equal_contiguous(offsets: Sequence[int], counts: Sequence[int]) -> bool:
+    """True when the blocks are non-empty, equal and back to back in rank order (what `ncclAllGather` needs)."""
+    n = counts[0]
+    return n > 0 and all(c == n for c in counts) and all(offsets[r] == offsets[0] + r * n for r in range(len(counts)))
+
+
 # ---- communicators --------------------------------------------------------------------------------------------------------
 class LocalComm:
     """World of one: every collective is the identity."""
 
     rank, world = 0, 1
+    last_collective = None  # which collective the last gather used (tests / bench line)
 
     def broadcast_bytes(self, buf: torch.Tensor, src: int = 0) -> None:
         pass
 
     def all_gather_blocks(self, local: torch.Tensor, out: torch.Tensor, counts: Sequence[int]) -> torch.Tensor:
-        out.copy_(local)
+        """`out` [sum(counts), ...] receives rank r's `counts[r]` rows at their offset (rank order)."""
+        offsets = [sum(counts[:r]) for r in range(self.world)]
+        if counts[self.rank]:
+            out[offsets[self.rank] : offsets[self.rank] + counts[self.rank]].copy_(local)
+        return self.all_gather_rows(out, offsets, counts)
+
+    def all_gather_rows(self, out: torch.Tensor, offsets: Sequence[int], counts: Sequence[int]) -> torch.Tensor:
+        """In place: rows [offsets[r], offsets[r] + counts[r]) of `out` are valid on rank r before the call and on every rank
+        after it.  The per-chunk form of the gather (`sharded_counterfactual_predictions`) calls this once per chunk."""
         return out
 
     def all_reduce_sum(self, t: torch.Tensor) -> None:
@@ -64,20 +79,22 @@ class TorchComm(LocalComm):
     def broadcast_bytes(self, buf, src=0):
         dist.broadcast(buf, src=src, group=self.group)
 
-    def all_gather_blocks(self, local, out, counts):
-        """`out` [sum(counts), ...] receives rank r's `counts[r]` rows at their offset."""
-        if len(set(counts)) == 1:
-            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+    def all_gather_rows(self, out, offsets, counts):
+        self.last_collective = "all_gather_into_tensor" if _equal_contiguous(offsets, counts) else "all_gather(padded)"
+        if max(counts) == 0:
+            return out
+        me = out[offsets[self.rank] : offsets[self.rank] + counts[self.rank]]
+        if _equal_contiguous(offsets, counts):  # equal blocks, back to back: the plain all-gather straight into place
+            dist.all_gather_into_tensor(out[offsets[0] : offsets[0] + self.world * counts[0]], me.contiguous(), group=self.group)
             return out
         width = max(counts)  # ragged: equal-sized padded blocks through the collective, trimmed into place
-        pad = local.new_zeros((width,) + tuple(local.shape[1:]))
-        pad[: local.shape[0]] = local
+        pad = out.new_zeros((width,) + tuple(out.shape[1:]))
+        pad[: counts[self.rank]] = me
         parts = [torch.empty_like(pad) for _ in range(self.world)]
         dist.all_gather(parts, pad, group=self.group)
-        lo = 0
         for r, n in enumerate(counts):
-            out[lo : lo + n] = parts[r][:n]
-            lo += n
+            if r != self.rank and n:
+                out[offsets[r] : offsets[r] + n] = parts[r][:n]
         return out
 
     def all_reduce_sum(self, t):
@@ -126,14 +143,23 @@ class RcclComm(LocalComm):
         with torch.cuda.device(self.device):
             self._lib_mod.check(self._lib_mod.get_lib().cwm_broadcast(self._handle, buf.data_ptr(), buf.numel() * buf.element_size(), src, self._stream()))
 
-    def all_gather_blocks(self, local, out, counts):
-        assert out.is_cuda and out.is_contiguous() and (local.is_contiguous() or local.numel() == 0)
-        row = out[0].numel() * out.element_size() if out.shape[0] else 0
-        sizes = (C.c_size_t * self.world)(*[n * row for n in counts])
-        offs = (C.c_size_t * self.world)(*[sum(counts[:r]) * row for r in range(self.world)])
+    def all_gather_rows(self, out, offsets, counts):
+        """Equal blocks back to back -> `ncclAllGather` in place (`cwm_allgather`, the tuned ring collective); anything else ->
+        `cwm_allgatherv` (one group of per-root broadcasts, blocks may differ or be empty).  Both on the current stream."""
+        assert out.is_cuda and out.is_contiguous()
+        lib, row = self._lib_mod.get_lib(), (out[0].numel() * out.element_size() if out.shape[0] else 0)
+        base = out.data_ptr()
         with torch.cuda.device(self.device):
-            self._lib_mod.check(self._lib_mod.get_lib().cwm_allgatherv(self._handle, local.data_ptr() if local.numel() else None, out.data_ptr(),
-                                                                 offs, sizes, self._stream()))
+            if _equal_contiguous(offsets, counts):
+                self.last_collective = "ncclAllGather"
+                self._lib_mod.check(lib.cwm_allgather(self._handle, base + offsets[self.rank] * row, base + offsets[0] * row, counts[0] * row,
+                                                      self._stream()))
+            else:
+                self.last_collective = "grouped ncclBroadcast"
+                sizes = (C.c_size_t * self.world)(*[n * row for n in counts])
+                offs = (C.c_size_t * self.world)(*[o * row for o in offsets])
+                send = base + offsets[self.rank] * row if counts[self.rank] else None
+                self._lib_mod.check(lib.cwm_allgatherv(self._handle, send, base, offs, sizes, self._stream()))
         return out
 
     def all_reduce_sum(self, t):
@@ -142,19 +168,19 @@ class RcclComm(LocalComm):
             self._lib_mod.check(self._lib_mod.get_lib().cwm_allreduce_sum_f32(self._handle, t.data_ptr(), t.numel(), self._stream()))
 
 
-_default: Optional[LocalComm] = None
+_comms: dict = {}
 
 
 def get_comm(device=None) -> LocalComm:
     """The process's communicator: `LocalComm` without a launcher; with `torch.distributed` initialised, `RcclComm` for a CUDA/HIP
     device (the RCCL id is created on rank 0 and handed out through the launcher's group) and `TorchComm` otherwise
     (CWM_COMM=torch selects `TorchComm` on GPUs too: the launcher's own NCCL/RCCL group)."""
-    global _default
-    if _default is not None:
-        return _default
+    key = torch.device(device).type if device is not None else "cpu"  # one communicator per device type: a first CPU call must not
+    if key in _comms:                                                   # pin `TorchComm` for later GPU calls
+        return _comms[key]
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         _default = LocalComm()
-    elif device is not None and torch.device(device).type == "cuda" and os.environ.get("CWM_COMM", "rccl") != "torch":
+    elif key == "cuda" and os.environ.get("CWM_COMM", "rccl") != "torch":
         # rank 0 creates the RCCL id; a failure there is broadcast too, so that every rank raises instead of waiting for an id
         box = [None]
         if dist.get_rank() == 0:
@@ -168,14 +194,15 @@ def get_comm(device=None) -> LocalComm:
         _default = RcclComm(dist.get_rank(), dist.get_world_size(), box[0], device)
     else:
         _default = TorchComm()
+    _comms[key] = _default
     return _default
 
 
 def reset_comm():
-    global _default
-    if isinstance(_default, RcclComm):
-        _default.close()
-    _default = None
+    for c in _comms.values():
+        if isinstance(c, RcclComm):
+            c.close()
+    _comms.clear()
 
 
 # ---- packed broadcast ---------------------------------------------------------------------------------------------------
@@ -220,6 +247,19 @@ def unpack_inputs(buf: torch.Tensor):
 
 
 # ---- the config-4 loop --------------------------------------------------------------------------------------------------
+class RemoteRankError(RuntimeError):
+    """Rank 0 failed while preparing the prompts; raised on the other ranks instead of leaving them inside a collective."""
+
+
+def _side_stream(comm, device):
+    """The stream the per-chunk gathers run on (one per communicator), so that a chunk's gather rides under the next chunk."""
+    st = getattr(comm, "_gather_stream", None)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        comm._gather_stream = st
+    return st
+
+
 def sharded_counterfactual_predictions(
     x: Optional[torch.Tensor],
     prompts: Optional[torch.Tensor],
@@ -239,39 +279,87 @@ def sharded_counterfactual_predictions(
       rect_fn(masks [S,Nt])    -> (masks, n_masked)                         rank 0 only, once for all S rows (global RNG order kept)
       predict_fn(x_rows, mask_rows, n_masked, chunk) -> y [n, ...]          the predictor over `chunk` rows per call, no host sync
     shapes = (x.shape, prompts.shape, Nt), if known on every rank, lets the receivers size the packed buffer without a
-    metadata collective.  Returns all S predictions in prompt order on every rank (only the local block with gather=False)."""
+    metadata collective.  Returns all S predictions in prompt order on every rank (only the local block with gather=False).
+
+    The gather is issued PER CHUNK: as soon as a rank's chunk c is queued, the all-gather of every rank's chunk c is queued on a side
+    stream behind it and runs under chunk c + 1 (2 / 4 ranks: 4 / 2 chunks per rank); with one chunk per rank (8 ranks, 256 prompts)
+    that is a single `ncclAllGather` of equal blocks.  A failure on rank 0 before the broadcast reaches the other ranks as a status
+    word in the packed header (they raise `RemoteRankError`)."""
     comm = comm or get_comm(device)
     rank, world = comm.rank, comm.world
+    failure = None
     if rank == 0:
-        xb, table = x.to(device), prompts.to(device)
-        x_all, masks = build_fn(xb, table)
-        masks, n_masked = rect_fn(masks)
+        try:
+            xb, table = x.to(device), prompts.to(device)
+            x_all, masks = build_fn(xb, table)
+            masks, n_masked = rect_fn(masks)
+            if world > 1:
+                buf = pack_inputs(xb, table, masks, n_masked, device)
+                if shapes is not None and buf.numel() != _layout(shapes[0], shapes[1], shapes[2])[3]:
+                    raise ValueError("packed prompt buffer has %d bytes, the shape hint says %d" % (buf.numel(), _layout(shapes[0], shapes[1], shapes[2])[3]))
+        except Exception as e:  # noqa: BLE001 -- the peers are (about to be) inside the broadcast: tell them, then raise here
+            if world == 1:
+                raise
+            failure = e
     if world > 1:
-        if rank == 0:
-            buf = pack_inputs(xb, table, masks, n_masked, device)
-        if shapes is None:  # receivers learn the buffer size from a first 8-byte broadcast
-            meta = torch.tensor([buf.numel() if rank == 0 else 0], dtype=torch.int64, device=device).view(torch.uint8)
+        if shapes is None:  # receivers learn the buffer size from a first 8-byte broadcast (0 = rank 0 failed)
+            meta = torch.tensor([buf.numel() if rank == 0 and failure is None else 0], dtype=torch.int64, device=device).view(torch.uint8)
             comm.broadcast_bytes(meta, 0)
             total = int(meta.view(torch.int64).item())
+            if failure is not None:
+                raise failure
+            if total == 0:
+                raise RemoteRankError("rank 0 failed while building the prompts")
         else:
             total = _layout(shapes[0], shapes[1], shapes[2])[3]
+            if failure is not None:
+                buf = torch.zeros(total, dtype=torch.uint8, device=device)  # magic 0 = status word "failed"
         if rank != 0:
             buf = torch.empty(total, dtype=torch.uint8, device=device)
         comm.broadcast_bytes(buf, 0)
+        if failure is not None:
+            raise failure
         if rank != 0:
+            if int(buf[:8].view(torch.int64).item()) == 0:
+                raise RemoteRankError("rank 0 failed while building the prompts")
             xb, table, masks, n_masked = unpack_inputs(buf)
     S = table.shape[0]
-    lo, hi = shard_range(S, rank, world)
+    bounds = [shard_range(S, r, world) for r in range(world)]
+    lo, hi = bounds[rank]
     if hi > lo:
         x_own = x_all[lo:hi] if rank == 0 else build_fn(xb, table[lo:hi])[0]
-        y_local = predict_fn(x_own, masks[lo:hi], n_masked, chunk)
-    else:  # an empty slice still joins the gather with the right trailing shape: predict one row, keep none
-        y_local = predict_fn(build_fn(xb, table[:1])[0], masks[:1], n_masked, chunk)[:0]
     if not gather or world == 1:
-        return y_local
-    counts = [shard_range(S, r, world)[1] - shard_range(S, r, world)[0] for r in range(world)]
-    out = torch.empty((S,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
-    return comm.all_gather_blocks(y_local.contiguous(), out, counts)
+        if hi > lo:
+            return predict_fn(x_own, masks[lo:hi], n_masked, chunk)
+        # an empty slice keeps the right trailing shape: predict one row, keep none
+        return predict_fn(build_fn(xb, table[:1])[0], masks[:1], n_masked, chunk)[:0]
+    # ---- chunk c of every rank is gathered while chunk c + 1 is predicted
+    on_gpu = torch.device(device).type == "cuda"
+    n_chunks = max(1, -(-max(h - l for l, h in bounds) // chunk))
+    out = None
+    if on_gpu:
+        main, side = torch.cuda.current_stream(device), _side_stream(comm, device)
+    for c in range(n_chunks):
+        a, b = min(lo + c * chunk, hi), min(lo + (c + 1) * chunk, hi)
+        if b > a:
+            y = predict_fn(x_own[a - lo : b - lo], masks[a:b], n_masked, chunk)
+        elif out is None:  # this rank owns nothing at all: one row gives the trailing shape
+            y = predict_fn(build_fn(xb, table[:1])[0], masks[:1], n_masked, chunk)[:0]
+        if out is None:
+            out = torch.empty((S,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+        if b > a:
+            out[a:b].copy_(y)
+        offs = [min(l + c * chunk, h) for l, h in bounds]
+        cnts = [min(l + (c + 1) * chunk, h) - o for (l, h), o in zip(bounds, offs)]
+        if on_gpu and n_chunks > 1:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                comm.all_gather_rows(out, offs, cnts)
+        else:
+            comm.all_gather_rows(out, offs, cnts)
+    if on_gpu and n_chunks > 1:
+        main.wait_stream(side)
+    return out
 
 
 def prompt_hooks(G, frame: Optional[int] = -1):

@@ -129,8 +129,48 @@ def patch_embed(x_bcthw: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torc
 
 
 # ----------------------------------------------------------------------------------------------
-# a4-a6: transformer block  (VideoMAE/utils.py:37-153)
+# operand-rounding hooks (precision budget of the HIP path; tests/precision_budget.py).  With the default (empty) table every
+# product below is plain fp32, i.e. the reference arithmetic.  A scheme rounds the two operands of ONE class of matrix product
+# the way an MFMA variant would see them and accumulates in fp32:
+#   "bf16"     one plane each (the library's `fast` mode)           "bf16x3"   hi+lo bf16 planes, hi*hi + hi*lo + lo*hi (`parity`)
+#   "fp16"     one fp16 plane each                                   "fp16_a2"  first operand hi+lo fp16, second one plane (2 MFMAs)
+#   "fp16_b2"  second operand hi+lo fp16, first one plane            "fp16x3"   hi+lo fp16 planes, three products
+# classes: "qk" (q k^T), "pv" (softmax . v), "qkv", "proj", "fc1", "fc2" (first operand = activations, second = weights).
 # ----------------------------------------------------------------------------------------------
+PRECISION: Dict[str, str] = {}
+
+
+def _split(x: torch.Tensor, dt) -> Tuple[torch.Tensor, torch.Tensor]:
+    hi = x.to(dt).float()
+    return hi, (x - hi).to(dt).float()
+
+
+def _mm(cls: str, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a @ b with the operand rounding of `PRECISION[cls]` (fp32 accumulation; exact when the class has no entry)."""
+    scheme = PRECISION.get(cls)
+    if scheme is None:
+        return a @ b
+    dt = torch.bfloat16 if scheme.startswith("bf16") else torch.float16
+    ah, al = _split(a, dt)
+    bh, bl = _split(b, dt)
+    if scheme in ("bf16", "fp16"):
+        return ah @ bh
+    if scheme.endswith("x3"):
+        return ah @ bh + (ah @ bl + al @ bh)
+    if scheme == "fp16_a2":
+        return ah @ bh + al @ bh
+    if scheme == "fp16_b2":
+        return ah @ bh + ah @ bl
+    raise ValueError(scheme)
+
+
+def _linear(cls: str, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    if cls not in PRECISION:
+        return F.linear(x, w, b)
+    y = _mm(cls, x, w.t())
+    return y if b is None else y + b
+
+
 def attention(x: torch.Tensor, W: Dict[str, torch.Tensor], pre: str, heads: int) -> torch.Tensor:
     """`Attention.forward` (VideoMAE/utils.py:87-121): qkv bias = [q_bias | 0 | v_bias]; q scaled
     after bias; dense softmax(q k^T) v; output projection with bias."""
@@ -139,20 +179,27 @@ def attention(x: torch.Tensor, W: Dict[str, torch.Tensor], pre: str, heads: int)
     bias = None
     if q_bias is not None:
         bias = torch.cat((q_bias, torch.zeros_like(q_bias), W[pre + "v_bias"]))
-    qkv = F.linear(x, W[pre + "qkv.weight"], bias)
+    qkv = _linear("qkv", x, W[pre + "qkv.weight"], bias)
     qkv = qkv.reshape(B, N, 3, heads, -1).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     hd = q.shape[-1]
     q = q * (hd ** -0.5)
-    attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)
-    o = (attn @ v).transpose(1, 2).reshape(B, N, -1)
-    return F.linear(o, W[pre + "proj.weight"], W[pre + "proj.bias"])
+    if "pv" in PRECISION:
+        # the kernels multiply the UN-normalised exp(s - max) with v and divide by the row sum afterwards
+        s_ = _mm("qk", q, k.transpose(-2, -1))
+        p = torch.exp(s_ - s_.amax(dim=-1, keepdim=True))
+        o = _mm("pv", p, v) / p.sum(dim=-1, keepdim=True)
+    else:
+        attn = _mm("qk", q, k.transpose(-2, -1)).softmax(dim=-1)
+        o = attn @ v
+    o = o.transpose(1, 2).reshape(B, N, -1)
+    return _linear("proj", o, W[pre + "proj.weight"], W[pre + "proj.bias"])
 
 
 def mlp(x: torch.Tensor, W: Dict[str, torch.Tensor], pre: str) -> torch.Tensor:
     """`Mlp.forward` (VideoMAE/utils.py:47-54): fc2(GELU_erf(fc1(x)))."""
-    h = F.gelu(F.linear(x, W[pre + "fc1.weight"], W[pre + "fc1.bias"]))
-    return F.linear(h, W[pre + "fc2.weight"], W[pre + "fc2.bias"])
+    h = F.gelu(_linear("fc1", x, W[pre + "fc1.weight"], W[pre + "fc1.bias"]))
+    return _linear("fc2", h, W[pre + "fc2.weight"], W[pre + "fc2.bias"])
 
 
 def layer_norm(x: torch.Tensor, W: Dict[str, torch.Tensor], pre: str) -> torch.Tensor:

@@ -34,7 +34,7 @@ TINY = C.VmaeConfig(
 )
 
 
-def build_ref_model(ns, cfg: C.VmaeConfig, seed: int):
+def build_ref_model(ns, cfg: C.VmaeConfig, seed: int, sharp: bool = False):
     from functools import partial
 
     if cfg.name in ("base_8x8patch_2frames_1tube", "large_4x4patch_2frames_1tube", "base_16x16patch_2frames_1tube"):
@@ -56,15 +56,15 @@ def build_ref_model(ns, cfg: C.VmaeConfig, seed: int):
             tubelet_size=1,
             norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
         )
-    sd = {k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, seed).items()}
+    sd = {k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, seed, sharp=sharp).items()}
     res = m.load_state_dict(sd)
     assert not res.missing_keys and not res.unexpected_keys, res
     return m.eval().requires_grad_(False)
 
 
-def run_model_case(ns, cfg, *, batch, k_vis, clump, seed, out_name, through_wrapper=True):
+def run_model_case(ns, cfg, *, batch, k_vis, clump, seed, out_name, through_wrapper=True, sharp=False):
     t0 = time.time()
-    m = build_ref_model(ns, cfg, seed)
+    m = build_ref_model(ns, cfg, seed, sharp)
     x = torch.from_numpy(S.synthetic_frames(batch, cfg, seed))
     mask = torch.from_numpy(S.synthetic_masks(batch, cfg, k_vis, seed, clump))
     out = {
@@ -74,6 +74,7 @@ def run_model_case(ns, cfg, *, batch, k_vis, clump, seed, out_name, through_wrap
         "k_vis": np.array(k_vis),
         "clump": np.array(clump),
         "mask": mask.numpy(),
+        "sharp": np.array(sharp),
     }
     with torch.no_grad():
         if through_wrapper:
@@ -481,6 +482,13 @@ def run_init_case(ns):
     print("[golden] init_tiny.npz")
 
 
+def run_sharp_cases(ns):
+    """Numerically hostile weights (`synthetic.sharpen_state_dict`: near one-hot softmax, LayerNorm weights U(0.2, 3), residual
+    growth) through the reference: pins parity where operand rounding hurts most (VideoMAE/utils.py:87-121)."""
+    run_model_case(ns, TINY, batch=2, k_vis=4, clump=1, seed=6, out_name="tiny_8x8_sharp.npz", sharp=True)
+    run_model_case(ns, C.CONFIGS["base_8x8patch_2frames_1tube"], batch=1, k_vis=8, clump=1, seed=2, out_name="base8_sharp_b1.npz", sharp=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-large", action="store_true")
@@ -506,6 +514,9 @@ def main():
     if args.only == "flowstats":
         run_flowstats_case(ns)
         return
+    if args.only == "sharp":
+        run_sharp_cases(ns)
+        return
     run_init_case(ns)
     run_flowstats_case(ns)
     run_shift_cases(ns)
@@ -520,6 +531,7 @@ def main():
     base = C.CONFIGS["base_8x8patch_2frames_1tube"]
     run_model_case(ns, base, batch=2, k_vis=8, clump=1, seed=0, out_name="base8_k8_b2.npz")
     run_model_case(ns, base, batch=1, k_vis=1, clump=1, seed=1, out_name="base8_k1_b1.npz")
+    run_sharp_cases(ns)
     if not args.skip_large:
         large = C.CONFIGS["large_4x4patch_2frames_1tube"]
         run_model_case(ns, large, batch=1, k_vis=32, clump=2, seed=0, out_name="large4_k32_b1.npz",

@@ -69,8 +69,9 @@ def _worker(rank, world, port, S, chunk, hint, out_dir):
     shapes = ((1, 2, 3, 8, 8), (S, 2), NT) if hint else None
     y = cdist.sharded_counterfactual_predictions(x, prompts, _build, _rect, _predict, "cpu", chunk=chunk, shapes=shapes)
     assert isinstance(cdist.get_comm("cpu"), cdist.TorchComm)
+    used = cdist.get_comm("cpu").last_collective
     y_loc = cdist.sharded_counterfactual_predictions(x, prompts, _build, _rect, _predict, "cpu", chunk=chunk, gather=False, shapes=shapes)
-    torch.save((y, y_loc), os.path.join(out_dir, "y%d.pt" % rank))
+    torch.save((y, y_loc, used), os.path.join(out_dir, "y%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -83,16 +84,54 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,S,chunk,hint", [(2, 16, 4, True), (2, 13, 4, False), (2, 1, 32, True), (4, 16, 3, True), (4, 6, 32, False), (4, 3, 1, True)])
+@pytest.mark.parametrize("world,S,chunk,hint", [(2, 16, 4, True), (2, 13, 4, False), (2, 1, 32, True), (4, 16, 3, True), (4, 6, 32, False), (4, 3, 1, True),
+                                                 (2, 16, 8, True), (4, 16, 32, False)])
 def test_sharded_prompts_match_single_process(tmp_path, world, S, chunk, hint):
     mp.spawn(_worker, args=(world, _free_port(), S, chunk, hint, str(tmp_path)), nprocs=world, join=True)
     ref = _single(S, chunk)
     assert ref.shape == (S, 1)
     for r in range(world):
-        y, y_loc = torch.load(os.path.join(str(tmp_path), "y%d.pt" % r))
+        y, y_loc, used = torch.load(os.path.join(str(tmp_path), "y%d.pt" % r))
         assert torch.equal(y, ref), (r, S, chunk)              # all S rows, prompt order, on every rank
         lo, hi = cdist.shard_range(S, r, world)
         assert y_loc.shape == (hi - lo, 1)                      # gather=False keeps the local block (possibly empty)
+        # equal blocks, one chunk per rank (the 8-rank / 256-prompt shape) take the plain all-gather; per-chunk and ragged gathers the general form
+        equal_one_chunk = S % world == 0 and S // world <= chunk
+        assert used == ("all_gather_into_tensor" if equal_one_chunk else "all_gather(padded)"), (used, world, S, chunk)
+
+
+def _failing_worker(rank, world, port, hint, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, prompts = _inputs(6) if rank == 0 else (None, None)
+
+    def bad_rect(masks):
+        raise ValueError("rect failed on rank 0")
+
+    shapes = ((1, 2, 3, 8, 8), (6, 2), NT) if hint else None
+    try:
+        cdist.sharded_counterfactual_predictions(x, prompts, _build, bad_rect, _predict, "cpu", chunk=4, shapes=shapes)
+        res = "no error"
+    except Exception as e:  # noqa: BLE001
+        res = type(e).__name__
+    # a wrong shape hint is caught on rank 0 before the collective, and reaches the peers the same way
+    try:
+        cdist.sharded_counterfactual_predictions(x, prompts, _build, _rect, _predict, "cpu", chunk=4, shapes=((1, 2, 3, 8, 8), (7, 2), NT))
+        res2 = "no error"
+    except Exception as e:  # noqa: BLE001
+        res2 = type(e).__name__
+    torch.save((res, res2), os.path.join(out_dir, "e%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("hint", [True, False])
+def test_rank0_failure_reaches_every_rank(tmp_path, hint):
+    """A failure on rank 0 before the packed broadcast must not leave the peers blocked in the collective."""
+    mp.spawn(_failing_worker, args=(2, _free_port(), hint, str(tmp_path)), nprocs=2, join=True)
+    assert torch.load(os.path.join(str(tmp_path), "e0.pt")) == ("ValueError", "ValueError")
+    assert torch.load(os.path.join(str(tmp_path), "e1.pt")) == ("RemoteRankError", "RemoteRankError")
 
 
 def test_packed_buffer_round_trip():

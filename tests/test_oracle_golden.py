@@ -20,8 +20,8 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
-def weights(cfg, seed):
-    return {k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, seed).items()}
+def weights(cfg, seed, sharp=False):
+    return {k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, seed, sharp=sharp).items()}
 
 
 def oracle_case(g, cfg, spec):
@@ -30,7 +30,8 @@ def oracle_case(g, cfg, spec):
     mask = torch.from_numpy(S.synthetic_masks(batch, cfg, k_vis, seed, clump))
     assert np.array_equal(mask.numpy(), g["mask"])  # the synthetic generator is platform-stable
     with torch.no_grad():
-        return x, mask, O.predict(weights(cfg, seed), spec, x, mask, normalize=True, frame=None, return_tokens=True)
+        sharp = bool(g["sharp"]) if "sharp" in g.files else False
+        return x, mask, O.predict(weights(cfg, seed, sharp), spec, x, mask, normalize=True, frame=None, return_tokens=True)
 
 
 @pytest.mark.parametrize("name", ["tiny_8x8_k4.npz", "tiny_8x8_k1.npz"])
@@ -56,6 +57,38 @@ def test_base8_full_size(name):
     assert err <= 2e-5, err
     rows = video[:, 1, :, :: cfg.img_size[0] // 8].numpy()
     assert np.abs(rows - g["video_frame1_rows"]).max() <= 2e-5
+
+
+def test_sharp_weights_full_size():
+    """Numerically hostile weights (synthetic.sharpen_state_dict): sharp softmax, LayerNorm weights U(0.2, 3), residual growth.  The
+    reference's own fp32 rounding is 1.3e-5 here (fp32 vs float64), so the oracle is allowed 1e-4."""
+    g = load("base8_sharp_b1.npz")
+    assert bool(g["sharp"])
+    cfg = C.CONFIGS["base_8x8patch_2frames_1tube"]
+    _, _, (video, y) = oracle_case(g, cfg, O.SPECS[cfg.name])
+    err = np.abs(y.numpy() - g["y_tokens"]).max()
+    assert err <= 1e-4, err
+    g = load("tiny_8x8_sharp.npz")
+    _, _, (video, y) = oracle_case(g, TINY, TINY_SPEC)
+    assert np.abs(y.numpy() - g["y_tokens"]).max() <= 5e-5
+
+
+def test_precision_hooks_default_to_reference_arithmetic():
+    """The operand-rounding hooks (tests/precision_budget.py) must be inert by default and restore cleanly."""
+    g = load("tiny_8x8_k4.npz")
+    x, mask, (_, y) = oracle_case(g, TINY, TINY_SPEC)
+    assert not O.PRECISION
+    O.PRECISION.update({c: "bf16x3" for c in ("qk", "pv", "qkv", "proj", "fc1", "fc2")})
+    try:
+        with torch.no_grad():
+            y3 = O.vmae_forward(weights(TINY, int(g["seed"])), TINY_SPEC, O.preprocess(x), mask)
+    finally:
+        O.PRECISION.clear()
+    d = (y3 - y).abs().max().item()
+    assert 0 < d < 1e-4, d
+    with torch.no_grad():
+        y0 = O.vmae_forward(weights(TINY, int(g["seed"])), TINY_SPEC, O.preprocess(x), mask)
+    assert torch.equal(y0, y)
 
 
 def test_large4_full_size():
