@@ -27,6 +27,9 @@ import torch.distributed as dist  # noqa: E402
 from counterfactualworldmodels_amd import _lib, config as C, synthetic as S, vmae  # noqa: E402  (loading the library makes no HIP call)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0      # HBM3E (same guide)
+EDGE_CLASSES = (("layernorm_kernel", _lib.KCLASS_LAYERNORM), ("patch_gather_kernel", _lib.KCLASS_PATCH_GATHER),
+                ("fill_mask_tokens_kernel", _lib.KCLASS_FILL_MASK), ("unembed_kernel", _lib.KCLASS_UNEMBED))
 
 # BASELINE configs[3]: 256 motion-counterfactual prompts over ONE frame pair, sharded over the ranks
 # (rank 0 broadcasts frame + prompt table, every rank builds + predicts its slice, all-gather).
@@ -71,9 +74,22 @@ def pmc_traffic(args, kernel):
             summ = json.load(f)
         if summ.get("workload") != args.workload or summ.get("mode") != args.mode:
             return None
-        return summ["hbm_bytes_per_launch"].get(kernel)
+        return summ["hbm_bytes_per_launch"].get(kernel), summ.get("tag")
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
+
+
+def edge_kernels(collect):
+    """the HBM-bound edge kernels, achieved GB/s = algorithmic bytes of the launches (cwm_hip.h CWM_KCLASS_*: every input
+    element read once, every output element written once) / their summed HIP-event durations, against the 8 TB/s HBM peak."""
+    out = {}
+    for name, kc in EDGE_CLASSES:
+        st = collect(kc)
+        if st["launches"]:
+            gbs = st["total_flops"] / (st["total_ms"] * 1e-3) / 1e9   # (`total_flops` carries bytes for these classes)
+            out[name] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "launches": st["launches"],
+                         "avg_launch_us": 1e3 * st["total_ms"] / st["launches"], "bytes_per_launch": st["total_flops"] / st["launches"]}
+    return out
 
 
 def cpu_baseline(cfg, k_vis, clump, seed, budget_s=20.0):
@@ -193,24 +209,43 @@ def run_imu(args, rank, local_rank, world, distributed):
     def step():
         return model(x, mask, x_context=imu, mask_context=mc, normalize=True, check=False)
 
+    def region():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     step()
     model.set_lanes(args.lanes)
     for _ in range(max(args.warmup, 1)):
         step()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    dt = region()
+    # kernel region (as in the headline workload): the same steps on ONE lane with HIP events around every launch of a class
+    classes = {"gemm_wide": _lib.KCLASS_GEMM_WIDE, "gemm_narrow": _lib.KCLASS_GEMM_NARROW, "attention": _lib.KCLASS_ATTENTION,
+               "cross_attention": _lib.KCLASS_CROSS_ATTN, "context_self_attention": _lib.KCLASS_SMALL_ATTN}
+    model.set_lanes(1)
+    for _ in range(2):
         step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    for kc in [_lib.KCLASS_GEMM, _lib.KCLASS_ATTENTION, _lib.KCLASS_CROSS_ATTN, _lib.KCLASS_SMALL_ATTN] + [kc for _, kc in EDGE_CLASSES]:
+        model.timing_enable(kc, True)
+    dt_one = region()
+    model.timing_collect(_lib.KCLASS_GEMM)  # books the wide / narrow split
+    stats = {name: model.timing_collect(kc) for name, kc in classes.items()}
+    edge = edge_kernels(model.timing_collect)
+    for kc in [_lib.KCLASS_GEMM, _lib.KCLASS_ATTENTION, _lib.KCLASS_CROSS_ATTN, _lib.KCLASS_SMALL_ATTN] + [kc for _, kc in EDGE_CLASSES]:
+        model.timing_enable(kc, False)
+    model.set_lanes(args.lanes)
     n_gpus = world if distributed else 1
     flops_pair = 1.422e12  # SURVEY.md §8(d), cfg 5 (k=4)
     value = B * n_gpus * args.steps / dt
@@ -222,6 +257,19 @@ def run_imu(args, rank, local_rank, world, distributed):
                    "per_gpu_batch": B, "mode": args.mode, "lanes": args.lanes, "tokens_decoder": cfg.main.num_tokens + cfg.main_max_pad},
         "model_tflops": flops_pair * value / 1e12, "model_frac_of_bf16_peak": flops_pair * value / 1e12 / (PEAK_BF16_TFLOPS * n_gpus),
     }
+
+    def entry(st):
+        tf = st["total_flops"] / (st["total_ms"] * 1e-3) / 1e12 if st["total_ms"] > 0 else 0.0
+        return {"achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "launches": st["launches"],
+                "avg_launch_us": 1e3 * st["total_ms"] / max(st["launches"], 1), "share_of_step": st["total_ms"] / (1e3 * dt_one) if dt_one > 0 else None}
+
+    dom = max(("gemm_wide", "gemm_narrow", "attention"), key=lambda k: stats[k]["total_ms"])
+    names = {"gemm_wide": "cwm::gemm8p_kernel", "gemm_narrow": "cwm::gemm_bf16_kernel<128x128>", "attention": "cwm::attention_pipe_kernel",
+             "cross_attention": "cwm::cross_attn_mfma_kernel (+ combine)", "context_self_attention": "cwm::small_attn_mfma_kernel"}
+    out["roofline"] = dict(entry(stats[dom]), bound="mfma", kernel=names[dom], traffic=None, edge_kernels=edge,
+                           region={"lanes": 1, "steps": args.steps, "ms_per_step": 1e3 * dt_one / args.steps, "value": B * n_gpus * args.steps / dt_one},
+                           note="algorithmic FLOPs of the class's launches / their summed HIP-event durations in a one-lane kernel region (rank 0)",
+                           other_kernel={names[k]: entry(v) for k, v in stats.items() if k != dom})
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -327,13 +375,18 @@ def main():
             G.predict(x, mask, frame=None)
     model.timing_enable(_lib.KCLASS_GEMM, True)
     model.timing_enable(_lib.KCLASS_ATTENTION, True)
+    for _, kc in EDGE_CLASSES:
+        model.timing_enable(kc, True)
     dt_one = timed_steps(G, x, mask, n_vis, args.steps, distributed)
     gemm = model.timing_collect(_lib.KCLASS_GEMM)                 # every GEMM launch ...
     gemm_wide = model.timing_collect(_lib.KCLASS_GEMM_WIDE)       # ... split by the kernel that ran it
     gemm_narrow = model.timing_collect(_lib.KCLASS_GEMM_NARROW)
     attn = model.timing_collect(_lib.KCLASS_ATTENTION)            # softmax(q k^T) v: 4 N^2 64 FLOP per (batch, head)
+    edge = edge_kernels(model.timing_collect)
     model.timing_enable(_lib.KCLASS_GEMM, False)
     model.timing_enable(_lib.KCLASS_ATTENTION, False)
+    for _, kc in EDGE_CLASSES:
+        model.timing_enable(kc, False)
     model.set_lanes(args.lanes)
 
     value = B * n_gpus * args.steps / dt
@@ -368,9 +421,16 @@ def main():
     dom = max(kernels, key=lambda k: kernels[k]["total_ms"])  # dominant kernel = most device time in the timed region
     st = kernels[dom]
     ach = tflops(st)
+    traffic, traffic_tag = pmc_traffic(args, dom)
     out["roofline"] = {
         "bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-        "traffic": pmc_traffic(args, dom), "launches": st["launches"], "avg_launch_us": 1e3 * st["total_ms"] / max(st["launches"], 1),
+        "traffic": traffic,
+        "traffic_from_profile": {"bytes_per_launch": traffic, "tag": traffic_tag,
+                                 "note": "HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/<tag>_pmc_summary.json: separate "
+                                         "FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections); the counters cannot be read inside this process, so this "
+                                         "is the profile's number, not a measurement of this run"},
+        "edge_kernels": edge,
+        "launches": st["launches"], "avg_launch_us": 1e3 * st["total_ms"] / max(st["launches"], 1),
         "share_of_step": st["total_ms"] / (1e3 * dt_one) if dt_one > 0 else None,
         "region": {"lanes": 1, "steps": args.steps, "ms_per_step": 1e3 * dt_one / args.steps, "value": B * n_gpus * args.steps / dt_one,
                    "note": "kernel region: the same steps as the timed region, one lane, HIP events around every GEMM launch"},

@@ -24,6 +24,8 @@ KCLASS_GEMM = 0
 KCLASS_ATTENTION = 1
 KCLASS_GEMM_WIDE = 2    # 256x256 8-phase kernel launches (booked together with KCLASS_GEMM)
 KCLASS_GEMM_NARROW = 3  # 128x128 kernel launches
+KCLASS_LAYERNORM, KCLASS_PATCH_GATHER, KCLASS_FILL_MASK, KCLASS_UNEMBED = 4, 5, 6, 7  # HBM-bound: `total_flops` = algorithmic BYTES
+KCLASS_CROSS_ATTN, KCLASS_SMALL_ATTN = 8, 9  # IMU-conditioned model
 
 _MODES = {"fast": MODE_FAST, "parity": MODE_PARITY, MODE_FAST: MODE_FAST, MODE_PARITY: MODE_PARITY}
 

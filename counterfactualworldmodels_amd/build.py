@@ -10,7 +10,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcwm_hip.so")
-SOURCES = ["gemm.hip", "gemm_sk.hip", "attention.hip", "attention_pipe.hip", "elementwise.hip", "conj_kernels.hip", "flowstats.hip", "engine.hip", "model.hip", "conj_model.hip", "comm.hip"]
+SOURCES = ["gemm.hip", "gemm_sk.hip", "attention.hip", "attention_pipe.hip", "elementwise.hip", "conj_kernels.hip", "conj_attention.hip", "flowstats.hip", "engine.hip", "model.hip",
+           "conj_model.hip", "comm.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_device.h", "attention_device.h", "engine.h", os.path.join("..", "..", "include", "cwm_hip.h")]
 
 
@@ -66,9 +67,28 @@ def build_library(force: bool = False, verbose: bool = False, out_path: str = No
     if not force and out_path == LIB_PATH and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    tag = "prod" if out_path == LIB_PATH else "side_%08x" % (hash(tuple(extra)) & 0xFFFFFFFF)
+    import hashlib
+
+    # (hashlib, not hash(): the latter is salted per process, so side builds never found their objects again)
+    tag = "prod" if out_path == LIB_PATH else "side_" + hashlib.sha1(" ".join(extra + [os.path.abspath(out_path)]).encode()).hexdigest()[:8]
     obj_dir = os.path.join(PKG_DIR, "build", tag)
     os.makedirs(obj_dir, exist_ok=True)
+    # One builder at a time per object directory: under torchrun every rank that finds the library stale lands here at once and
+    # they would write the same objects and the same link output.  The lock is held over compile + link + replace; a rank that
+    # waited re-checks and usually finds the work done.
+    import fcntl
+
+    with open(os.path.join(obj_dir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and out_path == LIB_PATH and not needs_build():
+                return LIB_PATH
+            return _build_locked(out_path, extra, obj_dir, force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(out_path, extra, obj_dir, force, verbose):
     base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + extra
     hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     jobs, objs = [], []
@@ -99,10 +119,11 @@ def build_library(force: bool = False, verbose: bool = False, out_path: str = No
                     raise RuntimeError("hipcc failed on %s:\n%s" % (obj, log))
                 if verbose and log.strip():
                     print(log, file=sys.stderr)
-    res = subprocess.run(base + ["-shared"] + objs + ["-ldl", "-o", out_path + ".tmp"], capture_output=True, text=True)
+    tmp = "%s.tmp%d" % (out_path, os.getpid())
+    res = subprocess.run(base + ["-shared"] + objs + ["-ldl", "-o", tmp], capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
-    os.replace(out_path + ".tmp", out_path)
+    os.replace(tmp, out_path)
     with open(stamp, "w") as fh:
         fh.write(shash)
     return out_path

@@ -180,7 +180,7 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
     def sync_weights(self, device: Optional[torch.device] = None, force: bool = False) -> int:
         """See `vmae.PretrainVisionTransformer.sync_weights` (in-place `.data` edits need force=True)."""
         if device is None:
-            device = self._plist[0].device if self._plist else next(self.parameters()).device
+            device = self._param_device()
         if not force and self._handle is not None and self._handle_device == device and self._params_unchanged():
             return 0
         h = self._ensure_handle(device)

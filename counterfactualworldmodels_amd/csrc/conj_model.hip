@@ -84,6 +84,11 @@ void shift_stream(StreamW& S, int b0, int vcap, int mlp_ratio, bool small) {
     }
 }
 
+// scratch of the context-side partials: the larger of the two kernel forms' needs (conj_kernels.hip / conj_attention.hip)
+size_t cross_partial_floats(int B, int heads, int M, int head_dim) {
+    return std::max(cross_attention_partial_floats(B, heads, M, head_dim), cross_attention_mfma_partial_floats(B, heads, M, head_dim));
+}
+
 ConjLane conj_lane(cwm_conj_model* m, int lane, int b0) {
     ConjLane L;
     L.m = m;
@@ -100,7 +105,7 @@ ConjLane conj_lane(cwm_conj_model* m, int lane, int b0) {
     L.qk_src = m->qk_src + Mb * 2 * Dmax;
     L.v_src = m->v_src + Mb * Dmax;
     L.scores_t = m->scores_t + Nb * m->cfg.cross_heads * Mtok;
-    L.cross_partial = m->cross_partial + cross_attention_partial_floats(b0, m->cfg.cross_heads, Mtok, (int)Dmax / m->cfg.cross_heads);
+    L.cross_partial = m->cross_partial + cross_partial_floats(b0, m->cfg.cross_heads, Mtok, (int)Dmax / m->cfg.cross_heads);
     L.ybuf = m->ybuf + 2 * Nb * Dmax;
     L.ysbuf = m->ysbuf + 2 * Mb * Dmax;
     return L;
@@ -217,7 +222,7 @@ int ensure_workspace(cwm_conj_model* m, int B, int vmain, int vctx) {
     const int Mtok = m->ctx.n_tok + m->ctx.max_pad;
     if ((rc = E.ws(&m->err, 4)) || (rc = E.ws(&m->qk, Nmax * 2 * Dmax)) || (rc = E.ws(&m->v, Nmax * Dmax)) || (rc = E.ws(&m->qk_src, Mmax * 2 * Dmax)) ||
         (rc = E.ws(&m->v_src, Mmax * Dmax)) || (rc = E.ws(&m->scores_t, Nmax * m->cfg.cross_heads * Mtok)) ||
-        (rc = E.ws(&m->cross_partial, cross_attention_partial_floats(Bc, m->cfg.cross_heads, Mtok, (int)Dmax / m->cfg.cross_heads))) || (rc = E.ws(&m->ybuf, 2 * Nmax * Dmax)) ||
+        (rc = E.ws(&m->cross_partial, cross_partial_floats(Bc, m->cfg.cross_heads, Mtok, (int)Dmax / m->cfg.cross_heads))) || (rc = E.ws(&m->ybuf, 2 * Nmax * Dmax)) ||
         (rc = E.ws(&m->ysbuf, 2 * Mmax * Dmax)))
         return rc;
     m->ws_batch = Bc;
@@ -233,7 +238,14 @@ int layernorm_to(Engine& E, const float* x, int rows, int D, const float* g, con
     memset(&ln, 0, sizeof(ln));
     ln.x = x; ln.ldx = D; ln.gamma = g; ln.beta = b; ln.eps = E.ln_eps; ln.D = D; ln.rows = rows;
     ln.out = out; ln.out_plane = (int64_t)rows * D; ln.ldo = D;
-    return launch_layernorm(ln, planes, s);
+    return E.run_layernorm(ln, planes, s);
+}
+
+// y = A W^T in the GEMM A-operand layout (what the MFMA cross attention reads its token fragments from)
+int linear_operand(Engine& E, const bf16* A, int rows, int K, const LinearW& L, bf16* out, int planes, hipStream_t s) {
+    GemmParams g = gemm_base(A, K, L, rows, planes);
+    g.epi = EPI_BF16; g.out_hi = out; g.out_plane = (int64_t)rows * L.N; g.ldo = L.N;
+    return E.run_gemm(g, planes, s);
 }
 
 int linear_f32(Engine& E, const bf16* A, int rows, int K, const LinearW& L, float* C, const float* resid, int planes, hipStream_t s) {
@@ -257,16 +269,26 @@ int run_cross(ConjLane& L, const CrossW& C, float* x, int N, int ci, float* src,
     int rc;
     if ((rc = layernorm_to(E, x, rows, ci, C.n1_g, C.n1_b, L.main.sb.hbuf, planes, s))) return rc;
     if ((rc = layernorm_to(E, src, rows_s, cs, C.n1s_g, C.n1s_b, L.ctx.sb.hbuf, planes, s))) return rc;
-    if ((rc = linear_f32(E, L.main.sb.hbuf, rows, ci, C.qk, L.qk, nullptr, planes, s))) return rc;
-    if ((rc = linear_f32(E, L.main.sb.hbuf, rows, ci, C.v, L.v, nullptr, planes, s))) return rc;
+    // main-stream projections: operand layout (bf16 hi [, lo] planes, the same 4 bytes per element as fp32) for the MFMA kernel
+    const bool mfma = g_conj_attn && cross_attention_mfma_ok(hd, M) && (2 * D) % 32 == 0;
+    if (mfma) {
+        if ((rc = linear_operand(E, L.main.sb.hbuf, rows, ci, C.qk, reinterpret_cast<bf16*>(L.qk), planes, s))) return rc;
+        if ((rc = linear_operand(E, L.main.sb.hbuf, rows, ci, C.v, reinterpret_cast<bf16*>(L.v), planes, s))) return rc;
+    } else {
+        if ((rc = linear_f32(E, L.main.sb.hbuf, rows, ci, C.qk, L.qk, nullptr, planes, s))) return rc;
+        if ((rc = linear_f32(E, L.main.sb.hbuf, rows, ci, C.v, L.v, nullptr, planes, s))) return rc;
+    }
     if ((rc = linear_f32(E, L.ctx.sb.hbuf, rows_s, cs, C.qk_src, L.qk_src, nullptr, planes, s))) return rc;
     if ((rc = linear_f32(E, L.ctx.sb.hbuf, rows_s, cs, C.v_src, L.v_src, nullptr, planes, s))) return rc;
     CrossAttnParams ca;
     memset(&ca, 0, sizeof(ca));
-    ca.qk = L.qk; ca.v = L.v; ca.qk_src = L.qk_src; ca.v_src = L.v_src; ca.B = B; ca.N = N; ca.M = M; ca.heads = heads; ca.head_dim = hd;
+    ca.qk = L.qk; ca.v = L.v; ca.qk_op = reinterpret_cast<const bf16*>(L.qk); ca.v_op = reinterpret_cast<const bf16*>(L.v); ca.qk_src = L.qk_src; ca.v_src = L.v_src; ca.B = B; ca.N = N; ca.M = M; ca.heads = heads; ca.head_dim = hd;
     ca.scale = 1.0f / sqrtf((float)hd);
     ca.y = L.ybuf; ca.y_plane = (int64_t)rows * D; ca.y_src = L.ysbuf; ca.y_src_plane = (int64_t)rows_s * D; ca.scores_t = L.scores_t; ca.partial = L.cross_partial;
-    if ((rc = launch_cross_attention(ca, planes, s))) return rc;
+    // both directions: 2 x (scores 2 N M hd + P.V 2 N M hd) FLOP per head
+    if ((rc = E.timed(CWM_KCLASS_CROSS_ATTN, 8.0 * (double)B * heads * N * M * hd, s,
+                      [&] { return mfma ? launch_cross_attention_mfma(ca, planes, s) : launch_cross_attention(ca, planes, s); })))
+        return rc;
     if ((rc = linear_f32(E, L.ybuf, rows, D, C.proj, x, x, planes, s))) return rc;          // x += proj(y) + b
     if ((rc = linear_f32(E, L.ysbuf, rows_s, D, C.proj_src, src, src, planes, s))) return rc;
     if ((rc = layernorm_to(E, x, rows, ci, C.n2_g, C.n2_b, L.main.sb.hbuf, planes, s))) return rc;
@@ -298,7 +320,7 @@ int to_decoder(cwm_conj_model* m, StreamW& S, int B, int vmax, int planes, hipSt
     g.epi = EPI_F32; g.C = S.x_dec; g.ldc = S.dec_dim;
     g.resid = S.pos_dec_ext; g.ldr = S.dec_dim; g.resid_rowmap = S.perm; g.rows_in = vmax; g.rows_out = next; g.map_stride = next;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
-    return launch_fill_mask_tokens(S.x_dec, S.mask_token, S.pos_dec_ext, S.perm, B, next, vmax, S.dec_dim, s);
+    return E.run_fill_mask_tokens(S.x_dec, S.mask_token, S.pos_dec_ext, S.perm, B, next, vmax, S.dec_dim, s);
 }
 
 }  // namespace
@@ -401,7 +423,7 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
     pg.x = x_in; pg.sb = a->x_stride_b; pg.sc = a->x_stride_c; pg.st = a->x_stride_t; pg.normalize = a->normalize;
     pg.C = mc.in_chans; pg.H = mc.img_h; pg.W = mc.img_w; pg.P = mc.patch; pg.perm = A.perm; pg.Nt = A.n_tok; pg.perm_stride = Nx; pg.n_rows = vm; pg.B = B;
     pg.out = A.tokens_in; pg.out_plane = (int64_t)B * vm * A.embed_kpad; pg.ld = A.embed_kpad;
-    if ((rc = launch_patch_gather(pg, planes, s))) return rc;
+    if ((rc = E.run_patch_gather(pg, planes, s))) return rc;
     if ((rc = embed_stream(m, A, B, vm, planes, s))) return rc;
     ImuGatherParams ig;
     memset(&ig, 0, sizeof(ig));
@@ -433,7 +455,7 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
     ln.x = A.x_dec; ln.ldx = A.dec_dim; ln.gamma = A.dec_norm_g; ln.beta = A.dec_norm_b; ln.eps = E.ln_eps; ln.D = A.dec_dim;
     ln.rows = B * n_out; ln.rows_out_per_b = n_out; ln.rows_in_per_b = Nx; ln.in_offset = vm;
     ln.out = A.sb.hbuf; ln.out_plane = (int64_t)B * n_out * A.dec_dim; ln.ldo = A.dec_dim;
-    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+    if ((rc = E.run_layernorm(ln, planes, s))) return rc;
     GemmParams g = gemm_base(A.sb.hbuf, A.dec_dim, A.head, B * n_out, planes);
     g.epi = EPI_F32; g.C = y_tokens; g.ldc = A.out_dim;
     if ((rc = E.run_gemm(g, planes, s))) return rc;

@@ -260,12 +260,51 @@ __global__ __launch_bounds__(256) void fill_mask_tokens_kernel(float* x_full, co
     }
 }
 
+// The same rows without the LayerNorm-fold outputs (the default path): FOUR rows per thread, all loads (perm -> positional row) issued
+// before the first store.  One row per thread ran as ~4.6 rounds of short-lived waves, each a dependent perm -> pos -> store
+// chain: 2.9 TB/s of stores (13.1 us for 38 MB, ViT-B/8 batch 32); with four independent chains per thread the launch is one round.
+__global__ __launch_bounds__(256) void fill_mask_tokens4_kernel(float* x_full, const float* mask_token, const float* pos, const int* perm, int Nt,
+                                                                 int n_vis, int D, int64_t rows, int64_t rows_q) {
+    const int d4 = D / 4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rows_q * d4) return;
+    const int64_t r0 = gid / d4;
+    const int c4 = (int)(gid - r0 * d4);
+    const int nm = Nt - n_vis;
+    const float4 mt = *reinterpret_cast<const float4*>(mask_token + c4 * 4);
+    size_t orow[4];
+    int tau[4];
+    bool live[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = r0 + i * rows_q;
+        live[i] = row < rows;
+        const int64_t rr = live[i] ? row : 0;
+        const int b = (int)(rr / nm), j = (int)(rr - (int64_t)b * nm);
+        orow[i] = (size_t)b * Nt + n_vis + j;
+        tau[i] = perm[orow[i]];
+    }
+    float4 pe[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pe[i] = *reinterpret_cast<const float4*>(pos + (size_t)tau[i] * D + c4 * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (live[i]) *reinterpret_cast<float4*>(x_full + orow[i] * D + c4 * 4) = make_float4(mt.x + pe[i].x, mt.y + pe[i].y, mt.z + pe[i].z, mt.w + pe[i].w);
+}
+
 int launch_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt,
                             int n_vis, int D, hipStream_t stream, bf16* split, float2* stats, int planes) {
     CWM_REQUIRE(D % 4 == 0, "fill_mask_tokens: D must be a multiple of 4");
     CWM_REQUIRE(!split || (stats && D % 32 == 0), "fill_mask_tokens: split rows need a stats buffer and D %% 32 == 0");
     const int64_t total4 = (int64_t)B * (Nt - n_vis) * (D / 4);
     if (total4 == 0) return 0;
+    if (!split) {
+        const int64_t rows = (int64_t)B * (Nt - n_vis), rows_q = (rows + 3) / 4;
+        hipLaunchKernelGGL(fill_mask_tokens4_kernel, dim3((unsigned)((rows_q * (D / 4) + 255) / 256)), dim3(256), 0, stream, x_full, mask_token, pos,
+                           perm, Nt, n_vis, D, rows, rows_q);
+        CWM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (planes == 2)
         hipLaunchKernelGGL(fill_mask_tokens_kernel<2>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, x_full, mask_token, pos, perm,
                            Nt, n_vis, D, total4, split, stats);
@@ -308,8 +347,51 @@ __global__ __launch_bounds__(256) void unembed_kernel(const UnembedParams p) {
     *reinterpret_cast<float4*>(p.out + ((((size_t)b * p.T + t) * p.C + c) * p.H + y) * p.W + x0) = o;
 }
 
+// C == 3 (every predictor of the path): one thread per 4 horizontally adjacent pixels of ALL THREE channels.  A masked patch row is
+// 4 px x 3 channels = 12 consecutive floats of the token (feature order (ph pw c), c fastest): three aligned 16-byte loads, transposed
+// in registers, three 16-byte stores (one per channel plane).  The one-channel form above reads the same 48 bytes from three threads
+// of three different waves with 4-byte loads at a 12-byte stride: 3.0 TB/s (25.7 us for 77 MB at ViT-B/8 batch 32).
+__global__ __launch_bounds__(256) void unembed3_kernel(const UnembedParams p) {
+    const int w4 = p.W / 4;
+    const int64_t total = (int64_t)p.B * p.T * p.H * w4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    int64_t r = gid;
+    const int x4 = (int)(r % w4); r /= w4;
+    const int y = (int)(r % p.H); r /= p.H;
+    const int t = (int)(r % p.T);
+    const int b = (int)(r / p.T);
+    const int x0 = x4 * 4;
+    const int gw = p.W / p.P;
+    const int n = (p.H / p.P) * gw;
+    const int Nt = p.T * n;
+    const int tau = t * n + (y / p.P) * gw + (x0 / p.P);
+    float4 o[3];
+    if (p.mask[(size_t)b * Nt + tau]) {
+        const int j = p.rank[(size_t)b * Nt + tau] - p.n_vis;
+        const float4* yp = reinterpret_cast<const float4*>(p.y + ((size_t)b * p.Nm + j) * (p.P * p.P * 3) + ((y % p.P) * p.P + (x0 % p.P)) * 3);
+        const float4 a = yp[0], bb = yp[1], c = yp[2];  // px0 (r g b) px1 (r | g b) px2 (r g | b) px3 (r g b)
+        o[0] = make_float4(a.x, a.w, bb.z, c.y);
+        o[1] = make_float4(a.y, bb.x, bb.w, c.z);
+        o[2] = make_float4(a.z, bb.y, c.x, c.w);
+    } else {
+        const float* src = p.x + b * p.sb + t * p.st + (int64_t)y * p.W + x0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = *reinterpret_cast<const float4*>(src + c * p.sc);
+    }
+    float* dst = p.out + (((size_t)b * p.T + t) * 3 * p.H + y) * p.W + x0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(dst + (size_t)c * p.H * p.W) = o[c];
+}
+
 int launch_unembed(const UnembedParams& p, hipStream_t stream) {
     CWM_REQUIRE(p.P % 4 == 0 && p.W % 4 == 0, "unembed: patch size and width must be multiples of 4");
+    if (p.C == 3 && (((uintptr_t)p.y | (uintptr_t)p.out | (uintptr_t)p.x) & 15) == 0 && (p.sc % 4 == 0) && (p.sb % 4 == 0) && (p.st % 4 == 0)) {
+        const int64_t total3 = (int64_t)p.B * p.T * p.H * (p.W / 4);
+        hipLaunchKernelGGL(unembed3_kernel, dim3((unsigned)((total3 + 255) / 256)), dim3(256), 0, stream, p);
+        CWM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const int64_t total = (int64_t)p.B * p.T * p.C * p.H * (p.W / 4);
     hipLaunchKernelGGL(unembed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
     CWM_HIP_CHECK(hipGetLastError());
@@ -324,6 +406,8 @@ int launch_unembed(const UnembedParams& p, hipStream_t stream) {
 //   frame `frame`: the destination patch (pi,pj) of every active patch (pi-dy, pj-dx) receives the
 //   active patch's pixels; everything else is the (static) input.  Pure copies: bit-exact.
 //   mask_out = (active ? masks : 1) & (shifted perturbation mask), destinations out of frame vanish.
+// fix_passive: 0 = the movie as given; 1 = every frame := frame 0 (`make_static_movie`); 2 = `MakeStatic` (perturbation.py:120-145)
+// applied before the shift: only the patches that `masks` leaves visible are replaced by their frame-0 pixels.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void shift_prompts_x_kernel(const ShiftPromptParams p) {
     const int w4 = p.W / 4;
@@ -338,7 +422,7 @@ __global__ __launch_bounds__(256) void shift_prompts_x_kernel(const ShiftPromptP
     const int i = (int)(r / p.T);
     const int b = i / p.S;
     const int x0 = x4 * 4;
-    const int ft = p.fix_passive ? 0 : t;
+    int ft = p.fix_passive == 1 ? 0 : t;
     int sy = y, sx = x0;
     if (t == p.frame) {
         const int gw = p.W / p.P, gh = p.H / p.P, n = gh * gw;
@@ -348,6 +432,10 @@ __global__ __launch_bounds__(256) void shift_prompts_x_kernel(const ShiftPromptP
             sy = y - dy * p.P;
             sx = x0 - dx * p.P;
         }
+    }
+    if (p.fix_passive == 2) {  // MakeStatic (perturbation.py:120-145): the patches `masks` leaves visible take their frame-0 pixels
+        const int gw = p.W / p.P, n = (p.H / p.P) * gw;
+        if (p.masks[(size_t)i * p.T * n + (size_t)t * n + (sy / p.P) * gw + sx / p.P] == 0) ft = 0;
     }
     const float4 v = *reinterpret_cast<const float4*>(p.x + ((((size_t)b * p.T + ft) * p.C + c) * p.H + sy) * p.W + sx);
     *reinterpret_cast<float4*>(p.x_out + ((((size_t)i * p.T + t) * p.C + c) * p.H + y) * p.W + x0) = v;
@@ -374,6 +462,7 @@ __global__ __launch_bounds__(256) void shift_prompts_mask_kernel(const ShiftProm
 int launch_shift_prompts(const ShiftPromptParams& p, hipStream_t stream) {
     CWM_REQUIRE(p.P % 4 == 0 && p.W % 4 == 0 && p.H % p.P == 0 && p.W % p.P == 0, "shift_prompts: bad patch/image size");
     CWM_REQUIRE(p.frame >= 0 && p.frame < p.T, "shift_prompts: frame out of range");
+    CWM_REQUIRE(p.fix_passive >= 0 && p.fix_passive <= 2, "shift_prompts: fix_passive must be 0, 1 or 2");
     const int64_t tx = (int64_t)p.B * p.S * p.T * p.C * p.H * (p.W / 4);
     const int64_t tm = (int64_t)p.B * p.S * p.T * (p.H / p.P) * (p.W / p.P);
     hipLaunchKernelGGL(shift_prompts_x_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, stream, p);

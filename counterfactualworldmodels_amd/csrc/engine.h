@@ -120,6 +120,22 @@ struct Engine {
 
     int run_gemm(const GemmParams& p, int planes, hipStream_t s);
     int run_attention(const AttnParams& p, int planes, hipStream_t s);
+    // the HBM-bound edge kernels, booked by class with their algorithmic bytes (cwm_hip.h CWM_KCLASS_*)
+    int run_layernorm(const LayerNormParams& p, int planes, hipStream_t s);
+    int run_patch_gather(const PatchGatherParams& p, int planes, hipStream_t s);
+    int run_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt, int n_vis, int D,
+                             hipStream_t s, bf16* split = nullptr, float2* stats = nullptr, int planes = 2);
+    int run_unembed(const UnembedParams& p, hipStream_t s);
+    // `launch()` between an event pair of class `kclass` (no events unless the class is enabled); work = FLOPs or bytes
+    template <typename F>
+    int timed(int kclass, double work, hipStream_t s, F&& launch) {
+        EventPair* e = nullptr;
+        if (int rc = timer_begin(kclass, work, s, &e)) return rc;
+        if (int rc = launch()) return rc;
+        return timer_end(e, s);
+    }
+    int timer_begin(int kclass, double work, hipStream_t s, EventPair** out);
+    int timer_end(EventPair* e, hipStream_t s);
     // Block.forward (VideoMAE/utils.py:146-153) on a residual stream x[B*n_tok, D] (in place), head_dim 64
     // sb.xsplit != nullptr: LayerNorm-fold form -- on entry sb.xsplit / sb.xstats describe x (rows identical to x's), on exit the block's
     // output rows (compact kept rows when n_keep is set); no LayerNorm launch

@@ -340,7 +340,8 @@ int Engine::missing_weights(char* buf, int buflen) {
 }
 
 // ---- timed launches ---------------------------------------------------------------------------
-static int timer_begin(KernelTimer& t, double flops, hipStream_t s, EventPair** out) {
+int Engine::timer_begin(int kclass, double flops, hipStream_t s, EventPair** out) {
+    KernelTimer& t = timers[kclass];
     *out = nullptr;
     if (!t.enabled) return 0;
     if (t.used == t.pool.size()) {
@@ -357,7 +358,7 @@ static int timer_begin(KernelTimer& t, double flops, hipStream_t s, EventPair** 
     return 0;
 }
 
-static int timer_end(EventPair* e, hipStream_t s) {
+int Engine::timer_end(EventPair* e, hipStream_t s) {
     if (e) CWM_HIP_CHECK(hipEventRecord(e->b, s));
     return 0;
 }
@@ -365,7 +366,8 @@ static int timer_end(EventPair* e, hipStream_t s) {
 int Engine::run_gemm(const GemmParams& p_in, int planes, hipStream_t s) {
     GemmParams p = p_in;
     p.overlapped = overlapped;
-    if ((int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) <= 256) {  // a launch small enough for the split-K kernel: hand it this stream's workspace
+    {   // every launch carries this stream's split-K workspace: the remainder rows of a mixed-tiling launch can be a small, deep
+        // launch (fc2 of a single-lane batch) even when the whole GEMM is not
         auto it = splitk_ws.find(s);
         if (it == splitk_ws.end()) {
             SplitKWs w = {nullptr, nullptr};
@@ -389,7 +391,7 @@ int Engine::run_gemm(const GemmParams& p_in, int planes, hipStream_t s) {
     }
     for (int i = 0; i < nparts; ++i) {
         EventPair* e;
-        if (int rc = timer_begin(timers[CWM_KCLASS_GEMM], 2.0 * part[i].M * (double)part[i].N * part[i].K, s, &e)) return rc;
+        if (int rc = timer_begin(CWM_KCLASS_GEMM, 2.0 * part[i].M * (double)part[i].N * part[i].K, s, &e)) return rc;
         if (e) e->sub = (cfgs[i] >= 3 && cfgs[i] != 6) ? CWM_KCLASS_GEMM_WIDE : CWM_KCLASS_GEMM_NARROW;
         if (int rc = (nparts == 2 ? launch_gemm_tile(part[i], planes, cfgs[i], s) : launch_gemm(part[i], planes, s))) return rc;
         if (int rc = timer_end(e, s)) return rc;
@@ -400,9 +402,27 @@ int Engine::run_gemm(const GemmParams& p_in, int planes, hipStream_t s) {
 int Engine::run_attention(const AttnParams& p, int planes, hipStream_t s) {
     EventPair* e;
     const double fl = 4.0 * (double)p.n_tok * p.n_tok * 64.0 * p.heads * p.batch;
-    if (int rc = timer_begin(timers[CWM_KCLASS_ATTENTION], fl, s, &e)) return rc;
+    if (int rc = timer_begin(CWM_KCLASS_ATTENTION, fl, s, &e)) return rc;
     if (int rc = launch_attention(p, planes, s)) return rc;
     return timer_end(e, s);
+}
+
+int Engine::run_layernorm(const LayerNormParams& p, int planes, hipStream_t s) {
+    return timed(CWM_KCLASS_LAYERNORM, (double)p.rows * p.D * (4.0 + 2.0 * planes), s, [&] { return launch_layernorm(p, planes, s); });
+}
+
+int Engine::run_patch_gather(const PatchGatherParams& p, int planes, hipStream_t s) {
+    return timed(CWM_KCLASS_PATCH_GATHER, (double)p.B * p.n_rows * p.C * p.P * p.P * (4.0 + 2.0 * planes), s, [&] { return launch_patch_gather(p, planes, s); });
+}
+
+int Engine::run_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt, int n_vis, int D,
+                                 hipStream_t s, bf16* split, float2* stats, int planes) {
+    return timed(CWM_KCLASS_FILL_MASK, (double)B * (Nt - n_vis) * D * 4.0, s,
+                 [&] { return launch_fill_mask_tokens(x_full, mask_token, pos, perm, B, Nt, n_vis, D, s, split, stats, planes); });
+}
+
+int Engine::run_unembed(const UnembedParams& p, hipStream_t s) {
+    return timed(CWM_KCLASS_UNEMBED, (double)p.B * p.T * p.C * p.H * p.W * 8.0, s, [&] { return launch_unembed(p, s); });
 }
 
 int Engine::timing_enable(int kclass, int enable) {
@@ -472,7 +492,7 @@ int Engine::run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H,
     memset(&ln, 0, sizeof(ln));
     ln.x = x; ln.ldx = D; ln.gamma = w.ln1_g; ln.beta = w.ln1_b; ln.eps = ln_eps; ln.D = D; ln.rows = M;
     ln.out = sb.hbuf; ln.out_plane = hplane; ln.ldo = D;
-    if (!fold && (rc = launch_layernorm(ln, planes, s))) return rc;
+    if (!fold && (rc = run_layernorm(ln, planes, s))) return rc;
 
     GemmParams g = fold ? fold_gemm(sb.xsplit, sb.xstats, w.qkv, M, planes) : gemm_base(sb.hbuf, D, w.qkv, M, planes);
     g.epi = EPI_QKV;
@@ -503,7 +523,7 @@ int Engine::run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H,
     if (!fold) {
         ln.gamma = w.ln2_g; ln.beta = w.ln2_b;
         if (part) { ln.rows = Mo; ln.rows_out_per_b = n_out; ln.rows_in_per_b = n_tok; ln.in_offset = first; ln.out_plane = (int64_t)Mo * D; }
-        if ((rc = launch_layernorm(ln, planes, s))) return rc;
+        if ((rc = run_layernorm(ln, planes, s))) return rc;
     }
     g = fold ? fold_gemm(sb.xsplit, sb.xstats, w.fc1, Mo, planes) : gemm_base(sb.hbuf, D, w.fc1, Mo, planes);
     g.epi = EPI_BF16_GELU; g.out_hi = sb.gbuf; g.out_plane = (int64_t)Mo * hidden; g.ldo = hidden;
@@ -525,7 +545,7 @@ int Engine::run_block_small(const BlockW& w, float* x, int B, int n_tok, int D, 
     memset(&ln, 0, sizeof(ln));
     ln.x = x; ln.ldx = D; ln.gamma = w.ln1_g; ln.beta = w.ln1_b; ln.eps = ln_eps; ln.D = D; ln.rows = M;
     ln.out = sb.hbuf; ln.out_plane = hplane; ln.ldo = D;
-    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+    if ((rc = run_layernorm(ln, planes, s))) return rc;
 
     GemmParams g = gemm_base(sb.hbuf, D, w.qkv, M, planes);
     g.epi = EPI_F32; g.C = sb.qkv_f32; g.ldc = 3 * D;
@@ -535,14 +555,17 @@ int Engine::run_block_small(const BlockW& w, float* x, int B, int n_tok, int D, 
     memset(&a, 0, sizeof(a));
     a.qkv = sb.qkv_f32; a.B = B; a.n_tok = n_tok; a.heads = H; a.head_dim = D / H;
     a.o = sb.hbuf; a.o_plane = hplane; a.ldo = D;
-    if ((rc = launch_small_attention(a, planes, s))) return rc;
+    if ((rc = timed(CWM_KCLASS_SMALL_ATTN, 4.0 * (double)B * H * n_tok * n_tok * (D / H), s, [&] {
+             return (g_conj_attn && small_attention_mfma_ok(n_tok, D / H) && D % 32 == 0) ? launch_small_attention_mfma(a, planes, s) : launch_small_attention(a, planes, s);
+         })))
+        return rc;
 
     g = gemm_base(sb.hbuf, D, w.proj, M, planes);
     g.epi = EPI_F32; g.C = x; g.ldc = D; g.resid = x; g.ldr = D;
     if ((rc = run_gemm(g, planes, s))) return rc;
 
     ln.gamma = w.ln2_g; ln.beta = w.ln2_b;
-    if ((rc = launch_layernorm(ln, planes, s))) return rc;
+    if ((rc = run_layernorm(ln, planes, s))) return rc;
 
     g = gemm_base(sb.hbuf, D, w.fc1, M, planes);
     g.epi = EPI_BF16_GELU; g.out_hi = sb.gbuf; g.out_plane = (int64_t)M * hidden; g.ldo = hidden;

@@ -23,6 +23,10 @@
 //   columns of one row
 // * fused epilogues (bias, residual(+row map), exact-erf GELU, bf16 hi/lo split, Q / K / V head scatter), staged through LDS so
 //   that every global access is an unconditional 16-byte lane access forming whole row segments (gemm_device.h)
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "gemm_device.h"
 #include <cstdio>
 #include <algorithm>
@@ -659,18 +663,22 @@ static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t strea
         int sk = std::min(std::min(cus / tiles128, nk_all / 12), 8);
         if (sk >= 3) {
             if (!p.sk2_slabs) {
-                // callers without a workspace of their own (the stand-alone entry points: one stream, one thread at a time)
-                static float* slabs = nullptr;
-                static unsigned* counts = nullptr;
-                static int slabs_dev = -1;
+                // callers without a workspace of their own (the stand-alone entry points, cwm_linear): one workspace per (device,
+                // stream), created under a lock -- launches on one stream are ordered, so they may share it; two streams never do
+                struct Ws { float* slabs; unsigned* counts; };
+                static std::mutex mu;
+                static std::map<std::pair<int, hipStream_t>, Ws> table;
                 int dev = 0;
                 CWM_HIP_CHECK(hipGetDevice(&dev));
-                if (!slabs || slabs_dev != dev) {
-                    if (int rc = splitk_workspace_alloc(&slabs, &counts)) return rc;
-                    slabs_dev = dev;
+                std::lock_guard<std::mutex> lock(mu);
+                auto it = table.find(std::make_pair(dev, stream));
+                if (it == table.end()) {
+                    Ws w = {nullptr, nullptr};
+                    if (int rc = splitk_workspace_alloc(&w.slabs, &w.counts)) return rc;
+                    it = table.emplace(std::make_pair(dev, stream), w).first;
                 }
-                p.sk2_slabs = slabs;
-                p.sk2_count = counts;
+                p.sk2_slabs = it->second.slabs;
+                p.sk2_count = it->second.counts;
             }
             p.splitk = sk;
         }

@@ -182,7 +182,9 @@ struct SmallAttnParams {
     int64_t o_plane;
     int ldo;
 };
-int launch_small_attention(const SmallAttnParams& p, int planes, hipStream_t stream);
+int launch_small_attention(const SmallAttnParams& p, int planes, hipStream_t stream);       // conj_kernels.hip: fp32 VALU form (any head_dim <= 64)
+int launch_small_attention_mfma(const SmallAttnParams& p, int planes, hipStream_t stream);  // conj_attention.hip: head_dim 32
+bool small_attention_mfma_ok(int n_tok, int head_dim);
 
 // ext_mask[b] = [mask[b] | pad slot j masked unless j < vmax - visible(b)]  (conjoined_vmae.py:49-116)
 int launch_pad_mask(const uint8_t* mask, int B, int N, int P, int vmax, uint8_t* ext_mask, hipStream_t stream);
@@ -203,8 +205,10 @@ struct ImuGatherParams {
 int launch_imu_gather(const ImuGatherParams& p, int planes, hipStream_t stream);
 
 struct CrossAttnParams {
-    const float* qk;      // [B*N][2D] main stream (fp32)
+    const float* qk;      // [B*N][2D] main stream (fp32)                 -- VALU kernels (conj_kernels.hip)
     const float* v;       // [B*N][D]
+    const bf16* qk_op;    // the same projections in the GEMM A-operand layout (common.h a_pos, row width 2D / D) -- MFMA kernel (conj_attention.hip)
+    const bf16* v_op;
     const float* qk_src;  // [B*M][2D] context stream
     const float* v_src;   // [B*M][D]
     int B, N, M, heads, head_dim;  // D = heads*head_dim
@@ -216,8 +220,12 @@ struct CrossAttnParams {
     float* scores_t;      // scratch [B][heads][M][N]
     float* partial;       // scratch, cross_attention_partial_floats(B, heads, M, head_dim) floats
 };
-int launch_cross_attention(const CrossAttnParams& p, int planes, hipStream_t stream);
+int launch_cross_attention(const CrossAttnParams& p, int planes, hipStream_t stream);       // fp32 VALU kernels: qk / v fp32, scores_t + partial scratch
 size_t cross_attention_partial_floats(int B, int heads, int M, int head_dim);
+int launch_cross_attention_mfma(const CrossAttnParams& p, int planes, hipStream_t stream);  // MFMA kernel: qk_op / v_op, partial scratch
+bool cross_attention_mfma_ok(int head_dim, int M);
+size_t cross_attention_mfma_partial_floats(int B, int heads, int M, int head_dim);
+extern int g_conj_attn;  // 1 (default): MFMA cross / small attention where the shapes allow; 0: the fp32 VALU kernels ("conj_attn" switch)
 
 int launch_perm_to_rank(const int* perm, int* rank, int B, int Nt, hipStream_t stream);
 

@@ -216,7 +216,7 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
     pg.x = x_in; pg.sb = a->x_stride_b; pg.sc = a->x_stride_c; pg.st = a->x_stride_t; pg.normalize = a->normalize;
     pg.C = c.in_chans; pg.H = c.img_h; pg.W = c.img_w; pg.P = c.patch; pg.perm = w.perm; pg.Nt = Nt; pg.n_rows = Nv; pg.B = B;
     pg.out = w.patches; pg.out_plane = (int64_t)B * Nv * m->patch_kpad; pg.ld = m->patch_kpad;
-    if ((rc = launch_patch_gather(pg, planes, s))) return rc;
+    if ((rc = E.run_patch_gather(pg, planes, s))) return rc;
     }
 
     // LayerNorm folded into the GEMMs around it (engine.h): no LayerNorm launch anywhere on the path.  Needs the LDS-staged epilogues.
@@ -247,13 +247,13 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
         memset(&ln, 0, sizeof(ln));
         ln.x = w.x_enc; ln.ldx = c.enc_dim; ln.gamma = m->enc_norm_g; ln.beta = m->enc_norm_b; ln.eps = c.ln_eps; ln.D = c.enc_dim;
         ln.rows = B * Nv; ln.out = w.sb.hbuf; ln.out_plane = (int64_t)B * Nv * c.enc_dim; ln.ldo = c.enc_dim;
-        if ((rc = launch_layernorm(ln, planes, s))) return rc;
+        if ((rc = E.run_layernorm(ln, planes, s))) return rc;
         g = gemm_base(w.sb.hbuf, c.enc_dim, m->e2d, B * Nv, planes);
     }
     g.epi = EPI_F32; g.C = w.x_dec; g.ldc = c.dec_dim;
     g.resid = m->pos_dec; g.ldr = c.dec_dim; g.resid_rowmap = w.perm; g.rows_in = Nv; g.rows_out = Nt; g.map_stride = Nt;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
-    if (Nm > 0 && (rc = launch_fill_mask_tokens(w.x_dec, m->mask_token, m->pos_dec, w.perm, B, Nt, Nv, c.dec_dim, s, fold ? sb_dec.xsplit : nullptr,
+    if (Nm > 0 && (rc = E.run_fill_mask_tokens(w.x_dec, m->mask_token, m->pos_dec, w.perm, B, Nt, Nv, c.dec_dim, s, fold ? sb_dec.xsplit : nullptr,
                                                 fold ? sb_dec.xstats : nullptr, planes)))
         return rc;
     }
@@ -274,7 +274,7 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
         ln.x = w.x_dec; ln.ldx = c.dec_dim; ln.gamma = m->dec_norm_g; ln.beta = m->dec_norm_b; ln.eps = c.ln_eps; ln.D = c.dec_dim;
         ln.rows = B * Nret; ln.rows_out_per_b = Nret; ln.rows_in_per_b = Nt; ln.in_offset = Nt - Nret;
         ln.out = w.sb.hbuf; ln.out_plane = (int64_t)B * Nret * c.dec_dim; ln.ldo = c.dec_dim;
-        if ((rc = launch_layernorm(ln, planes, s))) return rc;
+        if ((rc = E.run_layernorm(ln, planes, s))) return rc;
         g = gemm_base(w.sb.hbuf, c.dec_dim, m->head, B * Nret, planes);
     }
     g.epi = EPI_F32; g.C = y_tokens; g.ldc = m->out_dim;
@@ -290,7 +290,7 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
         u.mask = mask_in; u.rank = w.rank; u.B = B; u.T = c.num_frames; u.C = c.in_chans; u.H = c.img_h; u.W = c.img_w;
         u.P = c.patch; u.n_vis = Nv; u.Nm = Nm;
         u.out = a->y_video_dev + (size_t)b0 * c.num_frames * c.in_chans * c.img_h * c.img_w;
-        if ((rc = launch_unembed(u, s))) return rc;
+        if ((rc = E.run_unembed(u, s))) return rc;
     }
     return CWM_OK;
 }
@@ -635,6 +635,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
     }
     if (!strcmp(key, "attn_remap")) {
         g_attn_remap = value;
+        return CWM_OK;
+    }
+    if (!strcmp(key, "conj_attn")) {  // 1: MFMA cross / small attention of the IMU-conditioned model (conj_attention.hip); 0: the fp32 VALU kernels
+        g_conj_attn = value;
         return CWM_OK;
     }
     if (!strcmp(key, "attn_kernel")) {

@@ -432,21 +432,23 @@ class PredictorBasedGenerator(nn.Module):
         mask_shift = torch.empty((R, N), device=dev, dtype=torch.bool)
         with torch.cuda.device(dev):
             _lib.check(_lib.get_lib().cwm_shift_prompts(
-                x.data_ptr(), B, T, Cc, H, W, self.patch_size[-1], frame % T, samples_per_movie, int(bool(fix_passive)),
+                x.data_ptr(), B, T, Cc, H, W, self.patch_size[-1], frame % T, samples_per_movie,
+                2 if fix_passive == "make_static" else int(bool(fix_passive)),
                 active.data_ptr(), passive.data_ptr(), shifts.data_ptr(), x_shift.data_ptr(), mask_shift.data_ptr(),
                 _lib.current_stream_handle(dev)))
         return x_shift, mask_shift
 
-    def _shift(self, x, mask, active_patches=None, shift=None, frame=1):
+    def _shift(self, x, mask, active_patches=None, shift=None, frame=1, fix_passive=False):
         """One shift applied to every movie of x (prediction.py:760-779): returns (x_shift, rectangularised mask_shift) and
-        appends the shift (patch units) to `self.shifts`."""
+        appends the shift (patch units) to `self.shifts`.  fix_passive="make_static" applies `MakeStatic` (perturbation.py:120-145)
+        to the patches `mask` leaves visible first, in the same kernel."""
         if active_patches is None:
             active_patches = torch.ones_like(mask)
         self.inp_shape = x.shape
         dy, dx = self._random_mask_shift() if shift is None else (int(shift[0]), int(shift[1]))
         table = torch.tensor([[dy, dx]], dtype=torch.int32).expand(x.shape[0], 2)
         x_shift, mask_shift = self._shift_rows(x, mask.reshape(x.shape[0], -1), active_patches.reshape(x.shape[0], -1), table, frame,
-                                               fix_passive=False)
+                                               fix_passive=fix_passive)
         self._record_shift(dy, dx)
         return x_shift, self.mask_rectangularizer(mask_shift)
 
@@ -462,11 +464,19 @@ class PredictorBasedGenerator(nn.Module):
         self.inp_shape = x.shape
         mask = self.get_zeros_mask(x) if mask is None else mask
         active_patches = self.get_zeros_mask(x) if active_patches is None else active_patches
-        if fix_passive:
-            raise NotImplementedError("fix_passive=True (MakeStatic on the passive patches, perturbation.py:120-149) is not on the "
-                                      "predictor path; pass a static movie instead, as the UI does (interface.py:275-277)")
-        x_p, mask_p = self._shift(x, mask, active_patches=active_patches, shift=shift, frame=1)
+        # fix_passive: `x, _ = self.make_static(x, mask)` (prediction.py:802-803) folded into the prompt kernel
+        x_p, mask_p = self._shift(x, mask, active_patches=active_patches, shift=shift, frame=1,
+                                  fix_passive="make_static" if fix_passive else False)
         return self.predict(x_p, mask_p, frame=None, **kwargs)
+
+    def make_static(self, x, mask):
+        """`MakeStatic` (perturbation.py:120-145; the generator's `make_static` attribute, prediction.py:51-55): the patches `mask`
+        leaves visible in frames t > 0 take the pixels of the same patch in frame 0.  Returns (x_static, mask) like the reference."""
+        B = x.shape[0]
+        m = mask.reshape(B, -1)
+        zero = torch.zeros((B, 2), dtype=torch.int32)
+        x_static, _ = self._shift_rows(x, m, torch.ones_like(m), zero, 1, fix_passive="make_static")
+        return x_static, mask
 
     def forward(self, x, mask=None, frame=None, *args, **kwargs):
         self.set_input(x, mask)

@@ -116,8 +116,11 @@ class PretrainVisionTransformerDecoder(_NoForward):
 class WeightSync:
     """Mixin: a cheap "has any parameter changed since the last upload?" test for the modules that mirror their parameters into
     the library.  Walking `state_dict()` costs ~0.3 ms per forward for ViT-B (218 tensors) -- GPU idle time whenever the caller
-    synchronises between forwards -- so the tensors are listed once and only their version counters are compared (~20 us).  The
-    list is rebuilt after anything that can replace parameter objects (`load_state_dict`, `.to()` / `.cuda()` / `.float()`)."""
+    synchronises between forwards -- so the tensors are listed once, each with the module dict that owns it, and a forward only
+    checks (a) that every slot still holds the listed object (`setattr` / `register_parameter` replacing a Parameter, also through
+    a SUBMODULE's `.to()` when torch swaps parameter objects) and (b) the (storage pointer, version counter) pairs (`p.data = ...`,
+    `encoder.double()`, `copy_`, optimiser steps, `load_state_dict`): ~60 us.  Not visible to it: in-place edits through `.data`
+    that keep the storage (`p.data.mul_(2)`): call `sync_weights(force=True)` after those."""
 
     def _init_weight_sync(self):
         self._plist = None
@@ -132,12 +135,25 @@ class WeightSync:
         self._plist = None
         return out
 
+    def _param_device(self):
+        return self._plist[0][2].device if self._plist else next(self.parameters()).device
+
     def _params_unchanged(self) -> bool:
-        return self._plist is not None and tuple(p._version for p in self._plist) == self._psig
+        pl = self._plist
+        if pl is None:
+            return False
+        for slots, key, p in pl:
+            if slots.get(key) is not p:
+                return False
+        return tuple((p.data_ptr(), p._version) for _, _, p in pl) == self._psig
 
     def _remember_params(self):
-        self._plist = list(self.state_dict(keep_vars=True).values())
-        self._psig = tuple(p._version for p in self._plist)
+        pl = []
+        for mod in self.modules():
+            pl += [(mod._parameters, k, p) for k, p in mod._parameters.items() if p is not None]
+            pl += [(mod._buffers, k, b) for k, b in mod._buffers.items() if b is not None and k not in mod._non_persistent_buffers_set]
+        self._plist = pl
+        self._psig = tuple((p.data_ptr(), p._version) for _, _, p in pl)
 
 
 class PretrainVisionTransformer(WeightSync, nn.Module):
@@ -216,11 +232,12 @@ class PretrainVisionTransformer(WeightSync, nn.Module):
     def sync_weights(self, device: Optional[torch.device] = None, force: bool = False) -> int:
         """Push every parameter that changed since the last call into the library (packs to bf16
         hi/lo planes).  Counterpart of `load_state_dict` at the boundary (prediction.py:81-107).
-        A change is detected by (storage pointer, version counter): `load_state_dict`, `copy_`, optimizer steps bump the
-        counter, but in-place edits through `.data` (EMA swaps, weight surgery) do NOT -- call `sync_weights(force=True)`
-        (or `invalidate_weights()`) after such an edit, otherwise the library keeps running the old packed weights."""
+        A change is detected by object identity + (storage pointer, version counter) of every parameter (`WeightSync`):
+        `load_state_dict`, `copy_`, optimiser steps, `p.data = t`, `.to()` / `.double()` on the model or a submodule, a replaced
+        Parameter.  In-place edits through `.data` that keep the storage (`p.data.mul_(2)`) are NOT visible -- call
+        `sync_weights(force=True)` (or `invalidate_weights()`) after such an edit."""
         if device is None:
-            device = self._plist[0].device if self._plist else next(self.parameters()).device
+            device = self._param_device()
         if not force and self._handle is not None and self._handle_device == device and self._params_unchanged():
             return 0
         h = self._ensure_handle(device)

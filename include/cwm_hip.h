@@ -146,11 +146,20 @@ int cwm_conj_timing_collect(cwm_conj_model* m, int kclass, struct cwm_kernel_sta
 #define CWM_KCLASS_ATTENTION 1
 #define CWM_KCLASS_GEMM_WIDE 2   /* the GEMM launches that ran the 256x256 8-phase kernel (K >= 512, wide N: encoder qkv, fc1, fc2) */
 #define CWM_KCLASS_GEMM_NARROW 3 /* ... the 128x128 kernels (proj, K < 512, head, patch embed); both enabled / collected with class 0 */
-#define CWM_KCLASS_COUNT 4
+/* HBM-bound edge kernels (SURVEY.md 8d "reported separately as achieved GB/s"): for these classes `total_flops` holds the
+ * algorithmic BYTES of the launches (each input element read once, each output element written once), not FLOPs */
+#define CWM_KCLASS_LAYERNORM 4    /* rows * D * (4 read + 2 * planes written) */
+#define CWM_KCLASS_PATCH_GATHER 5 /* visible tokens * C*P*P * (4 read + 2 * planes written) */
+#define CWM_KCLASS_FILL_MASK 6    /* B * Nm * Dd * 4 written (the positional rows come from L2) */
+#define CWM_KCLASS_UNEMBED 7      /* B * T*C*H*W * (4 read + 4 written) */
+/* IMU-conditioned model only (cwm_conj_timing_*): FLOPs again */
+#define CWM_KCLASS_CROSS_ATTN 8   /* BidirectionalCrossAttention, both directions: 2 * (4 * N * M * hd) per head */
+#define CWM_KCLASS_SMALL_ATTN 9   /* the context stream's self-attention (25..50 tokens) */
+#define CWM_KCLASS_COUNT 10
 typedef struct cwm_kernel_stats {
     int64_t launches;
     double total_ms;    /* sum of launch durations (HIP events on the launch stream) */
-    double total_flops; /* algorithmic FLOPs (2*M*N*K; attention 4*N*N*hd per head) of those launches */
+    double total_flops; /* algorithmic FLOPs (2*M*N*K; attention 4*N*N*hd per head) of those launches; BYTES for classes 4-7 */
 } cwm_kernel_stats;
 int cwm_timing_enable(cwm_model* m, int kclass, int enable);
 /* Synchronises the recorded events, accumulates, and resets the event pool. */
@@ -179,8 +188,9 @@ int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const uint8_t* ma
 /* Motion-counterfactual prompt construction for B*S prompts at once.
  * replaces: the per-sample loop of FlowGenerator.create_motion_counterfactuals (segmentation.py:324-338)
  *           = PatchPerturbation.forward + ShiftPatchesAndMask.perturb (perturbation.py:99-113, 245-289)
- *           on make_static_movie(x) when fix_passive=1 (prediction.py:731-739), BEFORE the final
- *           mask_rectangularizer call (host).  x [B,T,C,H,W]; active/masks [B*S,Nt] bool ('(b s)' order,
+ *           on make_static_movie(x) when fix_passive=1 (prediction.py:731-739), or on MakeStatic(x, masks)
+ *           when fix_passive=2 (perturbation.py:120-145 as called at prediction.py:802-803: the patches `masks`
+ *           leaves visible take their frame-0 pixels), BEFORE the final mask_rectangularizer call (host).  x [B,T,C,H,W]; active/masks [B*S,Nt] bool ('(b s)' order,
  *           0 = active patch / 0 = passive visible patch); shifts [B*S,2] (dy,dx) in patch units;
  *           outputs x_out [B*S,T,C,H,W], mask_out [B*S,Nt].  Asynchronous on `stream`. */
 int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int P, int frame, int S, int fix_passive,

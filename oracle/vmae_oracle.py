@@ -383,6 +383,14 @@ def shift_patches_and_mask(x_1tchw, mask_1n, active_1n, shift_patches, P: int, f
     return x_out, mask_out
 
 
+def make_static(x_btchw: torch.Tensor, mask_bn: torch.Tensor, P: int) -> torch.Tensor:
+    """`MakeStatic.perturb` (perturbation.py:120-145, called at prediction.py:802-803): the patches `mask` leaves visible (0) in every
+    frame take the pixels of the same patch in frame 0; masked patches keep theirs.  Pure copies."""
+    B, T, C, H, W = x_btchw.shape
+    vis = (~mask_bn.bool()).view(B, T, H // P, W // P).repeat_interleave(P, -2).repeat_interleave(P, -1).unsqueeze(2)  # [B,T,1,H,W]
+    return torch.where(vis, x_btchw[:, 0:1].expand(-1, T, -1, -1, -1), x_btchw)
+
+
 def create_motion_counterfactuals(x_btchw, masks_bns, active_bns, shifts, P: int, frame: int = 1, fix_passive: bool = True):
     """`FlowGenerator.create_motion_counterfactuals` (segmentation.py:278-344) before the final
     `mask_rectangularizer` call: returns (x_shift [B*S,...], mask_shift [B*S,Nt]) in '(b s)' order."""

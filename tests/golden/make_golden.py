@@ -387,6 +387,19 @@ def run_wrapper_cases(ns):
     out["cf_img"], out["cf_passive"], out["cf_active"] = img.numpy(), passive.numpy(), active.numpy()
     out["cf_x_p"], out["cf_mask_p"], out["cf_y"] = x_p.numpy(), mask_p.numpy(), y_p.numpy()
     out["cf_shifts"] = np.array(G.shifts)
+    # fix_passive=True on a movie whose frames differ: MakeStatic on the passive patches before the shift (prediction.py:802-803,
+    # perturbation.py:120-145); two passive patches, one of them the shift's destination's neighbour
+    movie = x[:1].clone()
+    passive2 = passive.clone()
+    passive2[0, n + 10] = False
+    with torch.no_grad():
+        ms_x, ms_mask = G.make_static(movie, passive2.clone())
+        G.shifts = None
+        x_p2, mask_p2 = G._shift(ms_x, passive2.clone(), active_patches=active.clone(), shift=(1, -1), frame=1)
+        G.shifts = None
+        y_p2 = G.get_counterfactual_prediction(movie, mask=passive2.clone(), active_patches=active.clone(), shift=(1, -1), fix_passive=True)
+    out["ms_movie"], out["ms_passive"], out["ms_x"], out["ms_mask"] = movie.numpy(), passive2.numpy(), ms_x.numpy(), ms_mask.numpy()
+    out["ms_x_p"], out["ms_mask_p"], out["ms_y"] = x_p2.numpy(), mask_p2.numpy(), y_p2.numpy()
     # the batch driver with a flow model (segmentation.py:346-432): ordering, shifts list, flow shape
     S_n = 5
     act = torch.ones(1, 2 * n, S_n, dtype=torch.bool)

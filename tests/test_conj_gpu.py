@@ -110,3 +110,43 @@ def test_imu400_two_lanes_match_one_lane():
     assert y1.shape == y2.shape and err <= 5e-5
     assert torch.equal(y1.abs().sum(-1) == 0, y2.abs().sum(-1) == 0)
     assert torch.equal(m(x, mask, x_context=imu, mask_context=mc), y2)
+
+
+@pytest.mark.parametrize("which", ["tiny", "imu400"])
+def test_mfma_and_valu_conj_attention_agree(which):
+    """The cross attention / context self-attention on MFMAs (csrc/conj_attention.hip: flash dataflow, split-bf16 products, the
+    projections in the GEMM operand layout) against the exact-fp32 VALU kernels they replace (csrc/conj_kernels.hip, debug switch
+    "conj_attn" = 0): same forward output within the split-bf16 rounding, for ragged visible counts, masked context tokens
+    (fewer than 25 context keys), head_dim 32 (tiny) and 192 / 96 with 25 / 50 context tokens (imu400), in both modes."""
+    from counterfactualworldmodels_amd import _lib
+
+    lib = _lib.get_lib()
+    if which == "tiny":
+        g = np.load(os.path.join(GOLDEN, "conj_tiny.npz"))
+        m = build(TINY_CONJ, int(g["seed"]))
+        x = V.preprocess(torch.from_numpy(g["x"])).cuda()
+        mask, imu, mc = (torch.from_numpy(g[k]).cuda() for k in ("mask", "imu", "mask_context"))
+    else:
+        g = np.load(os.path.join(GOLDEN, "conj_imu400_b2.npz"))
+        cfg = C.CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"]
+        m = build(cfg, int(g["seed"]))
+        x = V.preprocess(torch.from_numpy(S.synthetic_frames(3, cfg.main, 1))).cuda()
+        mask2 = torch.from_numpy(g["mask"])
+        mask = torch.stack([mask2[i % 2] for i in range(3)]).cuda()
+        imu = torch.stack([torch.from_numpy(g["imu"])[i % 2] * (1.0 + 0.3 * i) for i in range(3)]).cuda()
+        mc = torch.zeros(3, 25, dtype=torch.bool, device="cuda")
+        mc[1, 3] = True
+        mc[2, 7:12] = True
+    try:
+        for mode, tol in (("parity", 1e-4), ("fast", 1e-1)):
+            m.mode = mode
+            _lib.check(lib.cwm_debug_set(b"conj_attn", 1))
+            y1 = m(x, mask, x_context=imu, mask_context=mc)
+            _lib.check(lib.cwm_debug_set(b"conj_attn", 0))
+            y0 = m(x, mask, x_context=imu, mask_context=mc)
+            err = (y1 - y0).abs().max().item()
+            print(f"[{which} {mode}] MFMA vs VALU conj attention: {err:.2e}")
+            assert torch.isfinite(y1).all() and err <= tol, (mode, err)
+            assert torch.equal(y1.abs().sum(-1) == 0, y0.abs().sum(-1) == 0)
+    finally:
+        _lib.check(lib.cwm_debug_set(b"conj_attn", 1))

@@ -126,3 +126,36 @@ def test_oracle_spec_matches_config():
         s = O.SPECS[name]
         for f in ("patch", "enc_dim", "enc_depth", "enc_heads", "dec_dim", "dec_depth", "dec_heads", "mlp_ratio"):
             assert getattr(s, f) == getattr(cfg, f)
+
+
+def test_weight_sync_signature_sees_every_way_a_parameter_can_change():
+    """vmae.WeightSync (no GPU needed: only the host-side change detector).  Cases from the round-2 review: `p.data = t` (new storage,
+    same version counter), a dtype conversion of a SUBMODULE (never reaches the top-level `_apply`), a Parameter replaced with setattr."""
+    import torch
+    from counterfactualworldmodels_amd import config as C, vmae
+
+    cfg = C.VmaeConfig(name="tiny_8x8", img_size=(32, 32), patch=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=1, dec_heads=2)
+    m = vmae.PretrainVisionTransformer(cfg)
+    assert not m._params_unchanged()           # nothing uploaded yet
+    m._remember_params()
+    assert m._params_unchanged()
+    assert len(m._plist) == len(m.state_dict())
+    w = m.decoder.head.weight
+    v0 = w._version
+    w.data = w.data.clone()                    # storage pointer changes, version counter does not
+    assert w._version == v0 and not m._params_unchanged()
+    m._remember_params()
+    m.encoder.double()                         # submodule conversion
+    assert not m._params_unchanged()
+    m.encoder.float()
+    m._remember_params()
+    assert m._params_unchanged()
+    m.decoder.head.bias = torch.nn.Parameter(torch.zeros_like(m.decoder.head.bias))   # replaced object
+    assert not m._params_unchanged()
+    m._remember_params()
+    with torch.no_grad():
+        m.mask_token.add_(1.0)                 # in-place: version counter
+    assert not m._params_unchanged()
+    m._remember_params()
+    m.load_state_dict(m.state_dict())          # post hook forgets the list
+    assert not m._params_unchanged()

@@ -195,6 +195,14 @@ def test_weight_edits_are_detected_without_walking_the_state_dict():
     assert (m(xp, mask) - y0).abs().max().item() <= 1e-6
     m2 = m.cpu().cuda()                                    # `.to()` replaces the parameter tensors: the list is rebuilt
     assert (m2(xp, mask) - y0).abs().max().item() <= 1e-6
+    # round-2 review: new storage behind the same version counter, a submodule-only conversion, a replaced Parameter
+    m2.decoder.head.bias.data = m2.decoder.head.bias.data + 0.25
+    assert ((m2(xp, mask) - y0) - 0.25).abs().max().item() <= 1e-5
+    m2.decoder.double()
+    assert ((m2(xp, mask) - y0) - 0.25).abs().max().item() <= 1e-5 and m2.sync_weights() == 0
+    m2.decoder.float()
+    m2.decoder.head.bias = torch.nn.Parameter(m2.decoder.head.bias.detach() - 0.25)
+    assert (m2(xp, mask) - y0).abs().max().item() <= 1e-5
 
 
 def test_qkv_epilogue_variants_agree_end_to_end():

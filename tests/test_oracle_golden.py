@@ -199,3 +199,16 @@ def test_nothing_masked_returns_all_tokens():
         y = O.vmae_forward(W, TINY_SPEC, O.preprocess(x), mask)
     assert y.shape == g["y_tokens"].shape == (2, 32, 192)
     assert np.abs(y.numpy() - g["y_tokens"]).max() <= 2e-5
+
+
+def test_make_static_and_shift_against_reference_fixture():
+    """f-1: `MakeStatic` on the passive patches followed by the shift (get_counterfactual_prediction(fix_passive=True),
+    prediction.py:802-812) -- oracle restatement vs the reference's own outputs, bit-exact."""
+    g = load("wrapper_surface.npz")
+    movie, passive = torch.from_numpy(g["ms_movie"]), torch.from_numpy(g["ms_passive"])
+    xs = O.make_static(movie, passive, 8)
+    assert np.array_equal(xs.numpy(), g["ms_x"]) and np.array_equal(passive.numpy(), g["ms_mask"])
+    assert not np.array_equal(g["ms_x"], g["ms_movie"])  # the fixture exercises the replacement
+    active = torch.from_numpy(g["cf_active"])
+    x_p, mask_p = O.shift_patches_and_mask(xs, passive, active, (1, -1), 8, frame=1)
+    assert np.array_equal(x_p.numpy(), g["ms_x_p"]) and np.array_equal(mask_p.numpy(), g["ms_mask_p"])

@@ -124,6 +124,39 @@ def test_single_prompt_counterfactual_and_error_maps_vs_reference():
     assert ea.shape == g["err_all"].shape and np.abs(ea.cpu().numpy() - g["err_all"]).max() <= 2e-4
 
 
+def test_make_static_on_passive_patches_vs_reference():
+    """`get_counterfactual_prediction(fix_passive=True)` = `MakeStatic` on the patches the passive mask leaves visible, then the shift
+    (prediction.py:802-812, perturbation.py:120-145), folded into the prompt kernel (fix_passive = 2): frames and masks bit-exact
+    against the reference's outputs on a movie whose two frames differ, the prediction within tolerance."""
+    g = np.load(os.path.join(GOLDEN, "wrapper_surface.npz"))
+    G = wrapper(TINY, 3)
+    movie, passive, active = (torch.from_numpy(g[k]).cuda() for k in ("ms_movie", "ms_passive", "cf_active"))
+    xs, m = G.make_static(movie, passive.clone())
+    assert np.array_equal(xs.cpu().numpy(), g["ms_x"]) and np.array_equal(m.cpu().numpy(), g["ms_mask"])
+    x_p, mask_p = G._shift(movie, passive.clone(), active_patches=active.clone(), shift=(1, -1), frame=1, fix_passive="make_static")
+    assert np.array_equal(x_p.cpu().numpy(), g["ms_x_p"]) and np.array_equal(mask_p.cpu().numpy(), g["ms_mask_p"])
+    G.shifts = None
+    y = G.get_counterfactual_prediction(movie, mask=passive.clone(), active_patches=active.clone(), shift=(1, -1), fix_passive=True)
+    assert y.shape == g["ms_y"].shape and np.abs(y.cpu().numpy() - g["ms_y"]).max() <= 2e-4
+    # and the oracle's restatement on a random table at the B/8 grid: the two-step form equals the fused kernel
+    cfg = C.CONFIGS["base_8x8patch_2frames_1tube"]
+    Gb = wrapper(cfg, 0)
+    xb = torch.from_numpy(S.synthetic_frames(2, cfg, 9)).cuda()
+    gen = torch.Generator().manual_seed(3)
+    pas = torch.rand(2, cfg.num_tokens, generator=gen) < 0.9
+    pas[:, : cfg.tokens_per_frame] = False
+    act = torch.ones(2, cfg.num_tokens, dtype=torch.bool)
+    act[0, cfg.tokens_per_frame + 100] = False
+    act[1, cfg.tokens_per_frame + 333] = False
+    xs_ref = O.make_static(xb.cpu(), pas, cfg.patch)
+    xs_dev, _ = Gb.make_static(xb, pas.cuda())
+    assert torch.equal(xs_dev.cpu(), xs_ref)
+    for b in range(2):
+        xr, mr = O.shift_patches_and_mask(xs_ref[b:b + 1], pas[b:b + 1], act[b:b + 1], (2, -3), cfg.patch, frame=1)
+        xd, md = Gb._shift_rows(xb[b:b + 1], pas[b:b + 1].cuda(), act[b:b + 1].cuda(), torch.tensor([[2, -3]], dtype=torch.int32), 1, "make_static")
+        assert torch.equal(xd.cpu(), xr) and torch.equal(md.cpu(), mr)
+
+
 def test_counterfactual_videos_and_flows_vs_reference():
     """`predict_counterfactual_videos_and_flows` with a plugged flow model (segmentation.py:346-432): '(b s)' ordering, the shifts
     list, flows [B*S,1,2,H,W], values equal to the reference's own run of the same call; independent of sample_batch_size."""
