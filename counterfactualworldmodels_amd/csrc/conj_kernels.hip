@@ -1,8 +1,9 @@
 // Kernels specific to the IMU-conditioned conjoined padded predictor (BASELINE configs[4]):
 // null-token padding bookkeeping, IMU tubelet gather, short-sequence self-attention for the context
 // stream (head_dim 32, <= 64 tokens) and the bidirectional cross attention between the N-token RGB
-// stream and the M <= 64-token IMU stream.  The cross/small attentions are exact-fp32 VALU kernels:
-// together they are < 5 % of this model's time (the RGB stream's 6336-token self-attention dominates).
+// stream and the M <= 64-token IMU stream.  The cross/small attentions here are the exact-fp32 VALU forms: the model runs the MFMA
+// kernels of conj_attention.hip where the shapes allow (every shape of the imu400 model) and keeps these for other head widths and as
+// the reference of the A/B test (debug switch "conj_attn" = 0).
 #include "common.h"
 #include "kernels.h"
 
@@ -376,12 +377,10 @@ int launch_cross_attention(const CrossAttnParams& p, int planes, hipStream_t str
     const size_t smem = ((size_t)3 * p.M * p.head_dim + (size_t)64 * (p.M + 1)) * sizeof(float);
     const dim3 g1((p.N + 63) / 64, p.B * p.heads), g2(kCrossSplit, p.B * p.heads), g3(p.M, p.B * p.heads);
     if (planes == 1) {
-        static bool a1 = false;
-        if (!a1) { CWM_HIP_CHECK(hipFuncSetAttribute((const void*)cross_attn_main_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a1 = true; }
+        if (int rc = cwm_set_max_lds((const void*)cross_attn_main_kernel<1>, 160 * 1024)) return rc;  // per (device, kernel): engine.hip
         hipLaunchKernelGGL(cross_attn_main_kernel<1>, g1, dim3(256), smem, stream, p);
     } else {
-        static bool a2 = false;
-        if (!a2) { CWM_HIP_CHECK(hipFuncSetAttribute((const void*)cross_attn_main_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a2 = true; }
+        if (int rc = cwm_set_max_lds((const void*)cross_attn_main_kernel<2>, 160 * 1024)) return rc;
         hipLaunchKernelGGL(cross_attn_main_kernel<2>, g1, dim3(256), smem, stream, p);
     }
     if (p.M <= 32) hipLaunchKernelGGL(cross_attn_src_partial_kernel<32>, g2, dim3(256), 0, stream, p);

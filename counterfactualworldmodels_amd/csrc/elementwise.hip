@@ -260,9 +260,9 @@ __global__ __launch_bounds__(256) void fill_mask_tokens_kernel(float* x_full, co
     }
 }
 
-// The same rows without the LayerNorm-fold outputs (the default path): FOUR rows per thread, all loads (perm -> positional row) issued
+// The same rows without the LayerNorm-fold outputs (the default path): EIGHT rows per thread, all loads (perm -> positional row) issued
 // before the first store.  One row per thread ran as ~4.6 rounds of short-lived waves, each a dependent perm -> pos -> store
-// chain: 2.9 TB/s of stores (13.1 us for 38 MB, ViT-B/8 batch 32); with four independent chains per thread the launch is one round.
+// chain: 2.9 TB/s of stores (13.1 us for 38 MB, ViT-B/8 batch 32); with independent chains per thread the launch is one round.
 __global__ __launch_bounds__(256) void fill_mask_tokens4_kernel(float* x_full, const float* mask_token, const float* pos, const int* perm, int Nt,
                                                                  int n_vis, int D, int64_t rows, int64_t rows_q) {
     const int d4 = D / 4;
@@ -272,11 +272,12 @@ __global__ __launch_bounds__(256) void fill_mask_tokens4_kernel(float* x_full, c
     const int c4 = (int)(gid - r0 * d4);
     const int nm = Nt - n_vis;
     const float4 mt = *reinterpret_cast<const float4*>(mask_token + c4 * 4);
-    size_t orow[4];
-    int tau[4];
-    bool live[4];
+    constexpr int R = 8;  // rows per thread: the whole launch is resident at once (no second, nearly empty round of waves)
+    size_t orow[R];
+    int tau[R];
+    bool live[R];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < R; ++i) {
         const int64_t row = r0 + i * rows_q;
         live[i] = row < rows;
         const int64_t rr = live[i] ? row : 0;
@@ -284,11 +285,11 @@ __global__ __launch_bounds__(256) void fill_mask_tokens4_kernel(float* x_full, c
         orow[i] = (size_t)b * Nt + n_vis + j;
         tau[i] = perm[orow[i]];
     }
-    float4 pe[4];
+    float4 pe[R];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pe[i] = *reinterpret_cast<const float4*>(pos + (size_t)tau[i] * D + c4 * 4);
+    for (int i = 0; i < R; ++i) pe[i] = *reinterpret_cast<const float4*>(pos + (size_t)tau[i] * D + c4 * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < R; ++i)
         if (live[i]) *reinterpret_cast<float4*>(x_full + orow[i] * D + c4 * 4) = make_float4(mt.x + pe[i].x, mt.y + pe[i].y, mt.z + pe[i].z, mt.w + pe[i].w);
 }
 
@@ -299,7 +300,7 @@ int launch_fill_mask_tokens(float* x_full, const float* mask_token, const float*
     const int64_t total4 = (int64_t)B * (Nt - n_vis) * (D / 4);
     if (total4 == 0) return 0;
     if (!split) {
-        const int64_t rows = (int64_t)B * (Nt - n_vis), rows_q = (rows + 3) / 4;
+        const int64_t rows = (int64_t)B * (Nt - n_vis), rows_q = (rows + 7) / 8;
         hipLaunchKernelGGL(fill_mask_tokens4_kernel, dim3((unsigned)((rows_q * (D / 4) + 255) / 256)), dim3(256), 0, stream, x_full, mask_token, pos,
                            perm, Nt, n_vis, D, rows, rows_q);
         CWM_HIP_CHECK(hipGetLastError());
@@ -352,42 +353,49 @@ __global__ __launch_bounds__(256) void unembed_kernel(const UnembedParams p) {
 // in registers, three 16-byte stores (one per channel plane).  The one-channel form above reads the same 48 bytes from three threads
 // of three different waves with 4-byte loads at a 12-byte stride: 3.0 TB/s (25.7 us for 77 MB at ViT-B/8 batch 32).
 __global__ __launch_bounds__(256) void unembed3_kernel(const UnembedParams p) {
-    const int w4 = p.W / 4;
-    const int64_t total = (int64_t)p.B * p.T * p.H * w4;
+    const int w4 = p.W / 4, hh = p.H / 2;  // two image rows (y, y + H/2) per thread: six independent 16-byte loads in flight
+    const int64_t total = (int64_t)p.B * p.T * hh * w4;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     int64_t r = gid;
     const int x4 = (int)(r % w4); r /= w4;
-    const int y = (int)(r % p.H); r /= p.H;
+    const int y0 = (int)(r % hh); r /= hh;
     const int t = (int)(r % p.T);
     const int b = (int)(r / p.T);
     const int x0 = x4 * 4;
     const int gw = p.W / p.P;
     const int n = (p.H / p.P) * gw;
     const int Nt = p.T * n;
-    const int tau = t * n + (y / p.P) * gw + (x0 / p.P);
-    float4 o[3];
-    if (p.mask[(size_t)b * Nt + tau]) {
-        const int j = p.rank[(size_t)b * Nt + tau] - p.n_vis;
-        const float4* yp = reinterpret_cast<const float4*>(p.y + ((size_t)b * p.Nm + j) * (p.P * p.P * 3) + ((y % p.P) * p.P + (x0 % p.P)) * 3);
-        const float4 a = yp[0], bb = yp[1], c = yp[2];  // px0 (r g b) px1 (r | g b) px2 (r g | b) px3 (r g b)
-        o[0] = make_float4(a.x, a.w, bb.z, c.y);
-        o[1] = make_float4(a.y, bb.x, bb.w, c.z);
-        o[2] = make_float4(a.z, bb.y, c.x, c.w);
-    } else {
-        const float* src = p.x + b * p.sb + t * p.st + (int64_t)y * p.W + x0;
+    float4 o[2][3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = *reinterpret_cast<const float4*>(src + c * p.sc);
+    for (int k = 0; k < 2; ++k) {
+        const int y = y0 + k * hh;
+        const int tau = t * n + (y / p.P) * gw + (x0 / p.P);
+        if (p.mask[(size_t)b * Nt + tau]) {
+            const int j = p.rank[(size_t)b * Nt + tau] - p.n_vis;
+            const float4* yp = reinterpret_cast<const float4*>(p.y + ((size_t)b * p.Nm + j) * (p.P * p.P * 3) + ((y % p.P) * p.P + (x0 % p.P)) * 3);
+            const float4 a = yp[0], bb = yp[1], c = yp[2];  // px0 (r g b) px1 (r | g b) px2 (r g | b) px3 (r g b)
+            o[k][0] = make_float4(a.x, a.w, bb.z, c.y);
+            o[k][1] = make_float4(a.y, bb.x, bb.w, c.z);
+            o[k][2] = make_float4(a.z, bb.y, c.x, c.w);
+        } else {
+            const float* src = p.x + b * p.sb + t * p.st + (int64_t)y * p.W + x0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[k][c] = *reinterpret_cast<const float4*>(src + c * p.sc);
+        }
     }
-    float* dst = p.out + (((size_t)b * p.T + t) * 3 * p.H + y) * p.W + x0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(dst + (size_t)c * p.H * p.W) = o[c];
+    for (int k = 0; k < 2; ++k) {
+        float* dst = p.out + (((size_t)b * p.T + t) * 3 * p.H + y0 + k * hh) * p.W + x0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(dst + (size_t)c * p.H * p.W) = o[k][c];
+    }
 }
 
 int launch_unembed(const UnembedParams& p, hipStream_t stream) {
     CWM_REQUIRE(p.P % 4 == 0 && p.W % 4 == 0, "unembed: patch size and width must be multiples of 4");
-    if (p.C == 3 && (((uintptr_t)p.y | (uintptr_t)p.out | (uintptr_t)p.x) & 15) == 0 && (p.sc % 4 == 0) && (p.sb % 4 == 0) && (p.st % 4 == 0)) {
-        const int64_t total3 = (int64_t)p.B * p.T * p.H * (p.W / 4);
+    if (p.C == 3 && p.H % 2 == 0 && (((uintptr_t)p.y | (uintptr_t)p.out | (uintptr_t)p.x) & 15) == 0 && (p.sc % 4 == 0) && (p.sb % 4 == 0) && (p.st % 4 == 0)) {
+        const int64_t total3 = (int64_t)p.B * p.T * (p.H / 2) * (p.W / 4);
         hipLaunchKernelGGL(unembed3_kernel, dim3((unsigned)((total3 + 255) / 256)), dim3(256), 0, stream, p);
         CWM_HIP_CHECK(hipGetLastError());
         return 0;

@@ -110,6 +110,8 @@ LaneWs lane_ws(const cwm_model* m, int lane, int b0) {
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+static int g_ln_fuse = 0;  // "ln_fuse" switch: LayerNorm folded into the GEMMs around it; read at model creation AND per forward
+
 extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
     CWM_REQUIRE(cfg && out, "cwm_model_create: null argument");
     const cwm_config& c = *cfg;
@@ -124,7 +126,9 @@ extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
     m->cfg = c;
     Engine& E = m->eng;
     E.ln_eps = c.ln_eps;
-    E.enable_folds = (c.enc_dim % 64 == 0 && c.dec_dim % 64 == 0);
+    // The LayerNorm fold (measured slower, off by default) keeps an fp32 copy + two folded packings of every consuming linear (~2.5x the
+    // packed-weight memory): only models created while the "ln_fuse" switch is on carry that state
+    E.enable_folds = g_ln_fuse && (c.enc_dim % 64 == 0 && c.dec_dim % 64 == 0);
     CWM_HIP_CHECK(hipGetDevice(&E.device));
     m->n_per_frame = (c.img_h / c.patch) * (c.img_w / c.patch);
     m->Nt = m->n_per_frame * c.num_frames;
@@ -146,7 +150,7 @@ extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
         E.add_vec_slot("encoder.norm.bias", m->enc_norm_b, {c.enc_dim});
         if ((rc = E.make_linear(m->e2d, c.dec_dim, c.enc_dim, false))) break;
         E.add_matrix_slot("encoder_to_decoder.weight", &m->e2d, {c.dec_dim, c.enc_dim});
-        if (c.enc_dim % 64 == 0 && c.dec_dim % 64 == 0 && (rc = E.set_fold(m->e2d, m->enc_norm_g, m->enc_norm_b))) break;  // encoder.norm folds in
+        if (E.enable_folds && (rc = E.set_fold(m->e2d, m->enc_norm_g, m->enc_norm_b))) break;  // encoder.norm folds in
         if ((rc = E.make_vec(&m->mask_token, c.dec_dim))) break;
         E.add_vec_slot("mask_token", m->mask_token, {1, 1, c.dec_dim});
         for (int i = 0; i < c.dec_depth && !rc; ++i)
@@ -183,7 +187,7 @@ static int g_prune_last_block = 1;
 // LayerNorm folded into the GEMMs around it (engine.h).  Implemented, parity-tested and selectable (cwm_debug_set "ln_fuse" = 1), but NOT
 // the default: measured on MI355X the extra 4 bytes/element a producer GEMM must store (its rows in operand layout) inside its
 // store-bound epilogue cost as much as the LayerNorm launch they replace (B/8 batch 32: +75 us per block vs 64 us).
-static int g_ln_fuse = 0;
+// (g_ln_fuse is defined above cwm_model_create, which reads it)
 
 // One lane: batch elements [b0, b0 + B) of the call, on stream s, in the workspace slice w.
 // Stages [stage_lo, stage_hi) of the lane's launch sequence: 0 = mask -> permutation, patch gather + embed; 1 .. Le = encoder blocks;
@@ -312,6 +316,8 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
         const int nmiss = m->eng.missing_weights(miss, sizeof(miss));
         CWM_REQUIRE(nmiss == 0, "cwm_forward: %d state-dict tensors not loaded (first: %s)", nmiss, miss);
     }
+    CWM_REQUIRE(!g_ln_fuse || m->e2d.raw, "cwm_forward: \"ln_fuse\" is on, but this model was created while it was off and carries no fold state "
+                                          "(set the switch before cwm_model_create)");
     if (int rc = ensure_workspace(m, B, Nv)) return rc;
     hipStream_t s = (hipStream_t)a->stream;
     if (int rc = m->eng.finalize_folds(s)) return rc;  // (before the lanes fork: they wait on an event recorded after it)

@@ -386,7 +386,9 @@ def prompt_hooks(G, frame: Optional[int] = -1):
         return masks, G.mask_rectangularizer.last_num_masked
 
     def predict(xs, ms, n_masked, chunk):
-        return G._select_frame(G._run_rect_batch(_RectBatch(xs, ms, n_masked), rows_per_call=chunk), frame)
+        y = G._run_rect_batch(_RectBatch(xs, ms, n_masked), rows_per_call=chunk)
+        G.reset_padding_masks()
+        return G._select_frame(y, frame)
 
     return build, rect, predict
 

@@ -279,7 +279,8 @@ class PredictorBasedGenerator(nn.Module):
             # NB the reference un-embeds with unnormalize(normalize(x)) for the conjoined model (prediction.py:436-446); the raw
             # input used here differs from that by at most one fp32 ulp at the visible pixels
             pieces.append(y if y.dim() == 5 else self.pred_patches_to_video(y, xs, mask=ms))
-            self.reset_padding_masks()
+            if r1 < R:  # between pieces only: the state after the LAST piece is the caller's (`predict(reset_masks=False)` keeps it,
+                self.reset_padding_masks()  # like the reference, prediction.py:451-452)
         return out if fused else (pieces[0] if len(pieces) == 1 else torch.cat(pieces, 0))
 
     def _as_rect(self, x, mask, row_kwargs=None) -> _RectBatch:

@@ -245,9 +245,11 @@ def test_layernorm_fold_matches_standalone_layernorm(name, cfg_name):
     lib = _lib.get_lib()
     try:
         for mode in ("parity", "fast"):
+            _lib.check(lib.cwm_debug_set(b"ln_fuse", 1))   # the fold state is allocated at model creation, only while the switch is on
             m = build(cfg, seed, mode=mode)
             G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
             xp = G._preprocess(x.cuda())
+            y_first = m(xp, mask.cuda()).cpu()              # (creates the library handle with the switch on)
             _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
             y0 = m(xp, mask.cuda()).cpu()
             _lib.check(lib.cwm_debug_set(b"ln_fuse", 1))
@@ -307,8 +309,10 @@ def test_last_decoder_block_pruning_is_exact():
             g = np.load(os.path.join(GOLDEN, name))
             seed, x, mask = case_inputs(g, cfg)
             for mode in ("parity", "fast"):
+                _lib.check(lib.cwm_debug_set(b"ln_fuse", 1))   # fold state exists only in models created with the switch on
                 m = build(cfg, seed, mode)
                 G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+                m(G._preprocess(x.cuda()), mask.cuda())
                 for fuse in (0, 1):
                     _lib.check(lib.cwm_debug_set(b"ln_fuse", fuse))
                     outs = []

@@ -249,7 +249,9 @@ def test_256_prompts_sharded_driver_equals_one_unchunked_call():
 
 def test_rectangulariser_on_device_masks_is_bit_exact_and_in_place():
     """`RectangularizeMasks` on device masks (pinned host staging, numpy row edits, one copy back): same result as on the CPU tensor with the
-    same torch seed (the reference's randperm order, masking.py:100-132), input mutated in place, `last_num_masked` reported."""
+    same torch seed (the reference's randperm order, masking.py:100-132), input mutated in place, `last_num_masked` reported.
+    NB this is a SELF-comparison (device-staged path vs the same class on a CPU tensor); the pin against the reference for this row
+    is the CPU test against the reference's own output, tests/test_host_logic.py (index_ops.npz `rect_out`)."""
     from counterfactualworldmodels_amd.masking import RectangularizeMasks
 
     g = torch.Generator().manual_seed(4)

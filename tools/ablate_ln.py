@@ -16,6 +16,7 @@ def run(tag):
     for _ in range(20): m.predict_video(x, mask, n_vis=792, check=False)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
     print("%-28s %.2f ms/step  %.0f frames/s" % (tag, 1e3 * dt, 32 / dt), flush=True)
+_lib.check(lib.cwm_debug_set(b"ln_fuse", 1))  # fold state is allocated at model creation, only while the switch is on
 m.predict_video(x, mask, n_vis=792)
 for lanes in (2, 1):
     m.set_lanes(lanes)
