@@ -564,13 +564,20 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
             const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
             if (tiles < cus) {
                 cfg = tiles * 2 >= cus ? 4 : 1;
-            } else if (p.overlapped) {
+            } else if (p.overlapped && !(g_gemm_debug & 128)) {
                 // two batch lanes: the other lane's kernels take the CUs a partly filled last round leaves idle, so the kernel with the
                 // fastest main loop wins regardless of the fill (B/8 batch 32 as 2 x 16: +2 % over the single-lane rule below)
                 cfg = 4;
-            } else {
+            } else if (g_gemm_debug & 256) {  // the round-1 thresholds (A/B)
                 const double fill = (double)tiles / (double)(((tiles + cus - 1) / cus) * cus);
                 if (fill >= (p.K >= 1024 ? 0.75 : 0.85)) cfg = 4;
+                else if (p.K >= 1024 || p.N >= 1024) cfg = 6;
+            } else {
+                // whole rounds on the 8-phase kernel; a last round that is less than 80 % full costs a whole tile period there, and its rows
+                // are cheaper on 128x128 tiles (mixed tiling, ~0.8 of the 8-phase rate): qkv at batch 32 = 891 tiles = 3.48 rounds,
+                // 254 -> 228 us (profiles/r3c_ab_mfma_order.log); the small short-K launches (proj: K, N < 1024) stay on 128x128 tiles
+                const int last = (int)(tiles % cus);
+                if (last == 0 || last * 5 >= cus * 4) cfg = 4;
                 else if (p.K >= 1024 || p.N >= 1024) cfg = 6;
             }
         }

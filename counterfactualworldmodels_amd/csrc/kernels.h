@@ -225,6 +225,7 @@ size_t cross_attention_partial_floats(int B, int heads, int M, int head_dim);
 int launch_cross_attention_mfma(const CrossAttnParams& p, int planes, hipStream_t stream);  // MFMA kernel: qk_op / v_op, partial scratch
 bool cross_attention_mfma_ok(int head_dim, int M);
 size_t cross_attention_mfma_partial_floats(int B, int heads, int M, int head_dim);
+extern int g_conj_ctx_stream;  // 1 (default): the IMU-conditioned model runs its context stream's blocks on a side stream between cross blocks
 extern int g_conj_attn;  // 1 (default): MFMA cross / small attention where the shapes allow; 0: the fp32 VALU kernels ("conj_attn" switch)
 
 int launch_perm_to_rank(const int* perm, int* rank, int B, int Nt, hipStream_t stream);

@@ -643,6 +643,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
         g_attn_remap = value;
         return CWM_OK;
     }
+    if (!strcmp(key, "conj_ctx_stream")) {
+        g_conj_ctx_stream = value;
+        return CWM_OK;
+    }
     if (!strcmp(key, "conj_attn")) {  // 1: MFMA cross / small attention of the IMU-conditioned model (conj_attention.hip); 0: the fp32 VALU kernels
         g_conj_attn = value;
         return CWM_OK;

@@ -1,8 +1,8 @@
 # Final measurement set of a round (GPU box): python tests, benches of every BASELINE config, latency table, microbenchmarks.
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
-python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -1 $OUT/pytest_gpu.log
+python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1; tail -1 $OUT/pytest_gpu.log
 python bench.py --steps 20 --warmup 5 > $OUT/bench_base8.json 2> $OUT/bench_base8.err
 python bench.py --steps 20 --warmup 5 --lanes 1 --no-cpu-baseline --no-prompts > $OUT/bench_base8_lanes1.json 2>/dev/null
 python bench.py --workload large4 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_large4.json 2>/dev/null
@@ -11,12 +11,11 @@ python bench.py --workload prompts256 --steps 8 --warmup 2 > $OUT/bench_prompts2
 python tools/latency.py > $OUT/latency.log 2>&1
 python tools/microbench.py gemm > $OUT/microbench_gemm_b8.log 2>&1
 python tools/mb_attn.py > $OUT/microbench_attn_remap.log 2>&1
-SHAPES=b1 VARIANTS=0:0,0:32,0:4 python tools/mb_variants.py > $OUT/microbench_gemm_b1.log 2>&1
-VARIANTS=0:0,1:0,1:64,4:0 python tools/mb_variants.py > $OUT/microbench_gemm_variants.log 2>&1
-python tools/mb_fold.py > $OUT/microbench_ln_fold.log 2>&1
-python tools/ab_step.py ln_fuse 0 1 2 > $OUT/ab_ln_fuse.log 2>&1
-python tools/ab_step.py attn_remap 1 0 2 > $OUT/ab_attn_remap.log 2>&1
-python tools/power_probe.py > $OUT/power_probe.log 2>&1
+VARIANTS=0:0,1:0,4:0,5:0,6:0 python tools/mb_variants.py > $OUT/microbench_gemm_variants.log 2>&1
+python tools/ab_conj.py conj_attn 0 1 2 > $OUT/ab_conj_attn.log 2>&1
+python tools/ab_conj.py conj_ctx_stream 0 1 2 > $OUT/ab_conj_ctx_stream.log 2>&1
+python tools/ab_step.py gemm_debug 256 0 1 > $OUT/ab_tile_rule_lanes1.log 2>&1
+bash tools/run_bench_2ranks_1gpu.sh > $OUT/bench_2ranks_1gpu.log 2>&1
 for f in base8 base8_lanes1 large4 imu4 prompts256; do python - $OUT/bench_$f.json <<'PY'
 import json,sys
 for line in open(sys.argv[1]):
