@@ -73,7 +73,7 @@ def pmc_traffic(args, kernel):
         with open(path) as f:
             summ = json.load(f)
         if summ.get("workload") != args.workload or summ.get("mode") != args.mode:
-            return None
+            return None, None
         return summ["hbm_bytes_per_launch"].get(kernel), summ.get("tag")
     except (OSError, KeyError, ValueError):
         return None, None
@@ -465,9 +465,17 @@ def main():
             out["prompts256"]["config"] = pm["config"]
             out["rccl_ranks"], out["collectives"] = pm["config"]["comm_world"], pm["config"]["collectives"]
         except Exception as e:  # noqa: BLE001
-            if distributed:  # the multi-rank path IS what N > 1 is run for: a broken broadcast / gather must not exit 0
-                raise
             out["prompts256"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            if distributed:
+                # the multi-rank path IS what N > 1 is run for: a broken broadcast / gather must not exit 0.  The headline measured above is
+                # still printed (with the error in it), then every rank that saw the failure leaves with a non-zero code -- without the
+                # teardown collectives, which ranks that are out of step with each other could not complete
+                import traceback
+
+                traceback.print_exc()
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                os._exit(3)
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, wl["k_vis"], wl["clump"], 0)

@@ -159,3 +159,31 @@ def test_weight_sync_signature_sees_every_way_a_parameter_can_change():
     m._remember_params()
     m.load_state_dict(m.state_dict())          # post hook forgets the list
     assert not m._params_unchanged()
+
+
+def test_bench_helpers_on_cpu():
+    """bench.py's host-side helpers that do not need a GPU: the committed-profile traffic lookup returns a (bytes, tag) pair for every
+    workload / mode (None, None when the profile is for another command), `--gpus N` without N GPUs and a launcher / flag mismatch exit 2."""
+    import subprocess
+    import sys
+    import types
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+
+    for wl, mode in (("base8", "parity"), ("base8", "fast"), ("large4", "parity"), ("imu4", "parity")):
+        got = bench.pmc_traffic(types.SimpleNamespace(workload=wl, mode=mode), "cwm::gemm8p_kernel<2, 0>")
+        assert isinstance(got, tuple) and len(got) == 2
+        if (wl, mode) != ("base8", "parity"):
+            assert got == (None, None)
+    st = {"launches": 4, "total_ms": 0.1, "total_flops": 4 * 155.7e6}
+    e = bench.edge_kernels(lambda kc: st if kc == bench._lib.KCLASS_LAYERNORM else {"launches": 0, "total_ms": 0.0, "total_flops": 0.0})
+    assert set(e) == {"layernorm_kernel"} and abs(e["layernorm_kernel"]["achieved"] - 6228.0) < 1.0 and e["layernorm_kernel"]["unit"] == "GB/s"
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env)
+    assert r.returncode == 2 and "refusing" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="1"))
+    assert r.returncode == 2 and "launcher started 1" in r.stderr

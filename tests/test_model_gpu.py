@@ -76,7 +76,9 @@ def test_base8_golden_parity_and_fast(name):
     yf = G.predict_tokens(x.cuda(), mask.cuda()).cpu().numpy()
     errf = np.abs(yf - g["y_tokens"]).max()
     print(f"[{name}] fast-mode (plain bf16) max-abs vs reference: {errf:.3e}")
-    assert errf <= 1.5e-1 and np.abs(yf - g["y_tokens"]).mean() <= 1.5e-2
+    # plain bf16 does not meet PARITY_TOL; its floor is 2x the measured error (2.5e-2 / 2.6e-2 on these goldens), so that the `secondary` bench
+    # line cannot silently get worse
+    assert errf <= 5e-2 and np.abs(yf - g["y_tokens"]).mean() <= 1.5e-2
 
 
 @pytest.mark.parametrize("name", ["tiny_8x8_sharp.npz", "base8_sharp_b1.npz"])
@@ -96,7 +98,7 @@ def test_sharp_weights_golden_parity(name):
     m.mode = "fast"
     yf = G.predict_tokens(x.cuda(), mask.cuda()).cpu().numpy()
     print(f"[{name}] sharp weights, fast-mode max-abs vs reference: {np.abs(yf - g['y_tokens']).max():.3e}")
-    assert np.isfinite(yf).all()
+    assert np.isfinite(yf).all() and np.abs(yf - g["y_tokens"]).max() <= 2.7e-1   # 2x the measured 1.3e-1
 
 
 def test_large4_golden_parity():
@@ -114,7 +116,7 @@ def test_large4_golden_parity():
     m.mode = "fast"
     yf = G.predict_tokens(x.cuda(), mask.cuda()).cpu().numpy()
     print(f"[large4] fast-mode max-abs vs reference: {np.abs(yf - g['y_tokens']).max():.3e}")
-    assert np.abs(yf - g["y_tokens"]).max() <= 2.5e-1
+    assert np.abs(yf - g["y_tokens"]).max() <= 7e-2   # 2x the measured 3.5e-2
 
 
 def test_bench_batch_properties():

@@ -5,8 +5,8 @@ mkdir -p $OUT
 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1; tail -1 $OUT/pytest_gpu.log
 python bench.py --steps 20 --warmup 5 > $OUT/bench_base8.json 2> $OUT/bench_base8.err
 python bench.py --steps 20 --warmup 5 --lanes 1 --no-cpu-baseline --no-prompts > $OUT/bench_base8_lanes1.json 2>/dev/null
-python bench.py --workload large4 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_large4.json 2>/dev/null
-python bench.py --workload imu4 --steps 8 --warmup 2 > $OUT/bench_imu4.json 2>/dev/null
+python bench.py --workload large4 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_large4.json 2> $OUT/bench_large4.err
+python bench.py --workload imu4 --steps 8 --warmup 2 > $OUT/bench_imu4.json 2> $OUT/bench_imu4.err
 python bench.py --workload prompts256 --steps 8 --warmup 2 > $OUT/bench_prompts256.json 2>/dev/null
 python tools/latency.py > $OUT/latency.log 2>&1
 python tools/microbench.py gemm > $OUT/microbench_gemm_b8.log 2>&1
