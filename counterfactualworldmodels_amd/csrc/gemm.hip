@@ -33,6 +33,36 @@
 
 namespace cwm {
 
+#ifdef CWM_GEMM_PROF
+// per-workgroup {s_memrealtime begin, end, s_memtime cycles total, cycles to the end of the main loop} (tools/gemm_prof.py)
+__device__ unsigned long long g_gemm_blocks[8192 * 4];
+int gemm_prof_dump() {
+    static unsigned long long h[8192 * 4];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_blocks), sizeof(h)) != hipSuccess) return -1;
+    FILE* f = fopen("/tmp/gemm_blocks.bin", "wb");
+    if (!f) return -1;
+    fwrite(h, 1, sizeof(h), f);
+    fclose(f);
+    return 0;
+}
+#define GEMM_PROF_BEGIN() const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_r0 = __builtin_amdgcn_s_memrealtime(); unsigned long long prof_main = 0
+#define GEMM_PROF_MAIN() prof_main = __builtin_amdgcn_s_memtime() - prof_t0
+#define GEMM_PROF_END()                                                              \
+    do {                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                 \
+            g_gemm_blocks[blockIdx.x * 4 + 0] = prof_r0;                             \
+            g_gemm_blocks[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();    \
+            g_gemm_blocks[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime() - prof_t0; \
+            g_gemm_blocks[blockIdx.x * 4 + 3] = prof_main;                           \
+        }                                                                            \
+    } while (0)
+#else
+int gemm_prof_dump() { return -1; }
+#define GEMM_PROF_BEGIN() do {} while (0)
+#define GEMM_PROF_MAIN() do {} while (0)
+#define GEMM_PROF_END() do {} while (0)
+#endif
+
 // Tile configurations (BM x BN output tile, WM x WN waves, each wave FM x FN MFMA fragments of 16x16):
 //   128x128, 2x2 waves (64x64 per wave)  : 64 KiB LDS, two workgroups per CU         -- small / odd shapes
 //   256x128, 4x2 waves (64x64 per wave)  : 96 KiB LDS, one 512-thread workgroup / CU
@@ -41,6 +71,7 @@ namespace cwm {
 // tiles raise the MFMA ceiling: per K tile a workgroup stages (BM+BN)*128 B and runs BM*BN/256*{2|3} MFMAs.
 template <int PLANES, int BM, int BN, int WM, int WN, int STAGES = 2, int FUSE = 0>
 __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN == 8 && STAGES == 2) ? 4 : 2) void gemm_bf16_kernel(const GemmParams p) {
+    GEMM_PROF_BEGIN();
     constexpr int NWAVES = WM * WN;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     // every K tile row is one 128-byte line in LDS and in memory: 64 k of the single plane (fast), or
@@ -194,6 +225,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN ==
             for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
+    GEMM_PROF_MAIN();
     static_assert(STAGES <= 4, "the counted waits above cover at most 3 tiles in flight");
     if constexpr (STAGES > 2) {
         if (nsplit > 1) {
@@ -247,6 +279,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN ==
     } else {
         epilogue_rows<PLANES, FM, FN>(p, acc, m0, n0, wr, wc, lane);
     }
+    GEMM_PROF_END();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -267,35 +300,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN ==
 // Write-after-read: A half-tiles are staged by the group that reads them (waves 0-3 stage and read rows 0-63,
 // waves 4-7 rows 64-127), so one phase after the reads suffices; W half-tiles are read by both groups, and
 // the leading group re-stages them two phases after the read (W0 read in P1 -> staged in P3, W1 P2 -> P4).
-#ifdef CWM_GEMM_PROF
-// per-workgroup {s_memrealtime begin, end, s_memtime cycles total, cycles to the end of the main loop} (tools/gemm_prof.py)
-__device__ unsigned long long g_gemm_blocks[8192 * 4];
-int gemm_prof_dump() {
-    static unsigned long long h[8192 * 4];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_blocks), sizeof(h)) != hipSuccess) return -1;
-    FILE* f = fopen("/tmp/gemm_blocks.bin", "wb");
-    if (!f) return -1;
-    fwrite(h, 1, sizeof(h), f);
-    fclose(f);
-    return 0;
-}
-#define GEMM_PROF_BEGIN() const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_r0 = __builtin_amdgcn_s_memrealtime(); unsigned long long prof_main = 0
-#define GEMM_PROF_MAIN() prof_main = __builtin_amdgcn_s_memtime() - prof_t0
-#define GEMM_PROF_END()                                                              \
-    do {                                                                             \
-        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                 \
-            g_gemm_blocks[blockIdx.x * 4 + 0] = prof_r0;                             \
-            g_gemm_blocks[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();    \
-            g_gemm_blocks[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime() - prof_t0; \
-            g_gemm_blocks[blockIdx.x * 4 + 3] = prof_main;                           \
-        }                                                                            \
-    } while (0)
-#else
-int gemm_prof_dump() { return -1; }
-#define GEMM_PROF_BEGIN() do {} while (0)
-#define GEMM_PROF_MAIN() do {} while (0)
-#define GEMM_PROF_END() do {} while (0)
-#endif
 
 template <int PLANES, int FUSE = 0>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
