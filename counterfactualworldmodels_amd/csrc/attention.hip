@@ -18,7 +18,7 @@
 // issued before the MFMAs of tile t.  LDS images are XOR-swizzled (K: conflict-free ds_read_b128; V: the four
 // key rows of a transposed read land on the four 64-byte quarters of the 256-byte bank row).
 // PLANES==2 is the split-bf16 "parity" mode (hi*hi + hi*lo + lo*hi for both products).
-#include "attention_device.h"
+#include "attention_tail.h"
 
 namespace cwm {
 
@@ -35,6 +35,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     const int N = p.n_tok;
     int qt, bh;
     attn_tile_of_block(p.n_q > 0 ? p.n_q : p.n_tok, 128, p.remap != 0, qt, bh);
+    if (attention_is_split_tail(p, qt, gridDim.x, p.n_q > 0 ? p.n_q : p.n_tok)) {  // ragged last tile of <= 32 rows: the four waves split the keys
+        attention_tail_block<PLANES>(p, smem, bh, qt * 128, p.n_q > 0 ? p.n_q : p.n_tok);
+        return;
+    }
     const int b = bh / p.heads, h = bh - b * p.heads;
     const int q0 = qt * 128 + wave * 32;
     // a wave whose 32 query rows all lie past the sequence end (N = 792: three of the 28 wave slots per head) only helps to
@@ -557,10 +561,12 @@ __global__ __launch_bounds__(512, 2) void attention8_kernel(const AttnParams p) 
 int g_attn_kernel = 0;  // 0 auto, 1: 4-wave kernel, 2: 8-wave staggered kernel, 3: software-pipelined kernel (attention_pipe.hip)
 
 int g_attn_remap = 1;
+int g_attn_tail = 1;
 
 int launch_attention(const AttnParams& p_in, int planes, hipStream_t stream) {
     AttnParams p = p_in;
     p.remap = g_attn_remap;
+    p.tail_split = g_attn_tail;
     CWM_REQUIRE(planes == 1 || planes == 2, "attention: planes must be 1 or 2");
     CWM_REQUIRE(p.n_tok > 0 && p.batch > 0 && p.heads > 0, "attention: empty problem");
     CWM_REQUIRE(p.ldo % 4 == 0, "attention: ldo must be a multiple of 4");

@@ -17,7 +17,7 @@
 // K / V tiles go global -> LDS by LDS-DMA, two slots each: iteration t first issues K(t+2) (slot of K(t), whose S was
 // computed in iteration t - 1) and V(t+1) (slot of V(t-1)), and ends with vmcnt(0) + one workgroup barrier, a whole
 // tile of work later.
-#include "attention_device.h"
+#include "attention_tail.h"
 #include <cstdio>
 
 namespace cwm {
@@ -258,6 +258,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
     const int NQ = p.n_q > 0 ? p.n_q : N;
     int qt, bh;
     attn_tile_of_block(NQ, 32 * NW, p.remap != 0, qt, bh);
+    if constexpr (NW == 4) {
+        if (attention_is_split_tail(p, qt, gridDim.x, NQ)) {  // ragged last tile of <= 32 rows: the four waves split the keys (attention_tail.h)
+            attention_tail_block<PLANES>(p, smem, bh, qt * 128, NQ);
+            return;
+        }
+    }
     const int b = bh / p.heads, h = bh - b * p.heads;
     const int q0 = qt * (32 * NW) + wave * 32;
     const bool active = q0 < NQ;  // idle waves (query rows past the end) only stage tiles and keep the barrier count

@@ -97,12 +97,14 @@ struct AttnParams {
     int n_tok, heads, batch;
     int remap;       // set by launch_attention: XCD-aware workgroup -> (query tile, head) mapping (attention_device.h; "attn_remap" switch)
     int q_off, n_q;  // queries = rows [q_off, q_off + n_q) of every (batch, head); n_q == 0: all n_tok.  O rows are b * n_q + (q - q_off)
+    int tail_split;  // set by launch_attention: a ragged last query tile of at most 32 rows splits the KEYS over its four waves (attention_tail.h; "attn_tail" switch)
 };
 
 int launch_attention(const AttnParams& p, int planes, hipStream_t stream);
 int attention_pipe_prof(int i);  // per-phase s_memtime totals of block 0 wave 0 (builds with -DCWM_ATTN_PROF only)
 int launch_attention_pipe(const AttnParams& p, int planes, hipStream_t stream);  // attention_pipe.hip; arguments checked by launch_attention
 extern int g_attn_remap;   // 1 (default): attn_tile_of_block's XCD-aware mapping; 0: plain (blockIdx.x, blockIdx.y)
+extern int g_attn_tail;    // 1 (default): key-split schedule for a ragged last query tile of <= 32 rows; 0: the regular schedule for every tile
 extern int g_attn_kernel;  // 0 auto, 1: 4-wave kernel, 2: 8-wave staggered kernel
 
 struct LayerNormParams {

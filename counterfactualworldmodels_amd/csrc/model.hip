@@ -639,6 +639,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
         g_ln_fuse = value;
         return CWM_OK;
     }
+    if (!strcmp(key, "attn_tail")) {
+        g_attn_tail = value;
+        return CWM_OK;
+    }
     if (!strcmp(key, "attn_remap")) {
         g_attn_remap = value;
         return CWM_OK;

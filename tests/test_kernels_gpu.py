@@ -332,6 +332,9 @@ def test_attention_variants_are_bitwise_equal_to_4wave_kernel(gu, kern):
     cases = [(2, 40, 1), (1, 64, 2), (2, 100, 1), (3, 129, 2), (1, 192, 2), (2, 300, 3), (2, 792, 12), (1, 1568, 6), (1, 1000, 2), (1, 3200, 1),
              (8, 792, 12), (6, 1568, 6)]
     try:
+        # (the key-split schedule of a ragged last query tile, attention_tail.h, re-associates the key sum and exists in the 4-wave
+        # workgroups only: this cross-check runs every tile on the regular schedule; the split has its own test below)
+        _lib.check(lib.cwm_debug_set(b"attn_tail", 0))
         for mode in ("parity", "fast"):
             for (B, N, H) in cases:
                 qkv = rnd(B, N, 3 * H * 64, seed=N + 1)
@@ -345,3 +348,41 @@ def test_attention_variants_are_bitwise_equal_to_4wave_kernel(gu, kern):
                     assert torch.equal(out, ref), (mode, B, N, H, rep, (out - ref).abs().max().item())
     finally:
         _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))
+        _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
+
+
+def test_attention_key_split_of_the_ragged_last_tile(gu):
+    """attention_tail.h: a last query tile of at most 32 rows (N = 129, 785, 792, 1568 ...) splits the KEYS of its tiles over the
+    workgroup's four waves and merges four (max, sum, O) partials.  Against the regular schedule of the same kernel the rows of that
+    tile may differ by the rounding of P (each wave has its own running maximum) and the order of the fp32 key sum, every other row must be bit-identical; the 4-wave and the pipelined kernel
+    share the split code (bit-identical to each other); odd and even key-tile counts, a masked last key tile, a late spike in the last
+    tile and one in the first, chip-filling grids; and the dense-softmax reference within the usual tolerance."""
+    lib = _lib.get_lib()
+    cases = [(2, 129, 1), (1, 160, 2), (2, 785, 1), (2, 792, 12), (1, 1568, 6), (8, 792, 12), (1, 897, 2), (1, 3104, 1)]
+    try:
+        for mode in ("parity", "fast"):
+            for (B, N, H) in cases:
+                qkv = rnd(B, N, 3 * H * 64, seed=N + 3)
+                qkv[0, N - 2, H * 64:H * 64 + 64] = qkv[0, N - 1, :64] * 6.0   # late spike for the LAST query (a tail row)
+                qkv[0, 3, H * 64:H * 64 + 64] = qkv[0, N - 3, :64] * 6.0       # early spike for another tail row
+                tail0 = (N // 128) * 128 if N % 128 else N
+                outs = {}
+                for kern in (1, 3):
+                    _lib.check(lib.cwm_debug_set(b"attn_kernel", kern))
+                    for tail in (0, 1):
+                        _lib.check(lib.cwm_debug_set(b"attn_tail", tail))
+                        outs[kern, tail] = gu.attention(qkv, H, mode=mode)
+                assert torch.equal(outs[1, 1], outs[3, 1]), (mode, B, N, H)
+                assert torch.equal(gu.attention(qkv, H, mode=mode), outs[3, 1])           # deterministic
+                assert torch.equal(outs[3, 1][:, :tail0], outs[3, 0][:, :tail0]), (mode, B, N, H)   # full tiles untouched
+                d = (outs[3, 1][:, tail0:] - outs[3, 0][:, tail0:]).abs().max().item() if tail0 < N else 0.0
+                # (every wave of the split exponentiates against its OWN running maximum, so the split-bf16 rounding of P -- 2^-17 relative -- falls on
+                # other values than in the regular schedule: differences of that order times |v|, not only a re-associated sum)
+                assert d <= (1e-4 if mode == "parity" else 1e-2), (mode, B, N, H, d)
+                if N % 128 and N % 128 <= 32 and N > 128:
+                    assert d > 0 or mode == "fast" or N == 129   # the split really ran (a re-associated sum seldom reproduces every bit)
+                err = (outs[3, 1] - ref_attention(qkv, H)).abs().max().item()
+                assert err <= (5e-4 if mode == "parity" else 5e-2), (mode, B, N, H, err)
+    finally:
+        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))
+        _lib.check(lib.cwm_debug_set(b"attn_tail", 1))

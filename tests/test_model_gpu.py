@@ -302,11 +302,13 @@ def test_last_decoder_block_pruning_is_exact():
     outputs are bit-identical to running the block in full, for the tiny model and for B/8 (both modes).  (Bitwise with the stand-alone
     LayerNorm kernels and without split-K -- the pruned GEMMs have fewer rows, so the small-launch heuristic may split K differently and
     re-associate the fp32 sums; with the LayerNorm fold the un-pruned run normalises its non-compact final rows with the stand-alone
-    kernel.  In those configurations the two agree to rounding.)"""
+    kernel; and with every attention tile on the regular schedule: pruning changes WHICH query rows form the ragged last tile, whose
+    key-split schedule (attention_tail.h) rounds P at other values.  In those configurations the two agree to rounding.)"""
     lib = _lib.get_lib()
     cases = [(TINY, "tiny_8x8_k4.npz"), (C.CONFIGS["base_8x8patch_2frames_1tube"], "base8_k8_b2.npz")]
     try:
         _lib.check(lib.cwm_debug_set(b"gemm_debug", 32))
+        _lib.check(lib.cwm_debug_set(b"attn_tail", 0))
         for cfg, name in cases:
             g = np.load(os.path.join(GOLDEN, name))
             seed, x, mask = case_inputs(g, cfg)
@@ -328,7 +330,8 @@ def test_last_decoder_block_pruning_is_exact():
                         assert diff <= (1e-4 if mode == "parity" else 3e-2), (name, mode, diff)
         _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
         _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
-        for cfg, name in cases:  # library defaults (split-K where the heuristic takes it): equal to rounding
+        _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
+        for cfg, name in cases:  # library defaults (split-K where the heuristic takes it, key-split attention tails): equal to rounding
             g = np.load(os.path.join(GOLDEN, name))
             seed, x, mask = case_inputs(g, cfg)
             m = build(cfg, seed, "parity")
@@ -342,6 +345,7 @@ def test_last_decoder_block_pruning_is_exact():
         _lib.check(lib.cwm_debug_set(b"prune_last_block", 1))
         _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
         _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
+        _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
 
 
 def test_two_lanes_match_one_lane_and_report_mask_errors_of_both():
