@@ -261,10 +261,14 @@ int cwm_bench_gemm_gapped(int M, int N, int K, int mode, int epi, int iters, int
  * model in the same process sees the same values): "gemm_tile" (0 automatic per shape, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase,
  * 5: persistent stream-K 8-phase, 6: 8-phase rounds + 128x128 remainder rows), "gemm_staged" (0: direct per-fragment epilogue),
  * "gemm_debug" (bit mask of ablations / A-B switches: 1 skip the epilogue's global stores, 2 skip the epilogue, 4 no 4-stage ring for small launches, 8 skip every
- * LayerNorm launch (timing only), 16 small launches on 4 instead of 8 waves, 32 no split-K, 64 the 128x128 kernel as 4-wave workgroups), "attn_kernel" (0 automatic, 1: 4-wave, 2: staggered 8-wave, 3: software-pipelined 4-wave),
- * "attn_remap" (0: plain workgroup order instead of one XCD per (batch, head) with the ragged query tiles last),
+ * LayerNorm launch (timing only), 16 small launches on 4 instead of 8 waves, 32 no split-K, 64 the 128x128 kernel as 4-wave workgroups, 128 the one-lane tile
+ * choice also inside a two-lane call, 256 the round-1 thresholds of the tile choice), "attn_kernel" (0 automatic, 1: 4-wave, 2: staggered 8-wave, 3: software-pipelined 4-wave),
+ * "attn_remap" (0: plain workgroup order instead of one XCD per (batch, head) with the ragged query tiles last), "attn_tail" (0: the regular schedule
+ * also for a ragged last query tile of <= 32 rows instead of splitting its keys over the four waves),
  * "prune_last_block" (0: run the last decoder block over all tokens), "ln_fuse" (1: LayerNorm folded into the GEMMs around it instead of the
- * stand-alone LayerNorm kernels -- measured slower, off by default); queries: "sk_error" (non-zero return = a stream-K hand-off
+ * stand-alone LayerNorm kernels -- measured slower, off by default; a model carries the fold state only if it was CREATED while the switch was on),
+ * "conj_attn" (0: the fp32 VALU cross / context attention kernels of the IMU-conditioned model instead of the MFMA ones), "conj_ctx_stream" (0: the
+ * context stream's blocks on the lane's own stream instead of a side stream between cross blocks); queries: "sk_error" (non-zero return = a stream-K hand-off
  * wait timed out), "attn_prof" / "gemm_prof" (per-workgroup timers of builds with -DCWM_ATTN_PROF / -DCWM_GEMM_PROF) */
 int cwm_debug_set(const char* key, int value);
 
