@@ -536,27 +536,36 @@ bool cross_attention_mfma_ok(int head_dim, int M) { return (head_dim == 32 || he
 size_t cross_attention_mfma_partial_floats(int B, int heads, int M, int head_dim) { return (size_t)B * heads * kCrossSplit2 * M * (head_dim + 4); }
 
 template <int PLANES, int NDB, int MT>
-static int launch_cross_mfma_t(const CrossAttnParams& p, hipStream_t stream) {
+static int launch_cross_mfma_t(const CrossAttnParams& p, hipStream_t stream, hipStream_t stream_b, int roles) {
     constexpr int HD = NDB * 32, KPLANE = 32 * MT * (HD * 2 + 16), VPLANE = HD * (64 * MT + 16);
     constexpr int smem_a = PLANES * (KPLANE + VPLANE), smem_b = PLANES * KPLANE + 4 * PLANES * 4096;
     auto ka = cross_attn_mfma_kernel<PLANES, NDB, MT, 0>;
     auto kb = cross_attn_mfma_kernel<PLANES, NDB, MT, 1>;
     if (int rc = cwm_set_max_lds((const void*)ka, smem_a)) return rc;
     if (int rc = cwm_set_max_lds((const void*)kb, smem_b)) return rc;
-    hipLaunchKernelGGL(ka, dim3(2 * kCrossSplit2 / 8, p.B * p.heads), dim3(512), smem_a, stream, p);
-    hipLaunchKernelGGL(kb, dim3(kCrossSplit2 / 4, p.B * p.heads), dim3(256), smem_b, stream, p);
-    hipLaunchKernelGGL(cross_attn_combine_kernel<PLANES>, dim3(p.M, p.B * p.heads), dim3(256), 0, stream, p);
+    // role A (main-stream update) on `stream`; role B (context update) + its combine on `stream_b` (may be the same stream)
+    if (roles & 1) hipLaunchKernelGGL(ka, dim3(2 * kCrossSplit2 / 8, p.B * p.heads), dim3(512), smem_a, stream, p);
+    if (roles & 2) {
+        hipLaunchKernelGGL(kb, dim3(kCrossSplit2 / 4, p.B * p.heads), dim3(256), smem_b, stream_b, p);
+        hipLaunchKernelGGL(cross_attn_combine_kernel<PLANES>, dim3(p.M, p.B * p.heads), dim3(256), 0, stream_b, p);
+    }
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-int launch_cross_attention_mfma(const CrossAttnParams& p, int planes, hipStream_t stream) {
+int launch_cross_attention_mfma(const CrossAttnParams& p, int planes, hipStream_t stream) { return launch_cross_attention_mfma_roles(p, planes, stream, stream, 3); }
+
+// roles: bit 0 = role A (main-stream update, on stream_a), bit 1 = role B + combine (context update, on stream_b).  The two roles touch
+// disjoint outputs and may run concurrently (conj_model.hip puts role B on the context stream's side stream).
+int launch_cross_attention_mfma_roles(const CrossAttnParams& p, int planes, hipStream_t stream_a, hipStream_t stream_b, int roles) {
+    // (a null stream handle is a valid stream: the role mask, not the handle, says what to launch)
+    hipStream_t const sa = stream_a, sb = stream_b;
     CWM_REQUIRE(cross_attention_mfma_ok(p.head_dim, p.M), "cross_attention (MFMA): head_dim %d / M %d not supported", p.head_dim, p.M);
     CWM_REQUIRE(p.qk_op && p.v_op && p.qk_src && p.v_src && p.y && p.y_src && p.partial, "cross_attention (MFMA): null argument");
     CWM_REQUIRE(p.N >= 1 && (int64_t)p.B * p.N * 4 * p.heads * p.head_dim < (1ll << 31), "cross_attention (MFMA): problem too large for 32-bit offsets");
     const int ndb = p.head_dim / 32, mt = p.M > 32 ? 2 : 1;
 #define CWM_CROSS_CASE(PL, NDB, MT) \
-    if (planes == PL && ndb == NDB && mt == MT) return launch_cross_mfma_t<PL, NDB, MT>(p, stream);
+    if (planes == PL && ndb == NDB && mt == MT) return launch_cross_mfma_t<PL, NDB, MT>(p, sa, sb, roles);
     CWM_CROSS_CASE(2, 6, 1) CWM_CROSS_CASE(2, 3, 1) CWM_CROSS_CASE(2, 3, 2) CWM_CROSS_CASE(2, 1, 1) CWM_CROSS_CASE(2, 1, 2)
     CWM_CROSS_CASE(1, 6, 1) CWM_CROSS_CASE(1, 3, 1) CWM_CROSS_CASE(1, 3, 2) CWM_CROSS_CASE(1, 1, 1) CWM_CROSS_CASE(1, 1, 2)
 #undef CWM_CROSS_CASE

@@ -48,12 +48,15 @@ struct cwm_conj_model {
     // the context (IMU) stream of every lane runs its blocks on a stream of its own between two cross blocks (conj_forward_lane)
     hipStream_t ctx_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_ctx[2] = {nullptr, nullptr}, ev_main[2] = {nullptr, nullptr};
+    hipEvent_t ev_cross[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // run_cross
     ~cwm_conj_model() {
         if (lane_stream) (void)hipStreamDestroy(lane_stream);
         for (int i = 0; i < 2; ++i) {
             if (ctx_stream[i]) (void)hipStreamDestroy(ctx_stream[i]);
             if (ev_ctx[i]) (void)hipEventDestroy(ev_ctx[i]);
             if (ev_main[i]) (void)hipEventDestroy(ev_main[i]);
+            for (int k = 0; k < 4; ++k)
+                if (ev_cross[i][k]) (void)hipEventDestroy(ev_cross[i][k]);
         }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -268,17 +271,36 @@ int linear_gelu(Engine& E, const bf16* A, int rows, int K, const LinearW& L, bf1
     return E.run_gemm(g, planes, s);
 }
 
-// CrossAttentionTransformerBlock.forward (transformer.py:559-583) with with_self_attention=False
-int run_cross(ConjLane& L, const CrossW& C, float* x, int N, int ci, float* src, int M, int cs, int B, int planes, hipStream_t s) {
+// CrossAttentionTransformerBlock.forward (transformer.py:559-583) with with_self_attention=False.
+//
+// s = the lane's stream (RGB side), sc = the lane's context stream (== s: everything in order on one stream).  With two streams and the
+// MFMA kernels the block runs as two chains that meet once:
+//     s :  LN(x) -> qk, v projections ---+--> role A (y = softmax_M . v_src) -> x += proj(y) -> LN2 -> MLP_trg
+//     sc:  LN(src) -> qk_src, v_src -----+--> role B + combine (y_src = softmax_N . v) -> src += proj_src(y_src) -> LN2 -> MLP_src
+// (+: each stream waits for the other one's projections).  The two roles stream disjoint halves of the RGB-side projections and run
+// concurrently; the ~10 tiny context-side launches leave the lane's stream.  ev[0..3] = {s projections done, sc projections done, role A
+// done, role B done}: the last two guard the projection buffers against the NEXT cross block of the lane (role B reads qk / v that the
+// next block's projections on s overwrite, role A reads qk_src / v_src that the next block overwrites on sc).
+int run_cross(ConjLane& L, const CrossW& C, float* x, int N, int ci, float* src, int M, int cs, int B, int planes, hipStream_t s, hipStream_t sc,
+              hipEvent_t* ev, bool& have_prev) {
     cwm_conj_model* m = L.m;
     Engine& E = m->eng;
     const int D = ci, heads = m->cfg.cross_heads, hd = D / heads;
     const int rows = B * N, rows_s = B * M;
     int rc;
-    if ((rc = layernorm_to(E, x, rows, ci, C.n1_g, C.n1_b, L.main.sb.hbuf, planes, s))) return rc;
-    if ((rc = layernorm_to(E, src, rows_s, cs, C.n1s_g, C.n1s_b, L.ctx.sb.hbuf, planes, s))) return rc;
     // main-stream projections: operand layout (bf16 hi [, lo] planes, the same 4 bytes per element as fp32) for the MFMA kernel
     const bool mfma = g_conj_attn && cross_attention_mfma_ok(hd, M) && (2 * D) % 32 == 0;
+    const bool two = sc != s && mfma;
+    if (sc != s && !two) {  // VALU fallback: one chain on s, bracketed by the context stream
+        CWM_HIP_CHECK(hipEventRecord(ev[1], sc));
+        CWM_HIP_CHECK(hipStreamWaitEvent(s, ev[1], 0));
+    }
+    hipStream_t const t = two ? sc : s;  // where the context side runs
+    if (two && have_prev) {
+        CWM_HIP_CHECK(hipStreamWaitEvent(s, ev[3], 0));  // the previous block's role B has read qk / v
+        CWM_HIP_CHECK(hipStreamWaitEvent(sc, ev[2], 0));  // ... its role A has read qk_src / v_src
+    }
+    if ((rc = layernorm_to(E, x, rows, ci, C.n1_g, C.n1_b, L.main.sb.hbuf, planes, s))) return rc;
     if (mfma) {
         if ((rc = linear_operand(E, L.main.sb.hbuf, rows, ci, C.qk, reinterpret_cast<bf16*>(L.qk), planes, s))) return rc;
         if ((rc = linear_operand(E, L.main.sb.hbuf, rows, ci, C.v, reinterpret_cast<bf16*>(L.v), planes, s))) return rc;
@@ -286,25 +308,45 @@ int run_cross(ConjLane& L, const CrossW& C, float* x, int N, int ci, float* src,
         if ((rc = linear_f32(E, L.main.sb.hbuf, rows, ci, C.qk, L.qk, nullptr, planes, s))) return rc;
         if ((rc = linear_f32(E, L.main.sb.hbuf, rows, ci, C.v, L.v, nullptr, planes, s))) return rc;
     }
-    if ((rc = linear_f32(E, L.ctx.sb.hbuf, rows_s, cs, C.qk_src, L.qk_src, nullptr, planes, s))) return rc;
-    if ((rc = linear_f32(E, L.ctx.sb.hbuf, rows_s, cs, C.v_src, L.v_src, nullptr, planes, s))) return rc;
+    if ((rc = layernorm_to(E, src, rows_s, cs, C.n1s_g, C.n1s_b, L.ctx.sb.hbuf, planes, t))) return rc;
+    if ((rc = linear_f32(E, L.ctx.sb.hbuf, rows_s, cs, C.qk_src, L.qk_src, nullptr, planes, t))) return rc;
+    if ((rc = linear_f32(E, L.ctx.sb.hbuf, rows_s, cs, C.v_src, L.v_src, nullptr, planes, t))) return rc;
+    if (two) {
+        CWM_HIP_CHECK(hipEventRecord(ev[0], s));
+        CWM_HIP_CHECK(hipEventRecord(ev[1], sc));
+        CWM_HIP_CHECK(hipStreamWaitEvent(sc, ev[0], 0));
+        CWM_HIP_CHECK(hipStreamWaitEvent(s, ev[1], 0));
+    }
     CrossAttnParams ca;
     memset(&ca, 0, sizeof(ca));
     ca.qk = L.qk; ca.v = L.v; ca.qk_op = reinterpret_cast<const bf16*>(L.qk); ca.v_op = reinterpret_cast<const bf16*>(L.v); ca.qk_src = L.qk_src; ca.v_src = L.v_src; ca.B = B; ca.N = N; ca.M = M; ca.heads = heads; ca.head_dim = hd;
     ca.scale = 1.0f / sqrtf((float)hd);
     ca.y = L.ybuf; ca.y_plane = (int64_t)rows * D; ca.y_src = L.ysbuf; ca.y_src_plane = (int64_t)rows_s * D; ca.scores_t = L.scores_t; ca.partial = L.cross_partial;
-    // both directions: 2 x (scores 2 N M hd + P.V 2 N M hd) FLOP per head
-    if ((rc = E.timed(CWM_KCLASS_CROSS_ATTN, 8.0 * (double)B * heads * N * M * hd, s,
-                      [&] { return mfma ? launch_cross_attention_mfma(ca, planes, s) : launch_cross_attention(ca, planes, s); })))
-        return rc;
+    if (two) {
+        if ((rc = launch_cross_attention_mfma_roles(ca, planes, s, sc, 1))) return rc;
+        CWM_HIP_CHECK(hipEventRecord(ev[2], s));
+        if ((rc = launch_cross_attention_mfma_roles(ca, planes, s, sc, 2))) return rc;
+        CWM_HIP_CHECK(hipEventRecord(ev[3], sc));
+        have_prev = true;
+    } else {
+        // both directions: 2 x (scores 2 N M hd + P.V 2 N M hd) FLOP per head
+        if ((rc = E.timed(CWM_KCLASS_CROSS_ATTN, 8.0 * (double)B * heads * N * M * hd, s,
+                          [&] { return mfma ? launch_cross_attention_mfma(ca, planes, s) : launch_cross_attention(ca, planes, s); })))
+            return rc;
+    }
     if ((rc = linear_f32(E, L.ybuf, rows, D, C.proj, x, x, planes, s))) return rc;          // x += proj(y) + b
-    if ((rc = linear_f32(E, L.ysbuf, rows_s, D, C.proj_src, src, src, planes, s))) return rc;
     if ((rc = layernorm_to(E, x, rows, ci, C.n2_g, C.n2_b, L.main.sb.hbuf, planes, s))) return rc;
     if ((rc = linear_gelu(E, L.main.sb.hbuf, rows, ci, C.mlp_t0, L.main.sb.gbuf, planes, s))) return rc;
     if ((rc = linear_f32(E, L.main.sb.gbuf, rows, C.mlp_t0.N, C.mlp_t2, x, x, planes, s))) return rc;
-    if ((rc = layernorm_to(E, src, rows_s, cs, C.n2s_g, C.n2s_b, L.ctx.sb.hbuf, planes, s))) return rc;
-    if ((rc = linear_gelu(E, L.ctx.sb.hbuf, rows_s, cs, C.mlp_s0, L.ctx.sb.gbuf, planes, s))) return rc;
-    return linear_f32(E, L.ctx.sb.gbuf, rows_s, C.mlp_s0.N, C.mlp_s2, src, src, planes, s);
+    if ((rc = linear_f32(E, L.ysbuf, rows_s, D, C.proj_src, src, src, planes, t))) return rc;
+    if ((rc = layernorm_to(E, src, rows_s, cs, C.n2s_g, C.n2s_b, L.ctx.sb.hbuf, planes, t))) return rc;
+    if ((rc = linear_gelu(E, L.ctx.sb.hbuf, rows_s, cs, C.mlp_s0, L.ctx.sb.gbuf, planes, t))) return rc;
+    if ((rc = linear_f32(E, L.ctx.sb.gbuf, rows_s, C.mlp_s0.N, C.mlp_s2, src, src, planes, t))) return rc;
+    if (sc != s && !two) {  // VALU fallback: the context stream continues behind the whole block
+        CWM_HIP_CHECK(hipEventRecord(ev[0], s));
+        CWM_HIP_CHECK(hipStreamWaitEvent(sc, ev[0], 0));
+    }
+    return 0;
 }
 
 // tokens + pos | null tokens, gathered by the padded mask (pad_and_mask_input, conjoined_vmae.py:125-134)
@@ -405,10 +447,10 @@ int g_conj_ctx_stream = 1;  // "conj_ctx_stream" switch: 0 keeps the context str
 
 // One lane: batch elements [b0, b0 + B) of the call on stream s.
 //
-// The context (IMU) stream is a chain of ~200 tiny launches (25 / 50 tokens per sample: 5-15 us each, latency-bound) that only meets
-// the RGB stream in the 8 cross blocks.  Between two cross blocks its self-attention blocks run on a stream of their own (sc), so
-// that the chain hides under the RGB stream's kernels instead of extending the lane by ~4 %: before a cross block the lane's stream
-// waits for sc, after it sc waits for the lane's stream.  (Not while kernel timers are on: those want every launch alone on the chip.)
+// The context (IMU) stream is a chain of ~300 tiny launches (25 / 50 tokens per sample: 5-15 us each, latency-bound) that only meets
+// the RGB stream in the 8 cross blocks.  It runs on a stream of its own (sc), so that the chain hides under the RGB stream's kernels
+// instead of extending the lane by ~4 %; inside a cross block the two streams exchange their projections once (run_cross).
+// (Not while kernel timers are on: those want every launch alone on the chip.)
 static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0, int B, hipStream_t s, int lane) {
     cwm_conj_model* m = L.m;
     const cwm_conj_config& c = m->cfg;
@@ -432,7 +474,9 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
         CWM_HIP_CHECK(hipStreamCreateWithFlags(&m->ctx_stream[lane], hipStreamNonBlocking));
         CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_ctx[lane], hipEventDisableTiming));
         CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_main[lane], hipEventDisableTiming));
+        for (int k = 0; k < 4; ++k) CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_cross[lane][k], hipEventDisableTiming));
     }
+    bool have_prev = false;  // a cross block of this forward has used the projection buffers (run_cross)
     hipStream_t sc = side ? m->ctx_stream[lane] : s;
     // main -> ctx: the context stream may continue once everything queued on s so far is done; ctx -> main likewise
     auto ctx_follows_main = [&]() -> int {
@@ -474,11 +518,9 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
     // encoder: cross block BEFORE the self-attention blocks listed in enc_cross (forward_encoder_blocks :543-576)
     for (int i = 0; i < mc.enc_depth; ++i) {
         for (int k = 0; k < c.n_enc_cross; ++k)
-            if (c.enc_cross[k] == i) {
-                if ((rc = main_follows_ctx())) return rc;
-                if ((rc = run_cross(L, m->enc_cross[k], A.x_enc, vm, A.enc_dim, S.x_enc, vc, S.enc_dim, B, planes, s))) return rc;
-                if ((rc = ctx_follows_main())) return rc;
-            }
+            if (c.enc_cross[k] == i &&
+                (rc = run_cross(L, m->enc_cross[k], A.x_enc, vm, A.enc_dim, S.x_enc, vc, S.enc_dim, B, planes, s, sc, m->ev_cross[lane], have_prev)))
+                return rc;
         if ((rc = E.run_block(A.enc[i], A.x_enc, B, vm, A.enc_dim, A.enc_heads, planes, A.sb, s))) return rc;
         if ((rc = E.run_block_small(S.enc[i], S.x_enc, B, vc, S.enc_dim, S.enc_heads, planes, S.sb, sc))) return rc;
     }
@@ -489,11 +531,9 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
         if ((rc = E.run_block(A.dec[i], A.x_dec, B, Nx, A.dec_dim, A.dec_heads, planes, A.sb, s))) return rc;
         if ((rc = E.run_block_small(S.dec[i], S.x_dec, B, Mx, S.dec_dim, S.dec_heads, planes, S.sb, sc))) return rc;
         for (int k = 0; k < c.n_dec_cross; ++k)
-            if (c.dec_cross[k] == i) {
-                if ((rc = main_follows_ctx())) return rc;
-                if ((rc = run_cross(L, m->dec_cross[k], A.x_dec, Nx, A.dec_dim, S.x_dec, Mx, S.dec_dim, B, planes, s))) return rc;
-                if ((rc = ctx_follows_main())) return rc;
-            }
+            if (c.dec_cross[k] == i &&
+                (rc = run_cross(L, m->dec_cross[k], A.x_dec, Nx, A.dec_dim, S.x_dec, Mx, S.dec_dim, B, planes, s, sc, m->ev_cross[lane], have_prev)))
+                return rc;
     }
     if ((rc = main_follows_ctx())) return rc;  // the call's stream semantics cover the context stream's work too
 

@@ -225,6 +225,7 @@ struct CrossAttnParams {
 int launch_cross_attention(const CrossAttnParams& p, int planes, hipStream_t stream);       // fp32 VALU kernels: qk / v fp32, scores_t + partial scratch
 size_t cross_attention_partial_floats(int B, int heads, int M, int head_dim);
 int launch_cross_attention_mfma(const CrossAttnParams& p, int planes, hipStream_t stream);  // MFMA kernel: qk_op / v_op, partial scratch
+int launch_cross_attention_mfma_roles(const CrossAttnParams& p, int planes, hipStream_t stream_a, hipStream_t stream_b, int roles);  // bit 0: main update on stream_a, bit 1: context update on stream_b
 bool cross_attention_mfma_ok(int head_dim, int M);
 size_t cross_attention_mfma_partial_floats(int B, int heads, int M, int head_dim);
 extern int g_conj_ctx_stream;  // 1 (default): the IMU-conditioned model runs its context stream's blocks on a side stream between cross blocks
