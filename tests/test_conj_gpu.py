@@ -150,3 +150,33 @@ def test_mfma_and_valu_conj_attention_agree(which):
             assert torch.equal(y1.abs().sum(-1) == 0, y0.abs().sum(-1) == 0)
     finally:
         _lib.check(lib.cwm_debug_set(b"conj_attn", 1))
+
+
+def test_context_side_stream_is_bitwise_neutral():
+    """cwm_debug_set("conj_ctx_stream"): the IMU stream's blocks and the context side of every cross block run on a side HIP stream per
+    lane, exchanging projections with the lane's stream through events (csrc/conj_model.hip run_cross).  Pure scheduling: outputs must be
+    bit-identical to the one-stream order, call after call (a missing event would show as a race), for one and two lanes."""
+    from counterfactualworldmodels_amd import _lib
+
+    lib = _lib.get_lib()
+    g = np.load(os.path.join(GOLDEN, "conj_imu400_b2.npz"))
+    cfg = C.CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"]
+    m = build(cfg, int(g["seed"]))
+    B = 6
+    x = V.preprocess(torch.from_numpy(S.synthetic_frames(B, cfg.main, 2))).cuda()
+    mask = torch.stack([torch.from_numpy(g["mask"])[i % 2] for i in range(B)]).cuda()
+    imu = torch.stack([torch.from_numpy(g["imu"])[i % 2] * (1.0 + 0.2 * i) for i in range(B)]).cuda()
+    mc = torch.zeros(B, 25, dtype=torch.bool, device="cuda")
+    mc[2, 5] = True
+    m(x[:1], mask[:1], x_context=imu[:1], mask_context=mc[:1])   # creates the library handle
+    try:
+        for lanes in (2, 1):
+            m.set_lanes(lanes)
+            _lib.check(lib.cwm_debug_set(b"conj_ctx_stream", 0))
+            ref = m(x, mask, x_context=imu, mask_context=mc)
+            _lib.check(lib.cwm_debug_set(b"conj_ctx_stream", 1))
+            for rep in range(4):
+                assert torch.equal(m(x, mask, x_context=imu, mask_context=mc), ref), (lanes, rep)
+    finally:
+        _lib.check(lib.cwm_debug_set(b"conj_ctx_stream", 1))
+        m.set_lanes(2)
