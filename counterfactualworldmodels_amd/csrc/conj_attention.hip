@@ -559,13 +559,12 @@ int launch_cross_attention_mfma(const CrossAttnParams& p, int planes, hipStream_
 // disjoint outputs and may run concurrently (conj_model.hip puts role B on the context stream's side stream).
 int launch_cross_attention_mfma_roles(const CrossAttnParams& p, int planes, hipStream_t stream_a, hipStream_t stream_b, int roles) {
     // (a null stream handle is a valid stream: the role mask, not the handle, says what to launch)
-    hipStream_t const sa = stream_a, sb = stream_b;
     CWM_REQUIRE(cross_attention_mfma_ok(p.head_dim, p.M), "cross_attention (MFMA): head_dim %d / M %d not supported", p.head_dim, p.M);
     CWM_REQUIRE(p.qk_op && p.v_op && p.qk_src && p.v_src && p.y && p.y_src && p.partial, "cross_attention (MFMA): null argument");
     CWM_REQUIRE(p.N >= 1 && (int64_t)p.B * p.N * 4 * p.heads * p.head_dim < (1ll << 31), "cross_attention (MFMA): problem too large for 32-bit offsets");
     const int ndb = p.head_dim / 32, mt = p.M > 32 ? 2 : 1;
 #define CWM_CROSS_CASE(PL, NDB, MT) \
-    if (planes == PL && ndb == NDB && mt == MT) return launch_cross_mfma_t<PL, NDB, MT>(p, sa, sb, roles);
+    if (planes == PL && ndb == NDB && mt == MT) return launch_cross_mfma_t<PL, NDB, MT>(p, stream_a, stream_b, roles);
     CWM_CROSS_CASE(2, 6, 1) CWM_CROSS_CASE(2, 3, 1) CWM_CROSS_CASE(2, 3, 2) CWM_CROSS_CASE(2, 1, 1) CWM_CROSS_CASE(2, 1, 2)
     CWM_CROSS_CASE(1, 6, 1) CWM_CROSS_CASE(1, 3, 1) CWM_CROSS_CASE(1, 3, 2) CWM_CROSS_CASE(1, 1, 1) CWM_CROSS_CASE(1, 1, 2)
 #undef CWM_CROSS_CASE
