@@ -14,9 +14,9 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def build(cfg, seed, mode="parity"):
+def build(cfg, seed, mode="parity", sharp=False):
     m = CV.ConjoinedPaddedVisionTransformer(cfg, mode=mode)
-    m.load_state_dict(conj_weights(cfg, seed))
+    m.load_state_dict(conj_weights(cfg, seed, sharp))
     return m.cuda().eval()
 
 
@@ -68,6 +68,22 @@ def test_imu400_full_size_golden():
     yf = m(V.preprocess(x).cuda(), mask, x_context=imu, mask_context=torch.zeros(2, 25, dtype=torch.bool, device="cuda")).cpu().numpy()
     print(f"[imu400 B=2 ragged] fast-mode max-abs vs reference: {np.abs(yf - g['y_tokens']).max():.3e}")
     assert np.abs(yf - g["y_tokens"]).max() <= 2.5e-1
+
+
+def test_imu400_sharp_weights_golden():
+    """The IMU-conditioned model under the hostile weights (sharp softmax in both streams' self-attention, LayerNorm weights U(0.2, 3)
+    incl. the cross blocks' norms, residual growth), one masked context token, against the reference's output."""
+    g = np.load(os.path.join(GOLDEN, "conj_imu400_sharp_b1.npz"))
+    cfg = C.CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"]
+    seed = int(g["seed"])
+    m = build(cfg, seed, sharp=True)
+    x = torch.from_numpy(S.synthetic_frames(1, cfg.main, seed))
+    mask, imu, mc = (torch.from_numpy(g[k]).cuda() for k in ("mask", "imu", "mask_context"))
+    y = m(V.preprocess(x).cuda(), mask, x_context=imu, mask_context=mc).cpu().numpy()
+    err = np.abs(y - g["y_tokens"]).max()
+    print(f"[imu400 sharp] parity-mode max-abs vs reference: {err:.3e}")
+    assert y.shape == g["y_tokens"].shape and err <= 1e-3, err
+    assert np.array_equal(np.abs(y).sum(-1) == 0, np.abs(g["y_tokens"]).sum(-1) == 0)
 
 
 def test_conj_errors():

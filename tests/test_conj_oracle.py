@@ -17,8 +17,11 @@ TINY_SPEC = CO.ConjSpec(main=V.VmaeSpec(img_size=(32, 32), patch=4, enc_dim=128,
                         enc_cross=(0,), dec_cross=(0,))
 
 
-def conj_weights(cfg, seed):
-    return {k: torch.from_numpy(S.synthetic_tensor(k, shp, seed)) for k, shp in C.conj_state_dict_schema(cfg).items()}
+def conj_weights(cfg, seed, sharp=False):
+    w = {k: S.synthetic_tensor(k, shp, seed) for k, shp in C.conj_state_dict_schema(cfg).items()}
+    if sharp:
+        w = S.sharpen_state_dict(w, seed)
+    return {k: torch.from_numpy(v) for k, v in w.items()}
 
 
 def test_schema_known_answers():
@@ -73,6 +76,21 @@ def test_imu400_full_size_vs_reference():
     assert y.shape == (2, 6272 + 64 - 3142, 48)
     err = np.abs(y.numpy() - g["y_tokens"]).max()
     assert err <= 5e-5, err
+
+
+def test_imu400_sharp_weights_vs_reference():
+    """Hostile weights (synthetic.sharpen_state_dict) through the full-size IMU-conditioned model, one masked context token."""
+    g = np.load(os.path.join(GOLDEN, "conj_imu400_sharp_b1.npz"))
+    cfg = C.CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"]
+    seed = int(g["seed"])
+    W = conj_weights(cfg, seed, sharp=True)
+    x = torch.from_numpy(S.synthetic_frames(1, cfg.main, seed))
+    mask, imu, mc = (torch.from_numpy(g[k]) for k in ("mask", "imu", "mask_context"))
+    assert np.array_equal(mask.numpy(), S.synthetic_masks(1, cfg.main, 4, seed))
+    with torch.no_grad():
+        y = CO.conj_forward(W, CO.IMU400_BASE_4X4, V.preprocess(x), mask, imu, mc)
+    err = np.abs(y.numpy() - g["y_tokens"]).max()
+    assert y.shape == g["y_tokens"].shape and err <= 1e-4, err
 
 
 def test_host_mirror_schema_and_attributes():

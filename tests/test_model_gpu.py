@@ -101,6 +101,22 @@ def test_sharp_weights_golden_parity(name):
     assert np.isfinite(yf).all() and np.abs(yf - g["y_tokens"]).max() <= 2.7e-1   # 2x the measured 1.3e-1
 
 
+def test_sharp_weights_large4_parity():
+    """ViT-L/4 (36 blocks) under the hostile weights, against the reference's output: parity mode inside 1e-3 (the CPU emulation of
+    the split-bf16 arithmetic predicts 1.6e-4)."""
+    g = np.load(os.path.join(GOLDEN, "large4_sharp_b1.npz"))
+    cfg = C.CONFIGS["large_4x4patch_2frames_1tube"]
+    seed = int(g["seed"])
+    x = torch.from_numpy(S.synthetic_frames(1, cfg, seed))
+    mask = torch.from_numpy(S.synthetic_masks(1, cfg, 32, seed, 2))
+    m = build(cfg, seed, "parity", sharp=True)
+    G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+    y = G.predict_tokens(x.cuda(), mask.cuda()).cpu().numpy()
+    err = np.abs(y - g["y_tokens"]).max()
+    print(f"[large4 sharp] parity-mode max-abs vs reference: {err:.3e}")
+    assert err <= PARITY_TOL, err
+
+
 def test_large4_golden_parity():
     g = np.load(os.path.join(GOLDEN, "large4_k32_b1.npz"))
     cfg = C.CONFIGS["large_4x4patch_2frames_1tube"]

@@ -73,6 +73,20 @@ def test_sharp_weights_full_size():
     assert np.abs(y.numpy() - g["y_tokens"]).max() <= 5e-5
 
 
+def test_sharp_weights_large4():
+    """The hostile-weights fixture of ViT-L/4 (36 blocks): the reference's own fp32 rounding is 9.5e-6 there (fp32 vs float64)."""
+    g = load("large4_sharp_b1.npz")
+    cfg = C.CONFIGS["large_4x4patch_2frames_1tube"]
+    seed = int(g["seed"])
+    x = torch.from_numpy(S.synthetic_frames(1, cfg, seed))
+    mask = torch.from_numpy(S.synthetic_masks(1, cfg, 32, seed, 2))
+    assert np.array_equal(mask.numpy(), g["mask"]) and bool(g["sharp"])
+    with torch.no_grad():
+        y = O.vmae_forward(weights(cfg, seed, sharp=True), O.SPECS[cfg.name], O.preprocess(x), mask)
+    err = np.abs(y.numpy() - g["y_tokens"]).max()
+    assert err <= 1e-4, err
+
+
 def test_precision_hooks_default_to_reference_arithmetic():
     """The operand-rounding hooks (tests/precision_budget.py) must be inert by default and restore cleanly."""
     g = load("tiny_8x8_k4.npz")
