@@ -116,11 +116,14 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN ==
         const int logical = (lane % 8) ^ lds_swizzle<64>(row);
         a_src[jj] = (unsigned)(p.m_offset + min(m0 + row, p.M - 1)) * (unsigned)(p.lda * PLANES) + logical * 8;
     }
+    // direct epilogue with bf16 outputs: the W rows of every 32-row group are staged in permuted order, so that a lane's two column
+    // fragments are 8 consecutive output columns (gemm_device.h, epilogue_direct)
+    const bool wperm = FUSE == 0 && p.direct && p.epi != EPI_F32;
 #pragma unroll
     for (int jj = 0; jj < NIB; ++jj) {
         const int row = (wave * NIB + jj) * 8 + lane / 8;
         const int logical = (lane % 8) ^ lds_swizzle<64>(row);
-        w_src[jj] = (unsigned)(n0 + row) * (unsigned)(p.K * PLANES) + logical * 8;
+        w_src[jj] = (unsigned)(n0 + (wperm ? w_row_perm(row) : row)) * (unsigned)(p.K * PLANES) + logical * 8;
     }
     auto issue_tile = [&](int stage, int k0) {
         char* sb = smem + stage * STAGE_BYTES;
@@ -270,6 +273,17 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN ==
             }
         }
     }
+    if constexpr (FUSE == 0) {
+        if (p.direct) {
+            __syncthreads();  // every wave is done with the operand tiles: the row table takes their place
+            int4* tab = reinterpret_cast<int4*>(smem);
+            epilogue_row_table<0>(p, tab, m0, BM, n0, BN, tid);
+            __syncthreads();
+            epilogue_direct_tile<PLANES, FM, FN>(p, acc, tab, wr * (16 * FM), n0 + wc * (16 * FN), lane);
+            GEMM_PROF_END();
+            return;
+        }
+    }
     if (p.staged) {
         __syncthreads();  // every wave is done with the operand tiles: LDS becomes the epilogue's staging space
         int4* tab = reinterpret_cast<int4*>(smem + NWAVES * 8192);
@@ -325,6 +339,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
     const int m0 = (first_m + (in_g % gm)) * 256, n0 = (in_g / gm) * 256;
 
     // ---- LDS-DMA sources: wave w stages pieces 2w, 2w+1 (rows 16w .. 16w+15) of every half-tile ----
+    // (direct epilogue with bf16 outputs: W rows permuted inside every 32-row group, gemm_device.h epilogue_direct)
+    const bool wperm = FUSE == 0 && p.direct && p.epi != EPI_F32;
     unsigned src[4][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
             const int row = wave * 16 + jj * 8 + lane / 8;
             const int logical = (lane % 8) ^ lds_swizzle<64>(row);
             src[h][jj] = (unsigned)(p.m_offset + min(m0 + h * 128 + row, p.M - 1)) * (unsigned)(p.lda * PLANES) + logical * 8;
-            src[2 + h][jj] = (unsigned)(n0 + h * 128 + row) * (unsigned)(p.K * PLANES) + logical * 8;
+            src[2 + h][jj] = (unsigned)(n0 + h * 128 + (wperm ? w_row_perm(row) : row)) * (unsigned)(p.K * PLANES) + logical * 8;
         }
     auto stage = [&](auto half_c, int buf, int kt) {
         constexpr int half = decltype(half_c)::value;
@@ -474,6 +490,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
         return;
     }
     GEMM_PROF_MAIN();
+    if constexpr (FUSE == 0) {
+        if (p.direct) {
+            // (the balancing barrier above is also the point where every wave is done reading the operand tiles)
+            int4* tab = reinterpret_cast<int4*>(smem);
+            epilogue_row_table<0>(p, tab, m0, 256, n0, 256, tid);
+            __syncthreads();
+            epilogue_direct<PLANES, 4>(
+                p, [&](int pi, int i, int j) { return acc[pi >> 1][pi & 1][i][j]; }, [&](int pi) { return (pi >> 1) * 128 + wr * 64; },
+                [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, tab, lane);
+            GEMM_PROF_END();
+            return;
+        }
+    }
     if (p.staged) {
         // (the balancing barrier above is also the point where every wave is done reading the operand tiles)
         int4* tab = reinterpret_cast<int4*>(smem + 8 * 8192);
@@ -519,7 +548,9 @@ int splitk_workspace_alloc(float** slabs, unsigned** counts) {
 int g_gemm_tile = 0;  // 0 = automatic choice per shape
 static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t stream);
 int g_gemm_debug = 0;
-int g_gemm_staged = 1;  // 0: force the direct (per-fragment) epilogue
+int g_gemm_staged = 1;  // 0: force the per-fragment epilogue of round 1
+int g_gemm_direct = 1;  // 1 (default): bf16-output epilogues (qkv, fc1, the cross-attention projections) store straight from the accumulators with the W tile
+                        // staged in permuted row order (gemm_device.h epilogue_direct); 2: the fp32-output epilogues too (measured slower); 0: LDS-staged everywhere
 
 // Mixed tiling (tile configuration 6): the leading rows that fill whole rounds of 256x256 tiles go to the 8-phase kernel, the
 // remaining rows to 128x128 tiles.  Both kernels apply the same product sequence to every accumulator, so the result does not
@@ -555,15 +586,17 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
         // profiles/r1n_*, r1o_*, r1p_* logs).  The 256x256 8-phase kernel has the fastest main loop (~1.6 PFLOP/s of executed MFMA
         // work) but one workgroup per CU, so what decides is how its grid fills the chip:
         //  * fewer tiles than CUs: one partial round -- fine from half the CUs up, else 128x128 tiles (more, smaller workgroups)
-        //  * whole rounds mostly full (fill >= 0.75 for long K, 0.85 for K < 1024, where the un-overlapped epilogue weighs more): 8-phase
+        //  * whole rounds + a last round at least half full: 8-phase
         //  * otherwise mixed tiling by rows (6): whole rounds of 256x256 tiles + a remainder of 128x128 tiles -- except the small
         //    short-K launches (proj of B/8), which stay on 128x128 tiles with two workgroups per CU
         //  * N < 512 or ragged narrow N (N = 384, head, patch embed): 128x128
         // (The persistent stream-K form (5) is never selected: it is no faster than (6) and its split tiles re-associate fp32 sums.)
-        //  * K < 512 (the B/8 decoder: K = 384): the 8-wave 128x128 kernel wins at every batch (its epilogues overlap the co-resident
-        //    workgroup's main loop, and with 12 K tiles the epilogue is a third of a 256x256 tile's time): qkv 150 -> 136 us, fc1 214 -> 208
+        //  * K < 512 (the B/8 decoder: K = 384), fp32 outputs: the 8-wave 128x128 kernel (its epilogues overlap the co-resident workgroup's
+        //    main loop, and with 12 K tiles the epilogue is a third of a 256x256 tile's time).  bf16 outputs (qkv, fc1) since round 4: with
+        //    the direct epilogue the 8-phase kernel wins there too (decoder qkv 149 -> 140 us, fc1 214 -> 191 us, profiles/r4_ab_gemm_direct.log)
         cfg = 1;
-        if (p.K >= 512 && p.M >= 512 && (p.N >= 1024 || (p.N >= 512 && p.N % 256 == 0))) {
+        const bool bf16_out = p.epi != EPI_F32;
+        if (p.K >= ((bf16_out && !(g_gemm_debug & 512)) ? 256 : 512) && p.M >= 512 && (p.N >= 1024 || (p.N >= 512 && p.N % 256 == 0))) {
             const int64_t tiles = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
             const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
             if (tiles < cus) {
@@ -572,16 +605,16 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
                 // two batch lanes: the other lane's kernels take the CUs a partly filled last round leaves idle, so the kernel with the
                 // fastest main loop wins regardless of the fill (B/8 batch 32 as 2 x 16: +2 % over the single-lane rule below)
                 cfg = 4;
-            } else if (g_gemm_debug & 256) {  // the round-1 thresholds (A/B)
-                const double fill = (double)tiles / (double)(((tiles + cus - 1) / cus) * cus);
-                if (fill >= (p.K >= 1024 ? 0.75 : 0.85)) cfg = 4;
-                else if (p.K >= 1024 || p.N >= 1024) cfg = 6;
             } else {
-                // whole rounds on the 8-phase kernel; a last round that is less than 80 % full costs a whole tile period there, and its rows
-                // are cheaper on 128x128 tiles (mixed tiling, ~0.8 of the 8-phase rate): qkv at batch 32 = 891 tiles = 3.48 rounds,
-                // 254 -> 228 us (profiles/r3c_ab_mfma_order.log); the small short-K launches (proj: K, N < 1024) stay on 128x128 tiles
+                // whole rounds on the 8-phase kernel; a last round that is less than half full (80 % for the short-K fp32 launches, where the
+                // un-overlapped epilogue weighs more) costs a whole tile period there, and its rows are cheaper on 128x128 tiles (mixed tiling,
+                // ~0.8 of the 8-phase rate): qkv at batch 32 = 891 tiles = 3.48 rounds, 254 -> 228 us (profiles/r3c_ab_mfma_order.log).  Round 4
+                // re-measured the threshold with the direct epilogue (profiles/r4_ab_gemm_direct.log): 48 % full -> mixed (222 vs 228 us),
+                // 55-64 % full -> 8-phase (ViT-L/4 qkv 351 vs 372, fc2 486 vs 507, decoder fc2 275 vs 291).  The small short-K launches
+                // (proj: K, N < 1024) stay on 128x128 tiles.
                 const int last = (int)(tiles % cus);
-                if (last == 0 || last * 5 >= cus * 4) cfg = 4;
+                const bool full_enough = (bf16_out || p.K >= 1024) ? last * 2 >= cus : last * 5 >= cus * 4;
+                if (last == 0 || full_enough) cfg = 4;
                 else if (p.K >= 1024 || p.N >= 1024) cfg = 6;
             }
         }
@@ -624,6 +657,7 @@ static int launch_gemm_checked(const GemmParams& p_in, int planes, int forced_cf
     CWM_REQUIRE((int64_t)(p.m_offset + p.M) * p.lda * planes < (1ll << 32) && (int64_t)(((p.N + 255) / 256) * 256) * p.K * planes < (1ll << 32),
                 "gemm: operand too large for 32-bit element offsets (M=%d lda=%d N=%d K=%d planes=%d): split the batch", p.m_offset + p.M, p.lda,
                 p.N, p.K, planes);
+    p.direct = (g_gemm_direct && p.staged && !p.ln_stats && !p.split_out && (p.epi != EPI_F32 || g_gemm_direct >= 2)) ? 1 : 0;
     int cfg = forced_cfg > 0 ? forced_cfg : gemm_choose_tile(p, planes);
     if (cfg == 6) {
         GemmParams a, b;

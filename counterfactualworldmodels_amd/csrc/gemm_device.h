@@ -473,6 +473,141 @@ __device__ __forceinline__ void epilogue_piece_seq(const GemmParams& p, Frag fra
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Direct epilogue (round 4, p.direct): the accumulators go from registers straight to global memory -- no LDS staging buffer, no
+// write -> wait -> read-back -> wait chain per piece, so the arithmetic of piece k + 1 (bias, GELU, hi / lo split) issues under the
+// stores of piece k.  What made the first per-fragment epilogue slow (8-byte stores, a division per row and fragment) is gone:
+//  * rows come from the LDS row table (one division per tile row, epilogue_row_table);
+//  * for the bf16 outputs the kernel stages the W tile with its rows PERMUTED inside every 32-row group (w_row_perm below), so that
+//    the two 16-column fragments of a lane hold 8 CONSECUTIVE output columns: one 16-byte store per plane and row
+//    (column of fragment j, lane group fq, element e:  nb + 8 fq + 4 j + e);  fp32 outputs keep the natural order (nb + 16 j + 4 fq + e),
+//    where a lane's 4 columns are 16 bytes already.
+// A wave instruction then writes 16 rows x 64 B (lane = 16 fq + fr: row fr, chunk fq).  tools/store_pattern.hip prices that shape at
+// 37 GB/s per CU against 100 GB/s for whole 128-byte lines per 8 lanes -- and 22-28 GB/s per CU for EITHER once all 256 CUs store
+// at the same time, which is what the epilogue round of a GEMM launch does (profiles/r4_store_pattern.log).
+// Same arithmetic per element, in the same order, as the staged form: outputs are bit-identical.
+__device__ __forceinline__ int w_row_perm(int row) {  // LDS row 16 j + 4 q + e of a 32-row group holds W row 8 q + 4 j + e
+    return (row & ~31) | ((row & 12) << 1) | ((row & 16) >> 2) | (row & 3);
+}
+
+template <int PLANES, int NPIECE, class Frag, class Row0, class Nb>
+__device__ __forceinline__ void epilogue_direct(const GemmParams& p, Frag frag, Row0 row0_of, Nb nb_of, const int4* tab, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    typedef __attribute__((address_space(1))) f32x4 gf32x4;
+    typedef __attribute__((address_space(1))) bf16x8 gbf16x8;
+    gf32x4* const trash = (gf32x4*)(g_epilogue_trash + lane * 4);
+    const bool f32_out = p.epi == EPI_F32;
+
+    // every bias load first (the vector-memory queue retires in order: nothing below waits for a store because of them)
+    f32x4 bias[NPIECE][2];
+#pragma unroll
+    for (int pi = 0; pi < NPIECE; ++pi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = nb_of(pi) + (f32_out ? j * 16 + fq * 4 : fq * 8 + j * 4);
+            bias[pi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) bias[pi][j] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        }
+
+    if (f32_out) {
+        // residual rows of one piece: requested one piece ahead, BEFORE the stores of the piece in front of them
+        auto load_resid = [&](int pi, f32x4 (&rv)[4][2]) {
+            const int nb = nb_of(pi), row0 = row0_of(pi);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int4 info = tab[row0 + i * 16 + fr];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = nb + j * 16 + fq * 4;
+                    const bool ok = p.resid && info.x >= 0 && n < p.N;
+                    const gf32x4* src = ok ? (const gf32x4*)(p.resid + (size_t)info.y * p.ldr + n) : trash;
+                    rv[i][j] = *src;
+                }
+            }
+        };
+        f32x4 rv[2][4][2];
+        load_resid(0, rv[0]);
+#pragma unroll
+        for (int pi = 0; pi < NPIECE; ++pi) {
+            const int nb = nb_of(pi), row0 = row0_of(pi);
+            if (pi + 1 < NPIECE) load_resid(pi + 1, rv[(pi + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int4 info = tab[row0 + i * 16 + fr];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = nb + j * 16 + fq * 4;
+                    const bool ok = info.x >= 0 && n < p.N;
+                    f32x4 v = frag(pi, i, j) + bias[pi][j];
+                    if (ok && p.resid) v += rv[pi & 1][i][j];
+                    gf32x4* dst = ok ? (gf32x4*)(p.C + (size_t)info.x * p.ldc + n) : trash;
+                    if (!(p.debug & 1)) *dst = v;
+                    else asm volatile("" ::"v"(v), "v"(dst));
+                }
+            }
+        }
+        return;
+    }
+
+#pragma unroll
+    for (int pi = 0; pi < NPIECE; ++pi) {
+        const int nb = nb_of(pi), row0 = row0_of(pi);
+        const int n = nb + fq * 8;  // this lane's 8 consecutive columns
+        bf16* base;
+        int64_t lo_off;
+        int row_mul, which = 0;
+        if (p.epi == EPI_QKV) {
+            which = nb / p.qkv_dim;
+            const int cD = nb - which * p.qkv_dim;
+            const int qh = cD / p.head_dim, qd = cD - qh * p.head_dim;
+            base = qkv_out_base(p, which) + (size_t)qh * p.n_tok * p.head_dim + qd + fq * 8;
+            row_mul = p.head_dim;
+            lo_off = p.qk_plane;
+        } else {
+            base = p.out_hi + a_pos<PLANES>(0, p.ldo, n);
+            row_mul = PLANES * p.ldo;
+            lo_off = kLoOffset;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int4 info = tab[row0 + i * 16 + fr];
+            bf16x8 hv, lv;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v = frag(pi, i, j) + bias[pi][j];
+                if (p.epi == EPI_BF16_GELU) v = gelu_erf4(v);
+                else if (which == 0 && p.epi == EPI_QKV) v *= p.q_scale;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bf16 hi = (bf16)v[e];
+                    hv[j * 4 + e] = hi;
+                    lv[j * 4 + e] = (bf16)(v[e] - (float)hi);
+                }
+            }
+            const bool ok = info.x >= 0 && n < p.N;
+            bf16* d = base + (size_t)info.x * row_mul;
+            gbf16x8* dh = ok ? (gbf16x8*)d : (gbf16x8*)trash;
+            gbf16x8* dl = ok ? (gbf16x8*)(d + lo_off) : (gbf16x8*)trash;
+            if (p.debug & 1) {
+                asm volatile("" ::"v"(hv), "v"(lv), "v"(dh), "v"(dl));
+                continue;
+            }
+            *dh = hv;
+            if constexpr (PLANES == 2) *dl = lv;
+        }
+    }
+}
+
+// Whole wave tile (FM x FN fragments at tile rows wrow0.., columns ncol0..) through the direct epilogue.
+template <int PLANES, int FM, int FN>
+__device__ __forceinline__ void epilogue_direct_tile(const GemmParams& p, const f32x4 (&acc)[FM][FN], const int4* tab, int wrow0, int ncol0, int lane) {
+    static_assert(FM % 4 == 0 && FN % 2 == 0, "wave tile must be a multiple of the 64x32 piece");
+    constexpr int PJ = FN / 2, NPIECE = (FM / 4) * PJ;
+    epilogue_direct<PLANES, NPIECE>(
+        p, [&](int pi, int i, int j) { return acc[(pi / PJ) * 4 + i][(pi % PJ) * 2 + j]; }, [&](int pi) { return wrow0 + (pi / PJ) * 64; },
+        [&](int pi) { return ncol0 + (pi % PJ) * 32; }, tab, lane);
+}
+
 // Whole wave tile (FM x FN fragments at tile rows wrow0.., columns ncol0..) through the staged epilogue.
 template <int PLANES, int FM, int FN, int FUSE>
 __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4 (&acc)[FM][FN], char* wlds, const int4* tab, int wrow0,

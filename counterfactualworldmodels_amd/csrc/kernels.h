@@ -67,6 +67,7 @@ struct GemmParams {
     float* sk2_slabs;        // [tiles * splitk][128 * 128] fp32 partial accumulators
     unsigned* sk2_count;     // [tiles] arrival counters (0 between launches)
     int staged;  // set by launch_gemm: epilogue through LDS with full-line global accesses (gemm.hip)
+    int direct;  // set by launch_gemm: 16-byte stores straight from the accumulators, W tile staged with permuted rows (gemm_device.h epilogue_direct)
     int overlapped;  // set by the engine: the launch runs beside another lane's kernels, so a partly filled last round of workgroups is not lost
     int debug;  // development ablations (cwm_debug_set "gemm_debug"): bit 0 skip the epilogue's global stores, bit 1 skip the epilogue
 };
@@ -84,6 +85,7 @@ int sk_error_flag();
 int gemm_prof_dump();  // builds with -DCWM_GEMM_PROF: per-workgroup timers of gemm8p_kernel -> /tmp/gemm_blocks.bin
 extern int g_gemm_debug;
 extern int g_gemm_staged;
+extern int g_gemm_direct;
 extern int g_gemm_tile;    // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256 output tile, 4: 256x256 8-phase, 5: persistent stream-K 8-phase
 
 struct AttnParams {

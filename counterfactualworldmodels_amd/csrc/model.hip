@@ -663,6 +663,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
         g_gemm_staged = value;
         return CWM_OK;
     }
+    if (!strcmp(key, "gemm_direct")) {
+        g_gemm_direct = value;
+        return CWM_OK;
+    }
     if (!strcmp(key, "gemm_debug")) {
         g_gemm_debug = value;
         return CWM_OK;
@@ -700,8 +704,8 @@ extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters,
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = Kp; p.W = W;
     p.M = M; p.N = N; p.K = Kp; p.bias = bias;
-    if (epi == 1) {
-        p.epi = EPI_BF16_GELU; p.out_hi = G; p.ldo = N;
+    if (epi == 1 || epi == 2) {
+        p.epi = epi == 1 ? EPI_BF16_GELU : EPI_BF16; p.out_hi = G; p.ldo = N;
     } else if (epi == 3) {
         CWM_REQUIRE(N % 192 == 0, "cwm_bench_gemm: QKV epilogue needs N = 3*64*heads");
         const int D = N / 3, H = D / 64, n_tok = 792 <= M && M % 792 == 0 ? 792 : M, B = M / n_tok;

@@ -268,11 +268,12 @@ def test_gemm_deep_ring_and_split_k_small_launches(gu):
         _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
 
 
-@pytest.mark.parametrize("tile", [1, 3, 4])
-def test_gemm_staged_epilogue_is_bitwise_equal_to_direct(gu, tile):
-    """The LDS-staged epilogue (row table + 64x32 pieces written back as full row segments) only re-routes the stores:
-    outputs must be bit-identical to the per-fragment epilogue, for fp32 (+bias, +residual), GELU and plain outputs,
-    ragged M / N and both modes."""
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+def test_gemm_epilogue_forms_are_bitwise_equal(gu, tile):
+    """The three epilogue forms only re-route the stores: the per-fragment form of round 1 (`gemm_staged` 0), the LDS-staged form (row
+    table + 64x32 pieces written back as full row segments; `gemm_direct` 0) and the direct form (16-byte stores straight from the
+    accumulators, W tile staged with permuted rows; `gemm_direct` 1 = bf16 outputs only, the default, 2 = fp32 outputs too) must give
+    bit-identical outputs, for fp32 (+bias, +residual), GELU and plain outputs, ragged M / N and both modes."""
     lib = _lib.get_lib()
     cases = [(300, 272, 128), (1000, 1152, 192), (77, 48, 512), (513, 400, 384), (2049, 768, 768)]
     try:
@@ -281,15 +282,18 @@ def test_gemm_staged_epilogue_is_bitwise_equal_to_direct(gu, tile):
             for (M, N, K) in cases:
                 a, w, b, r = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23), rnd(M, N, seed=24)
                 outs = []
-                for staged in (0, 1):
+                for staged, direct in ((0, 0), (1, 0), (1, 1), (1, 2)):
                     _lib.check(lib.cwm_debug_set(b"gemm_staged", staged))
+                    _lib.check(lib.cwm_debug_set(b"gemm_direct", direct))
                     outs.append((gu.linear(a, w, b, mode=mode), gu.linear(a, w, b, resid=r, mode=mode), gu.linear(a, w, b, gelu=True, mode=mode),
                                  gu.linear(a, w, None, mode=mode)))
-                for o0, o1 in zip(*outs):
-                    assert torch.equal(o0, o1), (tile, mode, M, N, K)
+                for other in outs[1:]:
+                    for o0, o1 in zip(outs[0], other):
+                        assert torch.equal(o0, o1), (tile, mode, M, N, K)
                 assert (outs[1][1] - (F.linear(a, w, b) + r)).abs().max().item() <= TOL[mode]
     finally:
         _lib.check(lib.cwm_debug_set(b"gemm_staged", 1))
+        _lib.check(lib.cwm_debug_set(b"gemm_direct", 1))
         _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
 
 

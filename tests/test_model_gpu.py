@@ -224,7 +224,7 @@ def test_weight_edits_are_detected_without_walking_the_state_dict():
 
 
 def test_qkv_epilogue_variants_agree_end_to_end():
-    """Direct vs LDS-staged GEMM epilogues (QKV head scatter included) and every tile configuration: same forward output,
+    """Direct, LDS-staged and per-fragment GEMM epilogues (QKV head scatter included) and every tile configuration: same forward output,
     bit for bit (all of them apply the same product sequence to every accumulator)."""
     g = np.load(os.path.join(GOLDEN, "tiny_8x8_k4.npz"))
     seed, x, mask = case_inputs(g, TINY)
@@ -236,20 +236,22 @@ def test_qkv_epilogue_variants_agree_end_to_end():
         for mode in ("parity", "fast"):
             m = build(TINY, seed, mode=mode)
             G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
-            for staged in (1, 0):
+            for staged, direct in ((1, 1), (1, 0), (0, 0), (1, 2)):
                 for tile in (0, 1, 3, 4):
                     _lib.check(lib.cwm_debug_set(b"gemm_staged", staged))
+                    _lib.check(lib.cwm_debug_set(b"gemm_direct", direct))
                     _lib.check(lib.cwm_debug_set(b"gemm_tile", tile))
-                    outs[(mode, staged, tile)] = m(G._preprocess(x.cuda()), mask.cuda()).cpu()
-            ref = outs[(mode, 1, 0)]
+                    outs[(mode, staged * 10 + direct, tile)] = m(G._preprocess(x.cuda()), mask.cuda()).cpu()
+            ref = outs[(mode, 11, 0)]
             for key, y in outs.items():
                 if key[0] == mode:
                     assert torch.equal(y, ref), key
     finally:
         _lib.check(lib.cwm_debug_set(b"gemm_staged", 1))
+        _lib.check(lib.cwm_debug_set(b"gemm_direct", 1))
         _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
         _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
-    assert np.abs(outs[("parity", 1, 0)].numpy() - g["y_tokens"]).max() <= 2e-4
+    assert np.abs(outs[("parity", 11, 0)].numpy() - g["y_tokens"]).max() <= 2e-4
 
 
 @pytest.mark.parametrize("name,cfg_name", [("tiny_8x8_k4.npz", None), ("base8_k8_b2.npz", "base_8x8patch_2frames_1tube")])
