@@ -10,7 +10,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcwm_hip.so")
-SOURCES = ["gemm.hip", "gemm_sk.hip", "attention.hip", "attention_pipe.hip", "elementwise.hip", "conj_kernels.hip", "conj_attention.hip", "flowstats.hip", "engine.hip", "model.hip",
+SOURCES = ["gemm.hip", "attention.hip", "attention_pipe.hip", "elementwise.hip", "conj_kernels.hip", "conj_attention.hip", "flowstats.hip", "engine.hip", "model.hip",
            "conj_model.hip", "comm.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_device.h", "attention_device.h", "attention_tail.h", "engine.h", os.path.join("..", "..", "include", "cwm_hip.h")]
 

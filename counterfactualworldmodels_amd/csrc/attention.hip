@@ -277,288 +277,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 8-wave form: two 128-query blocks of one (batch, head) per workgroup, the two wave groups one barrier apart.
-//
-// In the kernel above the four waves of a workgroup run in lockstep (one barrier per key tile) and the second workgroup
-// of the CU drifts at a random phase, so on every SIMD the two resident waves often sit in their MFMA segments together
-// (half rate each) and then in their softmax segments together (matrix pipe idle): MFMA busy stays near 40 %.  Here a
-// key tile is four barrier-separated phases per wave,
-//     a: S^T = K Q^T (MFMA)     b: online softmax + P conversion (VALU)     c: O^T += V^T P^T (MFMA)     d: stage K(t+2)
-// and waves 4-7 run one barrier behind waves 0-3 (wave w and w + 4 share a SIMD), so every interval pairs one wave's
-// MFMA phase with the other's VALU / staging phase:   (a | d)  (b | a)  (c | b)  (d | c).
-// K / V tiles (64 keys) go global -> LDS by LDS-DMA (no staging registers or ds_write pass; the XOR swizzles are applied to
-// the per-lane source address), two slots each:
-//     a(t): wait V(t) landed, issue V(t+1)   ...   c(t): wait K(t+1) landed   ...   d(t): issue K(t+2)
-// Every wait precedes a barrier that precedes the first read (of either group) of the tile it retires, and every slot is
-// re-staged at least one barrier after its last read by the lagging group.  Per-wave arithmetic (MFMA order, softmax) is
-// exactly that of attention_kernel, so the outputs are bit-identical (tests/test_kernels_gpu.py).
-template <int PLANES>
-__global__ __launch_bounds__(512, 2) void attention8_kernel(const AttnParams p) {
-    constexpr int TILE_BYTES = 64 * 64 * 2;         // one 64x64 bf16 tile
-    constexpr int SLOT_BYTES = TILE_BYTES * PLANES;  // hi [, lo] planes of one K or V tile
-    constexpr int V_BASE = 2 * SLOT_BYTES;           // LDS: 2 K slots, then 2 V slots
-    constexpr int NP = PLANES;                       // 1-KiB LDS-DMA pieces per wave, tile and operand
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void gbl_void;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int qcol = lane & 31, hh = lane >> 5;
-    const int N = p.n_tok;
-    const int bh = blockIdx.y;
-    const int b = bh / p.heads, h = bh - b * p.heads;
-    const int q0 = (blockIdx.x * 2 + grp) * 128 + (wave & 3) * 32;
-    const int NQ = p.n_q > 0 ? p.n_q : N;
-    const bool active = q0 < NQ;  // idle waves (query rows past the end) only stage tiles and keep the barrier count
-
-    const bf16* Qb = p.q + (size_t)bh * N * 64;
-    const bf16* Kb = p.k + (size_t)bh * N * 64;
-    const bf16* Vb = p.v + (size_t)bh * N * 64;
-
-    bf16x8 qf[PLANES][4];
-    {
-        const int qrow = p.q_off + min(q0 + qcol, NQ - 1);
-#pragma unroll
-        for (int pl = 0; pl < PLANES; ++pl)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                qf[pl][s] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)pl * p.qk_plane + (size_t)qrow * 64 + s * 16 + hh * 8);
-    }
-
-    // ---- LDS-DMA bookkeeping: piece = 8 key rows x 128 B; lane l lands at chunk l % 8 of row l / 8 ----
-    int st_row[NP], st_lds[NP], st_kchunk[NP], st_vchunk[NP];
-    const bf16 *st_kp[NP], *st_vp[NP];
-#pragma unroll
-    for (int jj = 0; jj < NP; ++jj) {
-        const int pi = wave * NP + jj, plane = pi >> 3, pc = pi & 7;
-        const int r = pc * 8 + (lane >> 3);
-        st_row[jj] = r;
-        st_lds[jj] = plane * TILE_BYTES + pc * 1024;
-        st_kchunk[jj] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;         // K image: chunk c of row r at c ^ ((r >> 1) & 7)
-        st_vchunk[jj] = ((lane & 7) ^ (((r >> 1) & 1) << 2)) * 8;  // V image: lds_off_v
-        st_kp[jj] = Kb + (size_t)plane * p.qk_plane;
-        st_vp[jj] = Vb + (size_t)plane * p.qk_plane;
-    }
-    auto stage_k = [&](int kt) {
-#pragma unroll
-        for (int jj = 0; jj < NP; ++jj) {
-            const int key = min(kt * 64 + st_row[jj], N - 1);  // rows past the end re-read the last key (P is exactly 0 there)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(st_kp[jj] + (size_t)key * 64 + st_kchunk[jj]),
-                                             (lds_void*)(smem + (kt & 1) * SLOT_BYTES + st_lds[jj]), 16, 0, 0);
-        }
-    };
-    auto stage_v = [&](int kt) {
-#pragma unroll
-        for (int jj = 0; jj < NP; ++jj) {
-            const int key = min(kt * 64 + st_row[jj], N - 1);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(st_vp[jj] + (size_t)key * 64 + st_vchunk[jj]),
-                                             (lds_void*)(smem + V_BASE + (kt & 1) * SLOT_BYTES + st_lds[jj]), 16, 0, 0);
-        }
-    };
-
-    int k_off[2][4];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) k_off[kb][s] = lds_off128(kb * 32 + qcol, 2 * s + hh);
-    int v_base[2];
-    {
-        const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
-#pragma unroll
-        for (int db = 0; db < 2; ++db) v_base[db] = lds_off_v(4 * (g >> 1) + q, db * 4 + (g & 1) * 2 + (pc >> 1)) + (pc & 1) * 8;
-    }
-
-    f32x16 oacc[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
-    const float kLog2e = 1.4426950408889634f;
-
-#define CWM_ATTN_BARRIER()                 \
-    do {                                   \
-        __builtin_amdgcn_sched_barrier(0); \
-        __builtin_amdgcn_s_barrier();      \
-        __builtin_amdgcn_sched_barrier(0); \
-    } while (0)
-#define CWM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-
-    const int nkt = (N + 63) / 64;
-    stage_k(0);
-    stage_v(0);
-    if (nkt > 1) {
-        stage_k(1);
-        CWM_WAIT_VMCNT(2 * NP);  // K(0) landed; V(0), K(1) in flight
-    } else {
-        CWM_WAIT_VMCNT(NP);
-    }
-    CWM_ATTN_BARRIER();
-    if (grp == 1) CWM_ATTN_BARRIER();  // waves 4-7 run one barrier behind waves 0-3
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const char* kbase = smem + (kt & 1) * SLOT_BYTES;
-        const char* vbase = smem + V_BASE + (kt & 1) * SLOT_BYTES;
-        const bool more = kt + 1 < nkt;
-        // ---- a: V(kt) landed (in flight behind it: K(kt+1)); issue V(kt+1); S^T = K Q^T ----
-        if (more) {
-            CWM_WAIT_VMCNT(NP);
-            stage_v(kt + 1);
-        } else {
-            CWM_WAIT_VMCNT(0);
-        }
-        f32x16 sacc[2];
-        if (active) {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase + k_off[kb][s]);
-                    if constexpr (PLANES == 2) {
-                        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kbase + TILE_BYTES + k_off[kb][s]);
-                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][s], sacc[kb], 0, 0, 0);
-                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sacc[kb], 0, 0, 0);
-                    }
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sacc[kb], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-        }
-        CWM_ATTN_BARRIER();
-        // ---- b: online softmax, P -> bf16 (hi, lo) ----
-        bf16x8 ph[4], plo[4];
-        if (active) {
-            if (!more && (N & 63)) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        if (key >= N) sacc[kb][r] = -INFINITY;
-                    }
-            }
-            float mx = sacc[0][0];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-            mx = max_lane_xor32(mx);
-            const float m_new = fmaxf(m_run, mx);
-            const bool grew = __any(m_new > m_run);
-            const float alpha = grew ? __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e) : 1.0f;
-            m_run = m_new;
-            const float mc = m_new * kLog2e;
-            float rowsum = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], kLog2e, -mc));
-                    sacc[kb][r] = pv;
-                    rowsum += pv;
-                }
-            l_run = l_run * alpha + rowsum;
-            if (grew) {
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float pv = sacc[ks >> 1][8 * (ks & 1) + j];
-                    const bf16 hi = (bf16)pv;
-                    ph[ks][j] = hi;
-                    if constexpr (PLANES == 2) plo[ks][j] = (bf16)(pv - (float)hi);
-                }
-            }
-        }
-        CWM_ATTN_BARRIER();
-        // ---- c: O^T += V^T P^T; then K(kt+1) landed (in flight behind it: V(kt+1)) ----
-        // The transposed reads are issued as inline asm: behind the builtin hipcc waits vmcnt(0) (it cannot tell the LDS-DMA
-        // in flight from the tile being read), which would drain the K / V prefetch in every tile.  Fragments of k-step
-        // ks + 1 are requested before the MFMAs of k-step ks; LDS returns in order, so a counted lgkmcnt retires ks.
-        if (active) {
-            constexpr int NRD = 4 * PLANES;  // reads per k-step: 2 d-blocks x planes x 2 halves
-            u32x2 vr0[2][PLANES][2], vr1[2][PLANES][2];
-            const unsigned va0 = (unsigned)(size_t)(lds_void*)(vbase + v_base[0]), va1 = (unsigned)(size_t)(lds_void*)(vbase + v_base[1]);
-#define CWM_PV_STEP(KS, VR)                                                                                                          \
-    do {                                                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                                           \
-        _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                                           \
-            const bf16x8 vf = __builtin_shufflevector(__builtin_bit_cast(bf16x4, VR[db][0][0]), __builtin_bit_cast(bf16x4, VR[db][0][1]), 0, 1, \
-                                                      2, 3, 4, 5, 6, 7);                                                             \
-            if constexpr (PLANES == 2) {                                                                                             \
-                const bf16x8 vl = __builtin_shufflevector(__builtin_bit_cast(bf16x4, VR[db][PLANES - 1][0]),                         \
-                                                          __builtin_bit_cast(bf16x4, VR[db][PLANES - 1][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[KS], oacc[db], 0, 0, 0);                                   \
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, plo[KS], oacc[db], 0, 0, 0);                                  \
-            }                                                                                                                        \
-            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph[KS], oacc[db], 0, 0, 0);                                       \
-        }                                                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                                           \
-    } while (0)
-            __builtin_amdgcn_s_setprio(1);
-            lds_read_v_step<0, PLANES>(vr0, va0, va1);
-            lds_read_v_step<1, PLANES>(vr1, va0, va1);
-            lds_wait_v_step<NRD, PLANES>(vr0);
-            CWM_PV_STEP(0, vr0);
-            lds_read_v_step<2, PLANES>(vr0, va0, va1);
-            lds_wait_v_step<NRD, PLANES>(vr1);
-            CWM_PV_STEP(1, vr1);
-            lds_read_v_step<3, PLANES>(vr1, va0, va1);
-            lds_wait_v_step<NRD, PLANES>(vr0);
-            CWM_PV_STEP(2, vr0);
-            lds_wait_v_step<0, PLANES>(vr1);
-            CWM_PV_STEP(3, vr1);
-#undef CWM_PV_STEP
-            __builtin_amdgcn_s_setprio(0);
-        }
-        if (more) CWM_WAIT_VMCNT(NP);
-        CWM_ATTN_BARRIER();
-        // ---- d: K(kt+2) into the slot K(kt) has left ----
-        if (kt + 2 < nkt) stage_k(kt + 2);
-        CWM_ATTN_BARRIER();
-    }
-    if (grp == 0) CWM_ATTN_BARRIER();  // balance the stagger barrier
-#undef CWM_ATTN_BARRIER
-#undef CWM_WAIT_VMCNT
-
-    // ---- normalise and store O[q][h*64 + d] ----------------------------------------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int q = q0 + qcol;
-    if (q < NQ) {
-        const int64_t orow = (int64_t)b * NQ + q;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 hi4, lo4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = oacc[db][4 * g + e] * inv;
-                    const bf16 hi = (bf16)v;
-                    hi4[e] = hi;
-                    if constexpr (PLANES == 2) lo4[e] = (bf16)(v - (float)hi);
-                }
-                const int d0 = db * 32 + 8 * g + 4 * hh;
-                bf16* dst = p.o + a_pos<PLANES>(orow, p.ldo, h * 64 + d0);  // GEMM A-operand layout (common.h)
-                *reinterpret_cast<bf16x4*>(dst) = hi4;
-                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + kLoOffset) = lo4;
-            }
-    }
-}
-
-int g_attn_kernel = 0;  // 0 auto, 1: 4-wave kernel, 2: 8-wave staggered kernel, 3: software-pipelined kernel (attention_pipe.hip)
+int g_attn_kernel = 0;  // 0 auto, 1: 4-wave kernel (this file), 3: software-pipelined kernel (attention_pipe.hip)
 
 int g_attn_remap = 1;
 int g_attn_tail = 1;
@@ -580,22 +299,11 @@ int launch_attention(const AttnParams& p_in, int planes, hipStream_t stream) {
     //     are ~70 % busy;
     //   fast mode: one MFMA per product leaves the loop VALU-bound: kernel 1 is 1-5 % ahead on the B/8 sequences (792, 1568 tokens),
     //     kernel 3 2-4 % ahead on the L/4 ones (3168, 6272) -> by sequence length;
-    //   the staggered 8-wave kernel (2) ties kernel 1 in parity mode and loses 25-35 % in fast mode.
-    // All three produce bit-identical outputs (tests/test_kernels_gpu.py); cwm_debug_set "attn_kernel" forces one.
+    //   (a staggered 8-wave kernel, "2", tied kernel 1 in parity mode and lost 25-35 % in fast mode: removed in round 4).
+    // Both produce bit-identical outputs (tests/test_kernels_gpu.py); cwm_debug_set "attn_kernel" forces one.
     const int kern = g_attn_kernel ? g_attn_kernel : ((planes == 2 || p.n_tok >= 2048) ? 3 : 1);
     if (kern == 3) return launch_attention_pipe(p, planes, stream);
-    if (kern == 2) {
-        const dim3 grid((nqb + 1) / 2, p.batch * p.heads);
-        const size_t smem = (size_t)4 * (64 * 64 * 2) * planes;  // 2 K slots + 2 V slots
-        if (planes == 1) {
-            hipLaunchKernelGGL(attention8_kernel<1>, grid, dim3(512), smem, stream, p);
-        } else {
-            if (int rc = cwm_set_max_lds((const void*)attention8_kernel<2>, (int)smem)) return rc;
-            hipLaunchKernelGGL(attention8_kernel<2>, grid, dim3(512), smem, stream, p);
-        }
-        CWM_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
+    CWM_REQUIRE(kern == 1, "attention: unknown kernel %d (1: 4-wave, 3: software-pipelined)", kern);
     const dim3 grid(nqb, p.batch * p.heads);
     const size_t smem = (size_t)2 * (64 * 64 * 2) * 2 * planes;
     if (planes == 1) {

@@ -42,7 +42,7 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* ptr) {
 }
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-// ds_read_b64_tr_b16 as inline asm (see attention8_kernel, phase c); OFF = immediate byte offset
+// ds_read_b64_tr_b16 as inline asm (attention.hip / attention_pipe.hip, the P V phase); OFF = immediate byte offset
 template <int OFF>
 __device__ __forceinline__ u32x2 lds_read_tr16_asm(unsigned addr) {
     u32x2 v;

@@ -192,7 +192,9 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
                 mc = m_new * kLog2e;
                 // (rescale here, not between the phases: a branch there lets LLVM sink every exponential below it, out of
                 // the MFMA shadow)
-                if (grew) {
+                // (the last tile has no MFMA slots to protect and the branch made hipcc keep a second copy of the 32 accumulator registers
+                // alive across it -- 5 dwords of scratch: there the multiplication is unconditional, alpha = 1.0f exactly when nothing grew)
+                if (!HAS_NEXT || grew) {
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -397,12 +399,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         CWM_TILE(true, sa, sb, kt, std::true_type{});
         CWM_TILE(true, sb, sa, kt + 1, std::true_type{});
     }
+    // ONE instance of the last tile: with two (S in sa after an odd count, in sb after an even one) hipcc merged the two paths through
+    // copies of the S and O accumulators and spilled around them; an even count moves its S values over instead (32 v_mov, once)
+    // ONE instance of the last tile: with two (S in sa after an odd count, in sb after an even one) hipcc merged the two paths through
+    // copies of the S and O accumulators and spilled around them (256 VGPRs + 5 dwords of scratch; now 222, none); an even count moves
+    // its S values over instead (32 v_mov, once per workgroup).  Same-box A/B: profiles/r4_ab_attention_no_spill.log (equal within noise).
     if (kt + 2 == nkt) {
         CWM_TILE(true, sa, sb, kt, std::true_type{});
-        CWM_TILE(false, sb, sa, kt + 1, std::true_type{});
-    } else {
-        CWM_TILE(false, sa, sb, kt, std::true_type{});
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) sa[kb] = sb[kb];
+        ++kt;
     }
+    CWM_TILE(false, sa, sb, kt, std::true_type{});
 #undef CWM_TILE
 #undef CWM_TILE_END
 #ifdef CWM_ATTN_PROF

@@ -220,47 +220,7 @@ int launch_patch_gather(const PatchGatherParams& p, int planes, hipStream_t stre
 // decoder input, masked half: x_full[b][n_vis + j] = mask_token + pos[perm[b][n_vis + j]]
 // (vmae.py:556-557).  The visible half is written by the encoder_to_decoder GEMM epilogue.
 // ---------------------------------------------------------------------------------------------
-template <int PLANES>
-__global__ __launch_bounds__(256) void fill_mask_tokens_kernel(float* x_full, const float* mask_token, const float* pos,
-                                                                const int* perm, int Nt, int n_vis, int D, int64_t total4, bf16* split,
-                                                                float2* stats) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = gid < total4;  // (no early return: the 8-lane sums below need every lane of a live group, and D % 32 == 0 keeps groups whole)
-    const int d4 = D / 4;
-    const int64_t row = live ? gid / d4 : 0;
-    const int c4 = live ? (int)(gid - row * d4) : 0;
-    const int nm = Nt - n_vis;
-    const int b = (int)(row / nm), j = (int)(row - (int64_t)b * nm);
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t orow = (size_t)b * Nt + n_vis + j;
-    if (live) {
-        const int tau = perm[(size_t)b * Nt + n_vis + j];
-        const float4 mt = *reinterpret_cast<const float4*>(mask_token + c4 * 4);
-        const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)tau * D + c4 * 4);
-        o = make_float4(mt.x + pe.x, mt.y + pe.y, mt.z + pe.z, mt.w + pe.w);
-        *reinterpret_cast<float4*>(x_full + orow * D + c4 * 4) = o;
-    }
-    if (split) {  // the same rows as GEMM A operand + their per-32-column (sum, sum of squares): LayerNorm folded into the next GEMM
-        const float ps = group8_sum((o.x + o.y) + (o.z + o.w));
-        const float pq = group8_sum(fmaf(o.x, o.x, o.y * o.y) + fmaf(o.z, o.z, o.w * o.w));
-        if (live) {
-            const float v[4] = {o.x, o.y, o.z, o.w};
-            bf16x4 hv, lv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bf16 hi = (bf16)v[e];
-                hv[e] = hi;
-                lv[e] = (bf16)(v[e] - (float)hi);
-            }
-            bf16* d = split + a_pos<PLANES>(orow, D, c4 * 4);
-            *reinterpret_cast<bf16x4*>(d) = hv;
-            if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(d + kLoOffset) = lv;
-            if ((c4 & 7) == 0) stats[orow * (D / 32) + (c4 >> 3)] = make_float2(ps, pq);
-        }
-    }
-}
-
-// The same rows without the LayerNorm-fold outputs (the default path): EIGHT rows per thread, all loads (perm -> positional row) issued
+// EIGHT rows per thread, all loads (perm -> positional row) issued
 // before the first store.  One row per thread ran as ~4.6 rounds of short-lived waves, each a dependent perm -> pos -> store
 // chain: 2.9 TB/s of stores (13.1 us for 38 MB, ViT-B/8 batch 32); with independent chains per thread the launch is one round.
 __global__ __launch_bounds__(256) void fill_mask_tokens4_kernel(float* x_full, const float* mask_token, const float* pos, const int* perm, int Nt,
@@ -293,25 +253,12 @@ __global__ __launch_bounds__(256) void fill_mask_tokens4_kernel(float* x_full, c
         if (live[i]) *reinterpret_cast<float4*>(x_full + orow[i] * D + c4 * 4) = make_float4(mt.x + pe[i].x, mt.y + pe[i].y, mt.z + pe[i].z, mt.w + pe[i].w);
 }
 
-int launch_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt,
-                            int n_vis, int D, hipStream_t stream, bf16* split, float2* stats, int planes) {
+int launch_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt, int n_vis, int D, hipStream_t stream) {
     CWM_REQUIRE(D % 4 == 0, "fill_mask_tokens: D must be a multiple of 4");
-    CWM_REQUIRE(!split || (stats && D % 32 == 0), "fill_mask_tokens: split rows need a stats buffer and D %% 32 == 0");
-    const int64_t total4 = (int64_t)B * (Nt - n_vis) * (D / 4);
-    if (total4 == 0) return 0;
-    if (!split) {
-        const int64_t rows = (int64_t)B * (Nt - n_vis), rows_q = (rows + 7) / 8;
-        hipLaunchKernelGGL(fill_mask_tokens4_kernel, dim3((unsigned)((rows_q * (D / 4) + 255) / 256)), dim3(256), 0, stream, x_full, mask_token, pos,
-                           perm, Nt, n_vis, D, rows, rows_q);
-        CWM_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
-    if (planes == 2)
-        hipLaunchKernelGGL(fill_mask_tokens_kernel<2>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, x_full, mask_token, pos, perm,
-                           Nt, n_vis, D, total4, split, stats);
-    else
-        hipLaunchKernelGGL(fill_mask_tokens_kernel<1>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, x_full, mask_token, pos, perm,
-                           Nt, n_vis, D, total4, split, stats);
+    const int64_t rows = (int64_t)B * (Nt - n_vis), rows_q = (rows + 7) / 8;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(fill_mask_tokens4_kernel, dim3((unsigned)((rows_q * (D / 4) + 255) / 256)), dim3(256), 0, stream, x_full, mask_token, pos, perm, Nt,
+                       n_vis, D, rows, rows_q);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }

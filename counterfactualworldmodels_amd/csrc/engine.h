@@ -25,13 +25,6 @@ struct LinearW {
     int64_t plane = 0;
     int N = 0, K = 0, Npad = 0, Kpad = 0;
     float* bias = nullptr;  // [Npad] (zero-filled) or nullptr when the layer has no bias
-    // ---- LayerNorm fold (Engine::set_fold): this linear consumes LN(x); the fused path feeds it the split of RAW x instead ----
-    const float *ln_g = nullptr, *ln_b = nullptr;  // the LayerNorm's weight / bias (device, owned by the engine); nullptr: no fold
-    float* raw = nullptr;      // [N][K] fp32 weight as loaded (kept so that the fold can be redone when any of its inputs is re-loaded)
-    bf16* wf = nullptr;        // W' = W diag(ln_g) packed like `w`
-    bf16* wf_il = nullptr;     // ... like `w_il`
-    float* colsum = nullptr;   // [2][Npad]: sum_k of the packed W' rows; [0] fast (hi only), [1] parity (hi + lo)
-    float* bias_ln = nullptr;  // [Npad] bias + W ln_b
 };
 
 struct BlockW {
@@ -68,10 +61,6 @@ struct KernelTimer {
 struct StreamBuffers {
     bf16 *hbuf = nullptr, *gbuf = nullptr, *qbuf = nullptr, *kbuf = nullptr, *vbuf = nullptr;
     float* qkv_f32 = nullptr;  // only for streams whose head_dim != 64 (small-sequence attention path)
-    // LayerNorm fold: the residual rows in A-operand layout + their per-32-column (sum, sum of squares), written by whichever kernel
-    // produced the residual stream last (nullptr: the stream runs the stand-alone LayerNorm kernel)
-    bf16* xsplit = nullptr;
-    float2* xstats = nullptr;
 };
 
 struct Engine {
@@ -81,9 +70,6 @@ struct Engine {
     std::map<std::string, Slot> slots;
     std::vector<void*> allocs;     // weights etc., freed on destroy
     std::vector<void*> ws_allocs;  // workspace, re-allocated when it has to grow
-    std::vector<LinearW*> folds;   // linears with a LayerNorm fold
-    bool fold_dirty = false;       // a state-dict tensor was (re-)loaded since the folds were computed
-    bool enable_folds = false;     // set by the model that runs the fused path BEFORE it creates its blocks (make_block)
     KernelTimer timers[CWM_KCLASS_COUNT];
     struct SplitKWs {
         float* slabs;
@@ -103,10 +89,6 @@ struct Engine {
     int free_workspace();
 
     int make_linear(LinearW& L, int N, int K, bool bias);
-    int set_fold(LinearW& L, const float* ln_g, const float* ln_b);  // L consumes LayerNorm(ln_g, ln_b): allocate the folded copies
-    int finalize_folds(hipStream_t s);                               // (re-)compute every fold if a weight changed; cheap no-op otherwise
-    // GEMM parameters of a fold consumer: A = split of the raw residual rows (lda = K), statistics from `stats`
-    GemmParams fold_gemm(const bf16* xsplit, const float2* stats, const LinearW& L, int M, int planes) const;
     int make_vec(float** v, int n);
     void add_matrix_slot(const std::string& key, LinearW* L, std::vector<int64_t> shape);
     void add_vec_slot(const std::string& key, float* dst, std::vector<int64_t> shape, int repeat = 1);
@@ -123,8 +105,7 @@ struct Engine {
     // the HBM-bound edge kernels, booked by class with their algorithmic bytes (cwm_hip.h CWM_KCLASS_*)
     int run_layernorm(const LayerNormParams& p, int planes, hipStream_t s);
     int run_patch_gather(const PatchGatherParams& p, int planes, hipStream_t s);
-    int run_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt, int n_vis, int D,
-                             hipStream_t s, bf16* split = nullptr, float2* stats = nullptr, int planes = 2);
+    int run_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt, int n_vis, int D, hipStream_t s);
     int run_unembed(const UnembedParams& p, hipStream_t s);
     // `launch()` between an event pair of class `kclass` (no events unless the class is enabled); work = FLOPs or bytes
     template <typename F>
@@ -137,8 +118,6 @@ struct Engine {
     int timer_begin(int kclass, double work, hipStream_t s, EventPair** out);
     int timer_end(EventPair* e, hipStream_t s);
     // Block.forward (VideoMAE/utils.py:146-153) on a residual stream x[B*n_tok, D] (in place), head_dim 64
-    // sb.xsplit != nullptr: LayerNorm-fold form -- on entry sb.xsplit / sb.xstats describe x (rows identical to x's), on exit the block's
-    // output rows (compact kept rows when n_keep is set); no LayerNorm launch
     int run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, StreamBuffers& sb, hipStream_t s, int n_keep = 0);
     // same for short sequences with any head_dim (fp32 VALU attention): the IMU context stream
     int run_block_small(const BlockW& w, float* x, int B, int n_tok, int D, int H, int planes, StreamBuffers& sb, hipStream_t s);

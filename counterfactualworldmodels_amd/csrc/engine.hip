@@ -105,83 +105,6 @@ int Engine::make_linear(LinearW& L, int N, int K, bool bias) {
     return 0;
 }
 
-int Engine::set_fold(LinearW& L, const float* ln_g, const float* ln_b) {
-    L.ln_g = ln_g;
-    L.ln_b = ln_b;
-    void* p;
-    if (int rc = alloc(&p, (size_t)L.N * L.K * sizeof(float), true, false)) return rc;
-    L.raw = (float*)p;
-    if (int rc = alloc(&p, (size_t)L.plane * sizeof(bf16), true, false)) return rc;
-    L.wf = (bf16*)p;
-    if (int rc = alloc(&p, (size_t)2 * L.plane * sizeof(bf16), true, false)) return rc;
-    L.wf_il = (bf16*)p;
-    if (int rc = alloc(&p, (size_t)2 * L.Npad * sizeof(float), true, false)) return rc;
-    L.colsum = (float*)p;
-    if (int rc = alloc(&p, (size_t)L.Npad * sizeof(float), true, false)) return rc;
-    L.bias_ln = (float*)p;
-    folds.push_back(&L);
-    fold_dirty = true;
-    return 0;
-}
-
-// One block per output row n: W'[n][k] = W[n][k] * g[k] packed in both operand layouts, the column sums of the PACKED values (what
-// the MFMAs will actually multiply the row mean with) and bias'[n] = bias[n] + sum_k W[n][k] b[k]; float64 accumulation.
-__global__ __launch_bounds__(256) void fold_pack_kernel(const float* raw, const float* g, const float* b, const float* bias, int N, int K,
-                                                          int Kpad, int Npad, bf16* wf, bf16* wf_il, float* colsum, float* bias_ln) {
-    const int n = blockIdx.x;
-    double s_hi = 0.0, s_il = 0.0, s_b = 0.0;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        const float w = raw[(size_t)n * K + k];
-        bf16 h, l;
-        split_bf16(w * g[k], h, l);
-        wf[(size_t)n * Kpad + k] = h;
-        bf16* d = wf_il + a_pos<2>(n, Kpad, k);
-        d[0] = h;
-        d[kLoOffset] = l;
-        s_hi += (double)(float)h;
-        s_il += (double)(float)h + (double)(float)l;
-        s_b += (double)w * (double)b[k];
-    }
-    __shared__ double red[3][256];
-    red[0][threadIdx.x] = s_hi;
-    red[1][threadIdx.x] = s_il;
-    red[2][threadIdx.x] = s_b;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            for (int i = 0; i < 3; ++i) red[i][threadIdx.x] += red[i][threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        colsum[n] = (float)red[0][0];
-        colsum[Npad + n] = (float)red[1][0];
-        bias_ln[n] = (float)(red[2][0] + (bias ? (double)bias[n] : 0.0));
-    }
-}
-
-int Engine::finalize_folds(hipStream_t s) {
-    if (!fold_dirty) return 0;
-    for (LinearW* L : folds) {
-        hipLaunchKernelGGL(fold_pack_kernel, dim3(L->N), dim3(256), 0, s, L->raw, L->ln_g, L->ln_b, L->bias, L->N, L->K, L->Kpad, L->Npad, L->wf,
-                           L->wf_il, L->colsum, L->bias_ln);
-        CWM_HIP_CHECK(hipGetLastError());
-    }
-    fold_dirty = false;
-    return 0;
-}
-
-GemmParams Engine::fold_gemm(const bf16* xsplit, const float2* stats, const LinearW& L, int M, int planes) const {
-    GemmParams p = gemm_base(xsplit, L.Kpad, L, M, planes);
-    p.W = planes == 2 ? L.wf_il : L.wf;
-    p.bias = L.bias_ln;
-    p.ln_stats = stats;
-    p.ln_np = L.K / 32;
-    p.ln_colsum = L.colsum + (planes == 2 ? L.Npad : 0);
-    p.ln_inv_d = 1.0f / (float)L.K;
-    p.ln_eps = ln_eps;
-    return p;
-}
-
 int Engine::make_vec(float** v, int n) {
     void* p;
     if (int rc = alloc(&p, (size_t)n * sizeof(float), true, false)) return rc;
@@ -225,9 +148,6 @@ int Engine::make_block(BlockW& b, const std::string& pre, int D, int hidden) {
     if ((rc = make_linear(b.qkv, 3 * D, D, true)) || (rc = make_linear(b.proj, D, D, true)) || (rc = make_linear(b.fc1, hidden, D, true)) ||
         (rc = make_linear(b.fc2, D, hidden, true)))
         return rc;
-    if (enable_folds && D % 64 == 0) {  // (the fold's statistics are kept per 32-column slice; K == Kpad so that the split rows are the A operand as they are)
-        if ((rc = set_fold(b.qkv, b.ln1_g, b.ln1_b)) || (rc = set_fold(b.fc1, b.ln2_g, b.ln2_b))) return rc;
-    }
     add_vec_slot(pre + "norm1.weight", b.ln1_g, {D});
     add_vec_slot(pre + "norm1.bias", b.ln1_b, {D});
     add_vec_slot(pre + "norm2.weight", b.ln2_g, {D});
@@ -306,14 +226,6 @@ int Engine::load_weight(const char* key, const float* data, int on_device, const
             src = tmp;
         }
         const int64_t total = (int64_t)L.Npad * L.Kpad;
-        if (L.raw) {
-            hipError_t ce = hipMemcpyAsync(L.raw, src, (size_t)s.numel * sizeof(float), hipMemcpyDeviceToDevice, 0);
-            if (ce != hipSuccess) {
-                if (tmp) (void)hipFree(tmp);
-                cwm_set_error("hipMemcpy failed: %s", hipGetErrorString(ce));
-                return CWM_ERR_HIP;
-            }
-        }
         hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, src, L.N, L.K, L.w, L.w_il, L.Npad,
                            L.Kpad);
         hipError_t e = hipDeviceSynchronize();
@@ -324,7 +236,6 @@ int Engine::load_weight(const char* key, const float* data, int on_device, const
         }
     }
     s.loaded = true;
-    fold_dirty = true;  // a LayerNorm vector, a bias or a matrix of some fold may have changed
     return CWM_OK;
 }
 
@@ -392,7 +303,7 @@ int Engine::run_gemm(const GemmParams& p_in, int planes, hipStream_t s) {
     for (int i = 0; i < nparts; ++i) {
         EventPair* e;
         if (int rc = timer_begin(CWM_KCLASS_GEMM, 2.0 * part[i].M * (double)part[i].N * part[i].K, s, &e)) return rc;
-        if (e) e->sub = (cfgs[i] >= 3 && cfgs[i] != 6) ? CWM_KCLASS_GEMM_WIDE : CWM_KCLASS_GEMM_NARROW;
+        if (e) e->sub = (cfgs[i] == 3 || cfgs[i] == 4) ? CWM_KCLASS_GEMM_WIDE : CWM_KCLASS_GEMM_NARROW;
         if (int rc = (nparts == 2 ? launch_gemm_tile(part[i], planes, cfgs[i], s) : launch_gemm(part[i], planes, s))) return rc;
         if (int rc = timer_end(e, s)) return rc;
     }
@@ -416,9 +327,9 @@ int Engine::run_patch_gather(const PatchGatherParams& p, int planes, hipStream_t
 }
 
 int Engine::run_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt, int n_vis, int D,
-                                 hipStream_t s, bf16* split, float2* stats, int planes) {
+                                 hipStream_t s) {
     return timed(CWM_KCLASS_FILL_MASK, (double)B * (Nt - n_vis) * D * 4.0, s,
-                 [&] { return launch_fill_mask_tokens(x_full, mask_token, pos, perm, B, Nt, n_vis, D, s, split, stats, planes); });
+                 [&] { return launch_fill_mask_tokens(x_full, mask_token, pos, perm, B, Nt, n_vis, D, s); });
 }
 
 int Engine::run_unembed(const UnembedParams& p, hipStream_t s) {
@@ -486,15 +397,14 @@ int Engine::run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H,
     const int hidden = w.fc1.N;
     const bool part = n_keep > 0 && n_keep < n_tok;
     const int n_out = part ? n_keep : n_tok, Mo = B * n_out, first = n_tok - n_out;
-    const bool fold = sb.xsplit != nullptr && w.qkv.raw != nullptr;  // LayerNorm folded into qkv / fc1
     int rc;
     LayerNormParams ln;
     memset(&ln, 0, sizeof(ln));
     ln.x = x; ln.ldx = D; ln.gamma = w.ln1_g; ln.beta = w.ln1_b; ln.eps = ln_eps; ln.D = D; ln.rows = M;
     ln.out = sb.hbuf; ln.out_plane = hplane; ln.ldo = D;
-    if (!fold && (rc = run_layernorm(ln, planes, s))) return rc;
+    if ((rc = run_layernorm(ln, planes, s))) return rc;
 
-    GemmParams g = fold ? fold_gemm(sb.xsplit, sb.xstats, w.qkv, M, planes) : gemm_base(sb.hbuf, D, w.qkv, M, planes);
+    GemmParams g = gemm_base(sb.hbuf, D, w.qkv, M, planes);
     g.epi = EPI_QKV;
     g.rows_in = n_tok; g.rows_out = n_tok; g.map_stride = n_tok;
     g.q_out = sb.qbuf; g.k_out = sb.kbuf; g.v_out = sb.vbuf;
@@ -510,22 +420,19 @@ int Engine::run_block(const BlockW& w, float* x, int B, int n_tok, int D, int H,
     if (part) { a.q_off = first; a.n_q = n_out; }
     if ((rc = run_attention(a, planes, s))) return rc;
 
-    // the two residual GEMMs: with the fold they also emit their output rows in A-operand layout + the rows' partial statistics
+    // the two residual GEMMs
     auto residual = [&](GemmParams& r) {
         r.epi = EPI_F32; r.C = x; r.ldc = D; r.resid = x; r.ldr = D;
         if (part) { r.rows_in = n_out; r.rows_out = n_tok; r.out_row_offset = first; }
-        if (fold) { r.split_out = sb.xsplit; r.split_ld = D; r.stats_out = sb.xstats; r.split_rows_per_b = n_out; }
     };
     g = gemm_base(sb.hbuf, D, w.proj, Mo, planes);
     residual(g);
     if ((rc = run_gemm(g, planes, s))) return rc;
 
-    if (!fold) {
-        ln.gamma = w.ln2_g; ln.beta = w.ln2_b;
-        if (part) { ln.rows = Mo; ln.rows_out_per_b = n_out; ln.rows_in_per_b = n_tok; ln.in_offset = first; ln.out_plane = (int64_t)Mo * D; }
-        if ((rc = run_layernorm(ln, planes, s))) return rc;
-    }
-    g = fold ? fold_gemm(sb.xsplit, sb.xstats, w.fc1, Mo, planes) : gemm_base(sb.hbuf, D, w.fc1, Mo, planes);
+    ln.gamma = w.ln2_g; ln.beta = w.ln2_b;
+    if (part) { ln.rows = Mo; ln.rows_out_per_b = n_out; ln.rows_in_per_b = n_tok; ln.in_offset = first; ln.out_plane = (int64_t)Mo * D; }
+    if ((rc = run_layernorm(ln, planes, s))) return rc;
+    g = gemm_base(sb.hbuf, D, w.fc1, Mo, planes);
     g.epi = EPI_BF16_GELU; g.out_hi = sb.gbuf; g.out_plane = (int64_t)Mo * hidden; g.ldo = hidden;
     if ((rc = run_gemm(g, planes, s))) return rc;
 

@@ -4,7 +4,7 @@
 // fc1/fc2, :93 qkv, :119 proj; vmae.py:547 encoder_to_decoder, :251 head; the Conv3d patch embed of
 // VideoMAE/utils.py:174-197 expressed as an im2col GEMM).
 //
-// Kernels in this file (launch_gemm picks per shape, gemm_choose_tile; gemm_sk.hip holds a persistent stream-K form):
+// Kernels in this file (launch_gemm picks per shape, gemm_choose_tile):
 //   gemm_bf16_kernel<PLANES, BM, BN, WM, WN>  one barrier + vmcnt(0) per K tile, 2-stage LDS ring; used as 128x128 / 256 threads
 //                                            with two workgroups per CU for narrow outputs (N <= 768) and remainders
 //   gemm8p_kernel<PLANES>                     256x256 / 512 threads, 8-phase main loop (staggered wave groups, LDS-DMA in flight
@@ -69,7 +69,7 @@ int gemm_prof_dump() { return -1; }
 //   256x256, 2x4 waves (128x64 per wave) : 128 KiB LDS, one 512-thread workgroup / CU -- highest FLOP per staged byte
 // The LDS fill (LDS-DMA pieces of 8 rows x 128 B) is the scarce resource (~25 B/clk/CU measured), so bigger
 // tiles raise the MFMA ceiling: per K tile a workgroup stages (BM+BN)*128 B and runs BM*BN/256*{2|3} MFMAs.
-template <int PLANES, int BM, int BN, int WM, int WN, int STAGES = 2, int FUSE = 0>
+template <int PLANES, int BM, int BN, int WM, int WN, int STAGES = 2>
 __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN == 8 && STAGES == 2) ? 4 : 2) void gemm_bf16_kernel(const GemmParams p) {
     GEMM_PROF_BEGIN();
     constexpr int NWAVES = WM * WN;
@@ -88,6 +88,11 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN ==
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
+    // split-K workspace: loaded VALUES of the two adjacent pointer fields (hipcc otherwise indexes the kernel-argument struct
+    // dynamically and keeps a copy of it in scratch -- the same hazard as qkv_out_base, gemm_device.h)
+    float* sk_slabs = p.sk2_slabs;
+    unsigned* sk_count = p.sk2_count;
+    if constexpr (STAGES > 2) asm volatile("" : "+s"(sk_slabs), "+s"(sk_count));
 
     // ---- tile selection: XCD chunking + GROUP_M-grouped order --------------------------------
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN ==
     }
     // direct epilogue with bf16 outputs: the W rows of every 32-row group are staged in permuted order, so that a lane's two column
     // fragments are 8 consecutive output columns (gemm_device.h, epilogue_direct)
-    const bool wperm = FUSE == 0 && p.direct && p.epi != EPI_F32;
+    const bool wperm = p.direct && p.epi != EPI_F32;
 #pragma unroll
     for (int jj = 0; jj < NIB; ++jj) {
         const int row = (wave * NIB + jj) * 8 + lane / 8;
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN ==
             // Hand-off (MI355X guide, Guideline 16): plain stores -> every storing wave's vmcnt(0) -> workgroup barrier -> one lane:
             // agent-scope release, returning agent-scope atomic add; last part: agent-scope acquire, vmcnt(0), barrier, plain loads.
             const int tile_id = (int)blockIdx.x / nsplit;
-            float* slab = p.sk2_slabs + ((size_t)tile_id * nsplit + part) * (BM * BN) + (size_t)wave * (FM * FN * 256) + lane * 4;
+            float* slab = sk_slabs + ((size_t)tile_id * nsplit + part) * (BM * BN) + (size_t)wave * (FM * FN * 256) + lane * 4;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -248,18 +253,18 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN ==
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned prev = __hip_atomic_fetch_add(p.sk2_count + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned prev = __hip_atomic_fetch_add(sk_count + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool last = prev == (unsigned)(nsplit - 1);
                 if (last) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(p.sk2_count + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                    __hip_atomic_store(sk_count + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
                 }
                 *flag = last ? 1 : 0;
             }
             __syncthreads();
             if (*flag == 0) return;
-            const float* base_slab = p.sk2_slabs + (size_t)tile_id * nsplit * (BM * BN) + (size_t)wave * (FM * FN * 256) + lane * 4;
+            const float* base_slab = sk_slabs + (size_t)tile_id * nsplit * (BM * BN) + (size_t)wave * (FM * FN * 256) + lane * 4;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -273,23 +278,18 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN ==
             }
         }
     }
-    if constexpr (FUSE == 0) {
-        if (p.direct) {
-            __syncthreads();  // every wave is done with the operand tiles: the row table takes their place
-            int4* tab = reinterpret_cast<int4*>(smem);
-            epilogue_row_table<0>(p, tab, m0, BM, n0, BN, tid);
-            __syncthreads();
-            epilogue_direct_tile<PLANES, FM, FN>(p, acc, tab, wr * (16 * FM), n0 + wc * (16 * FN), lane);
-            GEMM_PROF_END();
-            return;
-        }
-    }
-    if (p.staged) {
+    if (p.direct) {
+        __syncthreads();  // every wave is done with the operand tiles: the row table takes their place
+        int4* tab = reinterpret_cast<int4*>(smem);
+        epilogue_row_table(p, tab, m0, BM, tid);
+        __syncthreads();
+        epilogue_direct_tile<PLANES, FM, FN>(p, acc, tab, wr * (16 * FM), n0 + wc * (16 * FN), lane);
+    } else if (p.staged) {
         __syncthreads();  // every wave is done with the operand tiles: LDS becomes the epilogue's staging space
         int4* tab = reinterpret_cast<int4*>(smem + NWAVES * 8192);
-        epilogue_row_table<FUSE>(p, tab, m0, BM, n0, BN, tid);
+        epilogue_row_table(p, tab, m0, BM, tid);
         __syncthreads();
-        epilogue_staged<PLANES, FM, FN, FUSE>(p, acc, smem + wave * 8192, tab, wr * (16 * FM), n0 + wc * (16 * FN), lane, BM, n0, BN);
+        epilogue_staged<PLANES, FM, FN>(p, acc, smem + wave * 8192, tab, wr * (16 * FM), n0 + wc * (16 * FN), lane);
     } else {
         epilogue_rows<PLANES, FM, FN>(p, acc, m0, n0, wr, wc, lane);
     }
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN ==
 // waves 4-7 rows 64-127), so one phase after the reads suffices; W half-tiles are read by both groups, and
 // the leading group re-stages them two phases after the read (W0 read in P1 -> staged in P3, W1 P2 -> P4).
 
-template <int PLANES, int FUSE = 0>
+template <int PLANES>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
     GEMM_PROF_BEGIN();
     constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 128 B
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
 
     // ---- LDS-DMA sources: wave w stages pieces 2w, 2w+1 (rows 16w .. 16w+15) of every half-tile ----
     // (direct epilogue with bf16 outputs: W rows permuted inside every 32-row group, gemm_device.h epilogue_direct)
-    const bool wperm = FUSE == 0 && p.direct && p.epi != EPI_F32;
+    const bool wperm = p.direct && p.epi != EPI_F32;
     unsigned src[4][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -490,27 +490,24 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
         return;
     }
     GEMM_PROF_MAIN();
-    if constexpr (FUSE == 0) {
-        if (p.direct) {
-            // (the balancing barrier above is also the point where every wave is done reading the operand tiles)
-            int4* tab = reinterpret_cast<int4*>(smem);
-            epilogue_row_table<0>(p, tab, m0, 256, n0, 256, tid);
-            __syncthreads();
-            epilogue_direct<PLANES, 4>(
-                p, [&](int pi, int i, int j) { return acc[pi >> 1][pi & 1][i][j]; }, [&](int pi) { return (pi >> 1) * 128 + wr * 64; },
-                [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, tab, lane);
-            GEMM_PROF_END();
-            return;
-        }
+    // (the balancing barrier above is also the point where every wave is done reading the operand tiles)
+    if (p.direct) {
+        int4* tab = reinterpret_cast<int4*>(smem);
+        epilogue_row_table(p, tab, m0, 256, tid);
+        __syncthreads();
+        epilogue_direct<PLANES, 4>(
+            p, [&](int pi, int i, int j) { return acc[pi >> 1][pi & 1][i][j]; }, [&](int pi) { return (pi >> 1) * 128 + wr * 64; },
+            [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, tab, lane);
+        GEMM_PROF_END();
+        return;
     }
     if (p.staged) {
-        // (the balancing barrier above is also the point where every wave is done reading the operand tiles)
         int4* tab = reinterpret_cast<int4*>(smem + 8 * 8192);
-        epilogue_row_table<FUSE>(p, tab, m0, 256, n0, 256, tid);
+        epilogue_row_table(p, tab, m0, 256, tid);
         __syncthreads();
-        epilogue_piece_seq<PLANES, 4, FUSE>(
+        epilogue_piece_seq<PLANES, 4>(
             p, [&](int pi, int i, int j) { return acc[pi >> 1][pi & 1][i][j]; }, [&](int pi) { return (pi >> 1) * 128 + wr * 64; },
-            [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, smem + wave * 8192, tab, lane, 256, n0, 256);
+            [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, smem + wave * 8192, tab, lane);
         GEMM_PROF_END();
         return;
     }
@@ -545,6 +542,18 @@ int splitk_workspace_alloc(float** slabs, unsigned** counts) {
     return 0;
 }
 
+int gemm_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus = prop.multiProcessorCount & ~7;
+        if (cus < 8) cus = 256;
+    }
+    return cus;
+}
+
 int g_gemm_tile = 0;  // 0 = automatic choice per shape
 static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t stream);
 int g_gemm_debug = 0;
@@ -557,7 +566,7 @@ int g_gemm_direct = 1;  // 1 (default): bf16-output epilogues (qkv, fc1, the cro
 // depend on the split.  Returns false if the shape has no such split.
 bool gemm_mixed_split(const GemmParams& p, GemmParams* big, GemmParams* rest) {
     const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
-    const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
+    const int cus = gemm_cu_count();
     const int rounds = (tiles_m * tiles_n) / cus;
     const int big_rows = std::min(tiles_m - 1, rounds * cus / tiles_n);  // m-tile rows of the 8-phase part
     if (rounds < 1 || big_rows < 1) return false;
@@ -580,7 +589,7 @@ int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) { return
 // Tile configuration for a launch: g_gemm_tile (development switch) if set, else per shape.
 int gemm_choose_tile(const GemmParams& p, int planes) {
     (void)planes;
-    int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase, 5: stream-K 8-phase, 6: 4 + 1 by rows
+    int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase, 6: 4 + 1 by rows
     if (cfg == 0) {
         // Measured on MI355X (tools/microbench.py gemm / gemm_mid / gemm_l4: B/8 at batch 8, 16, 32 and L/4 batch 8, both modes;
         // profiles/r1n_*, r1o_*, r1p_* logs).  The 256x256 8-phase kernel has the fastest main loop (~1.6 PFLOP/s of executed MFMA
@@ -590,7 +599,8 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
         //  * otherwise mixed tiling by rows (6): whole rounds of 256x256 tiles + a remainder of 128x128 tiles -- except the small
         //    short-K launches (proj of B/8), which stay on 128x128 tiles with two workgroups per CU
         //  * N < 512 or ragged narrow N (N = 384, head, patch embed): 128x128
-        // (The persistent stream-K form (5) is never selected: it is no faster than (6) and its split tiles re-associate fp32 sums.)
+        // (A persistent stream-K form of the 8-phase kernel existed in rounds 1-3, measured no faster than (6), never selected and removed
+        // in round 4 -- git history)
         //  * K < 512 (the B/8 decoder: K = 384), fp32 outputs: the 8-wave 128x128 kernel (its epilogues overlap the co-resident workgroup's
         //    main loop, and with 12 K tiles the epilogue is a third of a 256x256 tile's time).  bf16 outputs (qkv, fc1) since round 4: with
         //    the direct epilogue the 8-phase kernel wins there too (decoder qkv 149 -> 140 us, fc1 214 -> 191 us, profiles/r4_ab_gemm_direct.log)
@@ -598,7 +608,7 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
         const bool bf16_out = p.epi != EPI_F32;
         if (p.K >= ((bf16_out && !(g_gemm_debug & 512)) ? 256 : 512) && p.M >= 512 && (p.N >= 1024 || (p.N >= 512 && p.N % 256 == 0))) {
             const int64_t tiles = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
-            const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
+            const int cus = gemm_cu_count();
             if (tiles < cus) {
                 cfg = tiles * 2 >= cus ? 4 : 1;
             } else if (p.overlapped && !(g_gemm_debug & 128)) {
@@ -639,12 +649,6 @@ static int launch_gemm_checked(const GemmParams& p_in, int planes, int forced_cf
         CWM_REQUIRE(p.ldo % 4 == 0, "gemm: ldo must be a multiple of 4");
         CWM_REQUIRE(planes == 1 || p.ldo % 32 == 0, "gemm: split-bf16 output rows are whole [32 hi | 32 lo] blocks: ldo=%d must be a multiple of 32", p.ldo);
     }
-    if (p.ln_stats || p.split_out) {
-        CWM_REQUIRE(g_gemm_staged, "gemm: the LayerNorm-fold epilogues exist in the LDS-staged form only");
-        CWM_REQUIRE(!p.ln_stats || (p.ln_colsum && p.ln_np > 0), "gemm: ln_stats needs ln_colsum and ln_np");
-        CWM_REQUIRE(!p.split_out || (p.epi == EPI_F32 && p.stats_out && p.N % 32 == 0 && p.split_ld % 32 == 0),
-                    "gemm: split rows need the fp32 epilogue, a stats buffer and N, split_ld multiples of 32 (N=%d)", p.N);
-    }
     // ---- LDS-staged epilogue whenever its 16-byte row segments are aligned (always, for the predictor's widths) ----
     p.staged = 0;
     if (g_gemm_staged) {
@@ -657,7 +661,7 @@ static int launch_gemm_checked(const GemmParams& p_in, int planes, int forced_cf
     CWM_REQUIRE((int64_t)(p.m_offset + p.M) * p.lda * planes < (1ll << 32) && (int64_t)(((p.N + 255) / 256) * 256) * p.K * planes < (1ll << 32),
                 "gemm: operand too large for 32-bit element offsets (M=%d lda=%d N=%d K=%d planes=%d): split the batch", p.m_offset + p.M, p.lda,
                 p.N, p.K, planes);
-    p.direct = (g_gemm_direct && p.staged && !p.ln_stats && !p.split_out && (p.epi != EPI_F32 || g_gemm_direct >= 2)) ? 1 : 0;
+    p.direct = (g_gemm_direct && p.staged && (p.epi != EPI_F32 || g_gemm_direct >= 2)) ? 1 : 0;
     int cfg = forced_cfg > 0 ? forced_cfg : gemm_choose_tile(p, planes);
     if (cfg == 6) {
         GemmParams a, b;
@@ -672,17 +676,11 @@ static int launch_gemm_checked(const GemmParams& p_in, int planes, int forced_cf
 
 static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t stream) {
     typedef void (*kern_t)(const GemmParams);
-    const int fuse = (p.ln_stats ? 1 : 0) | (p.split_out ? 2 : 0);  // LayerNorm-fold consumer / split producer (kernels.h)
-    if (cfg == 5) {
-        if (!fuse && sk_shape_ok(p.M, p.N, p.K, planes, sk_grid_size())) return launch_gemm_sk(p, planes, stream);
-        cfg = fuse ? 4 : 1;  // too few tiles for one span per CU / the stream-K kernel has no LayerNorm-fold epilogue
-    }
-    if (fuse && (cfg == 2 || cfg == 3)) cfg = 4;
-    if (fuse == 3) cfg = 1;  // consumer AND producer (encoder_to_decoder): only the 128x128 kernel has the registers for both
+    CWM_REQUIRE(cfg >= 1 && cfg <= 4, "gemm: unknown tile configuration %d", cfg);
     if (cfg == 4) {
-        static const kern_t k8[3][2] = {{gemm8p_kernel<1>, gemm8p_kernel<2>}, {gemm8p_kernel<1, 1>, gemm8p_kernel<2, 1>}, {gemm8p_kernel<1, 2>, gemm8p_kernel<2, 2>}};
+        static const kern_t k8[2] = {gemm8p_kernel<1>, gemm8p_kernel<2>};
         const size_t smem8 = 2 * 4 * 128 * 128;
-        kern_t k = k8[fuse][planes - 1];
+        kern_t k = k8[planes - 1];
         if (int rc = cwm_set_max_lds((const void*)k, (int)smem8)) return rc;
         const int tiles8 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         hipLaunchKernelGGL(k, dim3(tiles8), dim3(512), smem8, stream, p);
@@ -691,14 +689,11 @@ static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t strea
     }
     static const kern_t deep128[2] = {gemm_bf16_kernel<1, 128, 128, 2, 2, 4>, gemm_bf16_kernel<2, 128, 128, 2, 2, 4>};
     static const kern_t deep128w8[2] = {gemm_bf16_kernel<1, 128, 128, 2, 4, 4>, gemm_bf16_kernel<2, 128, 128, 2, 4, 4>};  // 8 waves of 64x32
-    static const kern_t fuse128[3][2] = {{gemm_bf16_kernel<1, 128, 128, 2, 2, 2, 1>, gemm_bf16_kernel<2, 128, 128, 2, 2, 2, 1>},
-                                         {gemm_bf16_kernel<1, 128, 128, 2, 2, 2, 2>, gemm_bf16_kernel<2, 128, 128, 2, 2, 2, 2>},
-                                         {gemm_bf16_kernel<1, 128, 128, 2, 2, 2, 3>, gemm_bf16_kernel<2, 128, 128, 2, 2, 2, 3>}};
     // 128x128 tiles, at most one workgroup per CU (fewer tiles than CUs): the 4-stage ring hides the staging latency that the second
     // co-resident workgroup hides in bigger launches ("gemm_debug" bit 2 switches it off for A/B runs)
     const int tiles128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-    const int cus = sk_grid_size() > 0 ? sk_grid_size() : 256;
-    const bool deep = cfg == 1 && !fuse && !(g_gemm_debug & 4) && tiles128 <= cus;
+    const int cus = gemm_cu_count();
+    const bool deep = cfg == 1 && !(g_gemm_debug & 4) && tiles128 <= cus;
     p.splitk = 1;
     if (deep && !(g_gemm_debug & 32)) {
         // fill the idle CUs of a latency-bound launch by cutting K: only where it pays (measured, ViT-B/8 batch 1: fc2 65 -> 32 us with
@@ -728,11 +723,10 @@ static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t strea
             p.splitk = sk;
         }
     }
-    if (fuse || deep) {
-        // (LayerNorm-fold launches take the 128x128 kernel whenever the 8-phase kernel was not chosen)
-        const size_t smem = (size_t)(deep ? 4 : 2) * (128 + 128) * 128;
-        const bool w8 = deep && !(g_gemm_debug & 16);  // 8 waves of 64x32 (two per SIMD cover each other's LDS / barrier latency); bit 4: 4 waves
-        kern_t k = fuse ? fuse128[fuse - 1][planes - 1] : w8 ? deep128w8[planes - 1] : deep128[planes - 1];
+    if (deep) {
+        const size_t smem = (size_t)4 * (128 + 128) * 128;
+        const bool w8 = !(g_gemm_debug & 16);  // 8 waves of 64x32 (two per SIMD cover each other's LDS / barrier latency); bit 4: 4 waves
+        kern_t k = w8 ? deep128w8[planes - 1] : deep128[planes - 1];
         if (int rc = cwm_set_max_lds((const void*)k, (int)smem)) return rc;
         hipLaunchKernelGGL(k, dim3(tiles128 * p.splitk), dim3(w8 ? 512 : 256), smem, stream, p);
         CWM_HIP_CHECK(hipGetLastError());

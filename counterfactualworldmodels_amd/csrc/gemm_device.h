@@ -1,4 +1,4 @@
-// Device-side building blocks shared by the GEMM kernels (gemm.hip, gemm_sk.hip): LDS tile addressing, exact-erf GELU,
+// Device-side building blocks of the GEMM kernels (gemm.hip): LDS tile addressing, exact-erf GELU,
 // row maps and the fused epilogues.  Not part of the C ABI.
 #pragma once
 #include "common.h"
@@ -185,10 +185,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
 //   piece buffer: [64 rows][128 B], 16-byte chunk c of row r at c ^ (r & 7)
 //     fp32: chunk = 4 columns;  bf16: chunks 0-3 = hi of 8 columns each, chunks 4-7 = lo (parity only)
 //   row table: out_row / residual row (EPI_F32, EPI_BF16*), b * heads * n_tok + token / - (EPI_QKV); -1 = row >= M
-//   FUSE (bit 0: LayerNorm-fold consumer, bit 1: split producer; kernels.h): .z/.w = the row's (rstd, mean * rstd) for a consumer (p.ln_stats), .z = the
-//   split row for a producer (p.split_out); behind the bm rows, bn floats: the tile's slice of p.ln_colsum.
-template <int FUSE>
-__device__ __forceinline__ void epilogue_row_table(const GemmParams& p, int4* tab, int m0, int bm, int n0, int bn, int tid) {
+__device__ __forceinline__ void epilogue_row_table(const GemmParams& p, int4* tab, int m0, int bm, int tid) {
     if (tid < bm) {
         const int m = m0 + tid;
         int4 e = make_int4(-1, 0, 0, 0);
@@ -196,39 +193,8 @@ __device__ __forceinline__ void epilogue_row_table(const GemmParams& p, int4* ta
             const RowMap rm = map_row(p, m + p.m_offset);
             if (p.epi == EPI_QKV) e.x = rm.b * p.heads * p.n_tok + rm.tok;
             else { e.x = rm.out_row; e.y = rm.res_row; }
-            if constexpr (FUSE != 0) {
-                if ((FUSE & 1) && p.ln_stats) {
-                    // LayerNorm statistics of A row m (biased variance, eps inside the root: nn.LayerNorm, VideoMAE/utils.py:148-149) from
-                    // the producer's per-32-column partial sums; reduced in float64 in a fixed order (deterministic)
-                    const float2* st = p.ln_stats + (size_t)(m + p.m_offset) * p.ln_np;
-                    double sum = 0.0, sq = 0.0;
-                    for (int i = 0; i < p.ln_np; ++i) {
-                        const float2 v = st[i];
-                        sum += (double)v.x;
-                        sq += (double)v.y;
-                    }
-                    const double mean = sum * (double)p.ln_inv_d;
-                    double var = sq * (double)p.ln_inv_d - mean * mean;
-                    var = var > 0.0 ? var : 0.0;
-                    const double rstd = 1.0 / sqrt(var + (double)p.ln_eps);
-                    e.z = __float_as_int((float)rstd);
-                    e.w = __float_as_int((float)(mean * rstd));
-                } else if ((FUSE & 2) && p.split_out) {
-                    e.z = p.rows_in > 0 ? rm.b * p.split_rows_per_b + rm.tok : m + p.m_offset;
-                }
-            }
         }
         tab[tid] = e;
-    }
-    if constexpr (FUSE != 0) {
-        // the tile's column vectors: [bn] column sums of the folded weight (consumer), then [bn] bias (the fused variants read the bias
-        // from LDS instead of holding it in 32 registers for the whole epilogue)
-        if (tid < bn) {
-            float* colv = reinterpret_cast<float*>(tab + bm);
-            const bool in = n0 + tid < p.N;
-            colv[tid] = ((FUSE & 1) && p.ln_stats && in) ? p.ln_colsum[n0 + tid] : 0.f;
-            colv[bn + tid] = (p.bias && in) ? p.bias[n0 + tid] : 0.f;
-        }
     }
 }
 
@@ -243,12 +209,8 @@ static __device__ __attribute__((aligned(16))) float g_epilogue_trash[64 * 4];
 //   nb_of(pi): its first column (global, multiple of 32).
 // Order of the vector-memory operations: every bias load first; a piece is read back in two halves, and the residual rows of
 // the NEXT half are requested BEFORE the stores of this half are issued, so the (in-order) wait for them never waits for a store.
-//   FUSE: the LayerNorm-fold consumer form of the first stage (v = rstd * acc - mean * rstd * colsum + bias'), and the producer's extra
-//   outputs in the read-back stage of EPI_F32 (the final rows split into the A-operand layout + their partial statistics); bm / n0:
-//   rows of the tile's row table (the column sums sit behind it) and the tile's first column.
-template <int PLANES, int NPIECE, int FUSE, class Frag, class Row0, class Nb>
-__device__ __forceinline__ void epilogue_piece_seq(const GemmParams& p, Frag frag, Row0 row0_of, Nb nb_of, char* wlds, const int4* tab, int lane,
-                                                   int bm = 0, int n0 = 0, int bn = 0) {
+template <int PLANES, int NPIECE, class Frag, class Row0, class Nb>
+__device__ __forceinline__ void epilogue_piece_seq(const GemmParams& p, Frag frag, Row0 row0_of, Nb nb_of, char* wlds, const int4* tab, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
     const bool f32_out = p.epi == EPI_F32;
     constexpr int NS = 8;  // read-back iterations of 8 rows (128-byte rows); fast-mode bf16 outputs: 4 iterations of 16 rows (64-byte rows)
@@ -259,16 +221,14 @@ __device__ __forceinline__ void epilogue_piece_seq(const GemmParams& p, Frag fra
     gf32x4* const trash = (gf32x4*)(g_epilogue_trash + lane * 4);
 
     f32x4 bias[NPIECE][2];
-    if constexpr (FUSE == 0) {
 #pragma unroll
-        for (int pi = 0; pi < NPIECE; ++pi)
+    for (int pi = 0; pi < NPIECE; ++pi)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = nb_of(pi) + j * 16;
-                bias[pi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.bias && n < p.N) bias[pi][j] = *reinterpret_cast<const f32x4*>(p.bias + n + fq * 4);
-            }
-    }
+        for (int j = 0; j < 2; ++j) {
+            const int n = nb_of(pi) + j * 16;
+            bias[pi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) bias[pi][j] = *reinterpret_cast<const f32x4*>(p.bias + n + fq * 4);
+        }
 
     // residual rows of half a piece (unit u = 2 pi + half: read-back iterations 4 half .. 4 half + 3), EPI_F32 only
     auto load_resid = [&](int u, f32x4 (&rv)[NS / 2]) {
@@ -299,39 +259,12 @@ __device__ __forceinline__ void epilogue_piece_seq(const GemmParams& p, Frag fra
             qd = cD - qh * p.head_dim;
         }
         // ---- accumulators (+ bias, activation, split) -> piece buffer ----
-        [[maybe_unused]] float2 rowst[4];  // LayerNorm fold: (rstd, mean * rstd) of this lane's four rows of the piece
-        if constexpr ((FUSE & 1) != 0) {
-            if (p.ln_stats) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rowst[i] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tab + row0 + i * 16 + fr) + 8);
-            }
-        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f32x4 bias_j;  // this lane's four bias values of the fragment column block
-            [[maybe_unused]] f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (FUSE != 0) {
-                const float* colv = reinterpret_cast<const float*>(tab + bm) + (nb - n0) + j * 16 + fq * 4;
-                bias_j = *reinterpret_cast<const f32x4*>(colv + bn);
-                if ((FUSE & 1) && p.ln_stats) cs = *reinterpret_cast<const f32x4*>(colv);
-            } else {
-                bias_j = bias[pi][j];
-            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = i * 16 + fr;
-                f32x4 v;
-                if constexpr ((FUSE & 1) != 0) {
-                    if (p.ln_stats) {
-                        const f32x4 a = frag(pi, i, j);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaf(a[e], rowst[i].x, fmaf(-rowst[i].y, cs[e], bias_j[e]));
-                    } else {
-                        v = frag(pi, i, j) + bias_j;
-                    }
-                } else {
-                    v = frag(pi, i, j) + bias_j;
-                }
+                f32x4 v = frag(pi, i, j) + bias[pi][j];
                 if (f32_out) {
                     *reinterpret_cast<f32x4*>(wlds + r * 128 + (((j * 4 + fq) ^ (r & 7)) << 4)) = v;
                 } else {
@@ -400,68 +333,6 @@ __device__ __forceinline__ void epilogue_piece_seq(const GemmParams& p, Frag fra
             }
             // ---- the next half-piece's residual rows, then this half's stores ----
             if (f32_out && 2 * pi + hf + 1 < 2 * NPIECE) load_resid(2 * pi + hf + 1, rv_next);
-            if constexpr ((FUSE & 2) != 0) {
-                if (f32_out && p.split_out) {
-                    // Split producer (LayerNorm folded into the next GEMM): the final rows in the A-operand layout + their partial statistics.
-                    // Issued here, with this half's stores, so that the residual loads requested above do not queue behind them.
-                    const int c = lane & 7;
-                    float2 my_stat = make_float2(0.f, 0.f);
-                    int my_srow = -1;
-#pragma unroll
-                    for (int s = 0; s < NS / 2; ++s) {
-                        const int n = nb + c * 4;
-                        const int4 info = tab[row0 + (hf * 4 + s) * 8 + (lane >> 3)];  // (re-read: cheaper than four live registers)
-                        const bool ok = info.x >= 0 && n < p.N;
-                        const int srow_s = ((FUSE & 1) && p.ln_stats) ? info.x : info.z;
-                        // the 8 lanes of a row hold its 32 columns of this piece: partial sums (every lane of the group gets the totals;
-                        // lane c == s keeps slot s, so that ONE store below covers the 32 rows of the half piece)
-                        const f32x4 w = ok ? v[s] : f32x4{0.f, 0.f, 0.f, 0.f};
-                        const float ps = group8_sum((w[0] + w[1]) + (w[2] + w[3]));
-                        const float pq = group8_sum(fmaf(w[0], w[0], w[1] * w[1]) + fmaf(w[2], w[2], w[3] * w[3]));
-                        if (c == s) {
-                            my_stat = make_float2(ps, pq);
-                            my_srow = ok ? srow_s : -1;
-                        }
-                        bf16x4 hv, lv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const bf16 hi = (bf16)w[e];
-                            hv[e] = hi;
-                            lv[e] = (bf16)(w[e] - (float)hi);
-                        }
-                        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-                        const bool odd = c & 1;
-                        if constexpr (PLANES == 2) {
-                            // even lanes write 8 hi values, odd lanes 8 lo values (the [32 hi | 32 lo] line of this 32-column block): one
-                            // 16-byte store per lane after swapping halves with the neighbour lane
-                            const u32x2 mine = odd ? __builtin_bit_cast(u32x2, hv) : __builtin_bit_cast(u32x2, lv);  // what the partner lane stores
-                            u32x2 got;
-                            got[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine[0], 0xB1, 0xf, 0xf, true);
-                            got[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine[1], 0xB1, 0xf, 0xf, true);
-                            const u32x2 own = odd ? __builtin_bit_cast(u32x2, lv) : __builtin_bit_cast(u32x2, hv);
-                            u32x4 line;
-                            line[0] = odd ? got[0] : own[0];
-                            line[1] = odd ? got[1] : own[1];
-                            line[2] = odd ? own[0] : got[0];
-                            line[3] = odd ? own[1] : got[1];
-                            bf16* d = p.split_out + a_pos<2>(srow_s, p.split_ld, n - (odd ? 4 : 0)) + (odd ? kLoOffset : 0);
-                            typedef __attribute__((address_space(1))) u32x4 gu32x4;
-                            gu32x4* sd = ok ? (gu32x4*)d : (gu32x4*)trash;
-                            *sd = line;
-                        } else {
-                            typedef __attribute__((address_space(1))) u32x2 gu32x2;
-                            gu32x2* sd = ok ? (gu32x2*)(p.split_out + (size_t)srow_s * p.split_ld + n) : (gu32x2*)trash;
-                            *sd = __builtin_bit_cast(u32x2, hv);
-                        }
-                        *dst[s] = v[s];  // (the fp32 row itself; the plain store loop below is skipped for this half)
-                    }
-                    typedef __attribute__((ext_vector_type(2))) float f32x2;
-                    typedef __attribute__((address_space(1))) f32x2 gf32x2;
-                    gf32x2* sd = my_srow >= 0 ? (gf32x2*)(p.stats_out + (size_t)my_srow * (p.N >> 5) + (nb >> 5)) : (gf32x2*)trash;
-                    *sd = f32x2{my_stat.x, my_stat.y};
-                    continue;
-                }
-            }
             if (wide) {
 #pragma unroll
                 for (int s = 0; s < NS / 2; ++s) *dst[s] = v[s];
@@ -609,14 +480,13 @@ __device__ __forceinline__ void epilogue_direct_tile(const GemmParams& p, const 
 }
 
 // Whole wave tile (FM x FN fragments at tile rows wrow0.., columns ncol0..) through the staged epilogue.
-template <int PLANES, int FM, int FN, int FUSE>
-__device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4 (&acc)[FM][FN], char* wlds, const int4* tab, int wrow0,
-                                                int ncol0, int lane, int bm, int n0, int bn) {
+template <int PLANES, int FM, int FN>
+__device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4 (&acc)[FM][FN], char* wlds, const int4* tab, int wrow0, int ncol0, int lane) {
     static_assert(FM % 4 == 0 && FN % 2 == 0, "wave tile must be a multiple of the 64x32 piece");
     constexpr int PJ = FN / 2, NPIECE = (FM / 4) * PJ;
-    epilogue_piece_seq<PLANES, NPIECE, FUSE>(
+    epilogue_piece_seq<PLANES, NPIECE>(
         p, [&](int pi, int i, int j) { return acc[(pi / PJ) * 4 + i][(pi % PJ) * 2 + j]; }, [&](int pi) { return wrow0 + (pi / PJ) * 64; },
-        [&](int pi) { return ncol0 + (pi % PJ) * 32; }, wlds, tab, lane, bm, n0, bn);
+        [&](int pi) { return ncol0 + (pi % PJ) * 32; }, wlds, tab, lane);
 }
 
 }  // namespace cwm

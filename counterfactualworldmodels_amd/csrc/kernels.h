@@ -42,26 +42,6 @@ struct GemmParams {
     int64_t qk_plane;
     int qkv_dim, heads, head_dim, n_tok;
     float q_scale;
-    // stream-K kernel (gemm_sk.hip); filled in by launch_gemm
-    float rows_in_inv;   // 1 / rows_in
-    float* sk_slabs;     // [grid][256*256] fp32 partial accumulators of split tiles
-    unsigned* sk_flags;  // [grid] slab published in launch `sk_epoch`
-    unsigned* sk_err;    // set to 1 if a hand-off wait timed out
-    unsigned sk_epoch;
-    // ---- LayerNorm folded into the GEMMs around it (engine.hip run_block) ----
-    // consumer (qkv, fc1, encoder_to_decoder, head): A is the split of the RAW residual rows and W carries the LayerNorm weight
-    // (W' = W diag(gamma)); the epilogue turns acc = x W'^T into LN(x) W^T + b = r (acc - mu * colsum) + bias', with the row
-    // statistics reduced from the producer's partial sums.  ln_stats == nullptr: plain GEMM.
-    const float2* ln_stats;  // [A rows][ln_np] partial (sum, sum of squares) over 32-column slices of the row
-    int ln_np;
-    const float* ln_colsum;  // [N] sum_k W'[n][k] of the packed (rounded) weights
-    float ln_inv_d, ln_eps;
-    // producer (patch embed, proj, fc2, encoder_to_decoder; EPI_F32 only): besides C also writes the rows in the A-operand
-    // layout of the next GEMM and their partial statistics.  split_out == nullptr: off.
-    bf16* split_out;         // [split rows][split_ld] (x 2, hi/lo interleaved, in parity mode)
-    int split_ld;
-    float2* stats_out;       // [split rows][N / 32]
-    int split_rows_per_b;    // split row = b * split_rows_per_b + tok (rows_in > 0), else the A row; ignored when ln_stats is set (= out row)
     // split-K of the latency-bound small launches (gemm.hip, deep-ring 128x128 kernel); filled in by launch_gemm
     int splitk;              // K is cut into this many ranges, one workgroup each (1: off)
     float* sk2_slabs;        // [tiles * splitk][128 * 128] fp32 partial accumulators
@@ -77,16 +57,13 @@ int splitk_workspace_alloc(float** slabs, unsigned** counts);
 int launch_gemm(const GemmParams& p, int planes, hipStream_t stream);
 int gemm_choose_tile(const GemmParams& p, int planes);
 bool gemm_mixed_split(const GemmParams& p, GemmParams* big, GemmParams* rest);  // tile configuration 6
-int launch_gemm_tile(const GemmParams& p, int planes, int cfg, hipStream_t stream);  // 1: 128x128 ... 4: 256x256 8-phase, 5: stream-K (see g_gemm_tile)
-int launch_gemm_sk(GemmParams& p, int planes, hipStream_t stream);  // persistent stream-K 8-phase kernel (gemm_sk.hip)
-bool sk_shape_ok(int M, int N, int K, int planes, int grid);
-int sk_grid_size();
-int sk_error_flag();
+int launch_gemm_tile(const GemmParams& p, int planes, int cfg, hipStream_t stream);  // 1: 128x128 ... 4: 256x256 8-phase (see g_gemm_tile)
+int gemm_cu_count();  // compute units of the current device, rounded down to a multiple of the 8 XCDs (256 on MI355X)
 int gemm_prof_dump();  // builds with -DCWM_GEMM_PROF: per-workgroup timers of gemm8p_kernel -> /tmp/gemm_blocks.bin
 extern int g_gemm_debug;
 extern int g_gemm_staged;
 extern int g_gemm_direct;
-extern int g_gemm_tile;    // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256 output tile, 4: 256x256 8-phase, 5: persistent stream-K 8-phase
+extern int g_gemm_tile;    // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256 output tile, 4: 256x256 8-phase, 6: 4 for the whole rounds + 1 for the remaining rows
 
 struct AttnParams {
     const bf16* q;   // [planes][B*H][N][64]   (q pre-scaled by hd^-0.5)
@@ -149,10 +126,7 @@ struct PatchGatherParams {
 int launch_patch_gather(const PatchGatherParams& p, int planes, hipStream_t stream);
 
 // x_full[b][n_vis + j][:] = mask_token + pos[perm[b][n_vis + j]]   (vmae.py:556-557)
-// split / stats (optional): the same rows in the A-operand layout of the mode + their (sum, sum of squares) partials per
-// 32-column slice, as the GEMM producers write them (LayerNorm folded into the consuming GEMM)
-int launch_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt,
-                            int n_vis, int D, hipStream_t stream, bf16* split = nullptr, float2* stats = nullptr, int planes = 2);
+int launch_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt, int n_vis, int D, hipStream_t stream);
 
 struct UnembedParams {
     const float* y;  // [B][Nm][P*P*C], feature order (ph, pw, c)

@@ -22,9 +22,6 @@ struct cwm_model {
     bf16* patches = nullptr;
     float *x_enc = nullptr, *x_dec = nullptr;
     StreamBuffers sb;
-    bf16* xsplit[2] = {nullptr, nullptr};   // [0] encoder stream, [1] decoder stream (LayerNorm fold, engine.h StreamBuffers)
-    float2* xstats[2] = {nullptr, nullptr};
-    int stats_per_lane_row = 0;
     // batch lanes (cwm_model_set_lanes): a batch whose halves keep >= kMinLaneRows encoder rows runs as two half batches, the first on the
     // caller's stream and the second on `lane_stream`, joined by events before cwm_forward returns control of the stream
     int lanes = 2;
@@ -47,8 +44,6 @@ struct LaneWs {
     bf16* patches;
     float *x_enc, *x_dec;
     StreamBuffers sb;
-    bf16* xsplit[2];
-    float2* xstats[2];
 };
 constexpr int kMinLaneRows = 6000;  // encoder rows (batch elements x visible tokens) a lane must have: below, the GEMM grids no longer fill the chip
 
@@ -70,10 +65,6 @@ int ensure_workspace(cwm_model* m, int B, int n_vis) {
         (rc = E.ws(&m->sb.kbuf, 2 * act)))
         return rc;
     if ((rc = E.ws(&m->sb.vbuf, 2 * act))) return rc;
-    // LayerNorm fold: residual rows in operand layout + partial statistics, one set per token stream (encoder / decoder)
-    m->stats_per_lane_row = std::max(c.enc_dim, c.dec_dim) / 32;
-    for (int i = 0; i < 2; ++i)
-        if ((rc = E.ws(&m->xsplit[i], 2 * act)) || (rc = E.ws(&m->xstats[i], std::max(rows_e, rows_d) * m->stats_per_lane_row))) return rc;
     m->ws_batch = Bc;
     m->ws_nvis = Nv;
     // (the zero fills above ran on the null stream; the lane streams are non-blocking and would not wait for them)
@@ -98,10 +89,6 @@ LaneWs lane_ws(const cwm_model* m, int lane, int b0) {
     w.sb.qbuf += 2 * act;
     w.sb.kbuf += 2 * act;
     w.sb.vbuf += 2 * act;
-    for (int i = 0; i < 2; ++i) {
-        w.xsplit[i] = m->xsplit[i] + 2 * act;
-        w.xstats[i] = m->xstats[i] + std::max(rows_e, rows_d) * m->stats_per_lane_row;
-    }
     return w;
 }
 
@@ -110,8 +97,6 @@ LaneWs lane_ws(const cwm_model* m, int lane, int b0) {
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
-static int g_ln_fuse = 0;  // "ln_fuse" switch: LayerNorm folded into the GEMMs around it; read at model creation AND per forward
-
 extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
     CWM_REQUIRE(cfg && out, "cwm_model_create: null argument");
     const cwm_config& c = *cfg;
@@ -126,9 +111,6 @@ extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
     m->cfg = c;
     Engine& E = m->eng;
     E.ln_eps = c.ln_eps;
-    // The LayerNorm fold (measured slower, off by default) keeps an fp32 copy + two folded packings of every consuming linear (~2.5x the
-    // packed-weight memory): only models created while the "ln_fuse" switch is on carry that state
-    E.enable_folds = g_ln_fuse && (c.enc_dim % 64 == 0 && c.dec_dim % 64 == 0);
     CWM_HIP_CHECK(hipGetDevice(&E.device));
     m->n_per_frame = (c.img_h / c.patch) * (c.img_w / c.patch);
     m->Nt = m->n_per_frame * c.num_frames;
@@ -150,7 +132,6 @@ extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
         E.add_vec_slot("encoder.norm.bias", m->enc_norm_b, {c.enc_dim});
         if ((rc = E.make_linear(m->e2d, c.dec_dim, c.enc_dim, false))) break;
         E.add_matrix_slot("encoder_to_decoder.weight", &m->e2d, {c.dec_dim, c.enc_dim});
-        if (E.enable_folds && (rc = E.set_fold(m->e2d, m->enc_norm_g, m->enc_norm_b))) break;  // encoder.norm folds in
         if ((rc = E.make_vec(&m->mask_token, c.dec_dim))) break;
         E.add_vec_slot("mask_token", m->mask_token, {1, 1, c.dec_dim});
         for (int i = 0; i < c.dec_depth && !rc; ++i)
@@ -161,7 +142,6 @@ extern "C" int cwm_model_create(const cwm_config* cfg, cwm_model** out) {
         E.add_vec_slot("decoder.norm.bias", m->dec_norm_b, {c.dec_dim});
         if ((rc = E.make_linear(m->head, m->out_dim, c.dec_dim, true))) break;
         E.add_matrix_slot("decoder.head.weight", &m->head, {m->out_dim, c.dec_dim});
-        if (m->e2d.raw && (rc = E.set_fold(m->head, m->dec_norm_g, m->dec_norm_b))) break;  // decoder.norm folds into the head
         E.add_vec_slot("decoder.head.bias", m->head.bias, {m->out_dim});
         if ((rc = E.make_sinusoid(&m->pos_enc, m->Nt, c.enc_dim))) break;  // vmae.py:75
         if ((rc = E.make_sinusoid(&m->pos_dec, m->Nt, c.dec_dim))) break;  // vmae.py:366
@@ -184,10 +164,9 @@ extern "C" int cwm_model_load_weight(cwm_model* m, const char* key, const float*
 extern "C" int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen) { return m->eng.missing_weights(buf, buflen); }
 
 static int g_prune_last_block = 1;
-// LayerNorm folded into the GEMMs around it (engine.h).  Implemented, parity-tested and selectable (cwm_debug_set "ln_fuse" = 1), but NOT
-// the default: measured on MI355X the extra 4 bytes/element a producer GEMM must store (its rows in operand layout) inside its
-// store-bound epilogue cost as much as the LayerNorm launch they replace (B/8 batch 32: +75 us per block vs 64 us).
-// (g_ln_fuse is defined above cwm_model_create, which reads it)
+// (Rounds 2-3 carried a form with every LayerNorm folded into the GEMMs around it -- parity-tested, measured slower: the 4 bytes / element
+// a producer GEMM then adds to its store-bound epilogue cost more than the LayerNorm launch they replace, DESIGN.md section 4.6 -- never the
+// default and removed in round 4.)
 
 // One lane: batch elements [b0, b0 + B) of the call, on stream s, in the workspace slice w.
 // Stages [stage_lo, stage_hi) of the lane's launch sequence: 0 = mask -> permutation, patch gather + embed; 1 .. Le = encoder blocks;
@@ -223,18 +202,11 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
     if ((rc = E.run_patch_gather(pg, planes, s))) return rc;
     }
 
-    // LayerNorm folded into the GEMMs around it (engine.h): no LayerNorm launch anywhere on the path.  Needs the LDS-staged epilogues.
-    const bool fold = g_ln_fuse && g_gemm_staged && m->e2d.raw != nullptr;
     StreamBuffers sb_enc = w.sb, sb_dec = w.sb;
-    if (fold) {
-        sb_enc.xsplit = w.xsplit[0]; sb_enc.xstats = w.xstats[0];
-        sb_dec.xsplit = w.xsplit[1]; sb_dec.xstats = w.xstats[1];
-    }
     if (in_range(0)) {
     g = gemm_base(w.patches, m->patch_kpad, m->patch, B * Nv, planes);
     g.epi = EPI_F32; g.C = w.x_enc; g.ldc = c.enc_dim;
     g.resid = m->pos_enc; g.ldr = c.enc_dim; g.resid_rowmap = w.perm; g.rows_in = Nv; g.rows_out = Nv; g.map_stride = Nt;
-    if (fold) { g.split_out = sb_enc.xsplit; g.split_ld = c.enc_dim; g.stats_out = sb_enc.xstats; g.split_rows_per_b = Nv; }
     if ((rc = E.run_gemm(g, planes, s))) return rc;
     }
 
@@ -244,22 +216,15 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
 
     // a7: encoder.norm, encoder_to_decoder (no bias); a8: + pos[vis] written straight into x_full rows [0,Nv)
     if (in_range(st_e2d)) {
-    if (fold) {
-        g = E.fold_gemm(sb_enc.xsplit, sb_enc.xstats, m->e2d, B * Nv, planes);
-        g.split_out = sb_dec.xsplit; g.split_ld = c.dec_dim; g.stats_out = sb_dec.xstats;  // (split row = out row for a fold consumer)
-    } else {
-        memset(&ln, 0, sizeof(ln));
-        ln.x = w.x_enc; ln.ldx = c.enc_dim; ln.gamma = m->enc_norm_g; ln.beta = m->enc_norm_b; ln.eps = c.ln_eps; ln.D = c.enc_dim;
-        ln.rows = B * Nv; ln.out = w.sb.hbuf; ln.out_plane = (int64_t)B * Nv * c.enc_dim; ln.ldo = c.enc_dim;
-        if ((rc = E.run_layernorm(ln, planes, s))) return rc;
-        g = gemm_base(w.sb.hbuf, c.enc_dim, m->e2d, B * Nv, planes);
-    }
+    memset(&ln, 0, sizeof(ln));
+    ln.x = w.x_enc; ln.ldx = c.enc_dim; ln.gamma = m->enc_norm_g; ln.beta = m->enc_norm_b; ln.eps = c.ln_eps; ln.D = c.enc_dim;
+    ln.rows = B * Nv; ln.out = w.sb.hbuf; ln.out_plane = (int64_t)B * Nv * c.enc_dim; ln.ldo = c.enc_dim;
+    if ((rc = E.run_layernorm(ln, planes, s))) return rc;
+    g = gemm_base(w.sb.hbuf, c.enc_dim, m->e2d, B * Nv, planes);
     g.epi = EPI_F32; g.C = w.x_dec; g.ldc = c.dec_dim;
     g.resid = m->pos_dec; g.ldr = c.dec_dim; g.resid_rowmap = w.perm; g.rows_in = Nv; g.rows_out = Nt; g.map_stride = Nt;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
-    if (Nm > 0 && (rc = E.run_fill_mask_tokens(w.x_dec, m->mask_token, m->pos_dec, w.perm, B, Nt, Nv, c.dec_dim, s, fold ? sb_dec.xsplit : nullptr,
-                                                fold ? sb_dec.xstats : nullptr, planes)))
-        return rc;
+    if (Nm > 0 && (rc = E.run_fill_mask_tokens(w.x_dec, m->mask_token, m->pos_dec, w.perm, B, Nt, Nv, c.dec_dim, s))) return rc;
     }
 
     // a9: decoder blocks over the full token set, norm + head on the last Nm tokens
@@ -270,17 +235,12 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
         if (in_range(st_e2d + 1 + i) && (rc = E.run_block(m->dec[i], w.x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, sb_dec, s, keep))) return rc;
     }
     if (!in_range(st_head)) return CWM_OK;
-    if (fold && (pruned || Nm == 0)) {
-        // the last block left exactly the B * Nret rows the head reads, compact, in operand layout: decoder.norm folds into the head GEMM
-        g = E.fold_gemm(sb_dec.xsplit, sb_dec.xstats, m->head, B * Nret, planes);
-    } else {
-        memset(&ln, 0, sizeof(ln));
-        ln.x = w.x_dec; ln.ldx = c.dec_dim; ln.gamma = m->dec_norm_g; ln.beta = m->dec_norm_b; ln.eps = c.ln_eps; ln.D = c.dec_dim;
-        ln.rows = B * Nret; ln.rows_out_per_b = Nret; ln.rows_in_per_b = Nt; ln.in_offset = Nt - Nret;
-        ln.out = w.sb.hbuf; ln.out_plane = (int64_t)B * Nret * c.dec_dim; ln.ldo = c.dec_dim;
-        if ((rc = E.run_layernorm(ln, planes, s))) return rc;
-        g = gemm_base(w.sb.hbuf, c.dec_dim, m->head, B * Nret, planes);
-    }
+    memset(&ln, 0, sizeof(ln));
+    ln.x = w.x_dec; ln.ldx = c.dec_dim; ln.gamma = m->dec_norm_g; ln.beta = m->dec_norm_b; ln.eps = c.ln_eps; ln.D = c.dec_dim;
+    ln.rows = B * Nret; ln.rows_out_per_b = Nret; ln.rows_in_per_b = Nt; ln.in_offset = Nt - Nret;
+    ln.out = w.sb.hbuf; ln.out_plane = (int64_t)B * Nret * c.dec_dim; ln.ldo = c.dec_dim;
+    if ((rc = E.run_layernorm(ln, planes, s))) return rc;
+    g = gemm_base(w.sb.hbuf, c.dec_dim, m->head, B * Nret, planes);
     g.epi = EPI_F32; g.C = y_tokens; g.ldc = m->out_dim;
     if ((rc = E.run_gemm(g, planes, s))) return rc;
 
@@ -316,11 +276,8 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
         const int nmiss = m->eng.missing_weights(miss, sizeof(miss));
         CWM_REQUIRE(nmiss == 0, "cwm_forward: %d state-dict tensors not loaded (first: %s)", nmiss, miss);
     }
-    CWM_REQUIRE(!g_ln_fuse || m->e2d.raw, "cwm_forward: \"ln_fuse\" is on, but this model was created while it was off and carries no fold state "
-                                          "(set the switch before cwm_model_create)");
     if (int rc = ensure_workspace(m, B, Nv)) return rc;
     hipStream_t s = (hipStream_t)a->stream;
-    if (int rc = m->eng.finalize_folds(s)) return rc;  // (before the lanes fork: they wait on an event recorded after it)
 
     // Batch lanes: between two dependent kernels the queue idles ~6 us (x 136 kernels = 5 % of a batch-32 step) and every kernel ends in a
     // partially filled round of workgroups; further, independent slices of the batch on other queues fill both.
@@ -630,13 +587,8 @@ extern "C" int cwm_debug_set(const char* key, int value) {
     }
     if (!strcmp(key, "gemm_prof")) return gemm_prof_dump();  // query (profiling builds)
     if (!strcmp(key, "attn_prof")) return attention_pipe_prof(value);  // query (profiling builds)
-    if (!strcmp(key, "sk_error")) return sk_error_flag() == 0 ? CWM_OK : CWM_ERR_INVALID;  // query: stream-K hand-off timeouts
     if (!strcmp(key, "prune_last_block")) {
         g_prune_last_block = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "ln_fuse")) {
-        g_ln_fuse = value;
         return CWM_OK;
     }
     if (!strcmp(key, "attn_tail")) {
@@ -680,9 +632,6 @@ extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters,
     CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_bench_gemm: bad mode");
     const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
     const int Kp = round_up(K, 64), Np = round_up(N, 256);
-    // epi + 10: the LayerNorm-fold form of the same epilogue (0 -> split producer, 1 / 3 -> fold consumer)
-    const bool fold = epi >= 10;
-    epi = epi % 10;
     Scratch sc;
     bf16* A = sc.get<bf16>((size_t)2 * M * Kp);
     bf16* W = sc.get<bf16>((size_t)2 * Np * Kp);
@@ -691,15 +640,11 @@ extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters,
     bf16* G = sc.get<bf16>((size_t)2 * M * N + 64 * 1024);
     bf16* G2 = sc.get<bf16>((size_t)2 * M * N + 64 * 1024);
     bf16* G3 = sc.get<bf16>((size_t)2 * M * N + 64 * 1024 * 64);
-    float2* stats = sc.get<float2>((size_t)M * (std::max(N, Kp) / 32 + 1));
-    float* colsum = sc.get<float>(Np);
-    CWM_REQUIRE(A && W && bias && Cm && G && G2 && G3 && stats && colsum, "cwm_bench_gemm: out of device memory");
+    CWM_REQUIRE(A && W && bias && Cm && G && G2 && G3, "cwm_bench_gemm: out of device memory");
     fill_bf16(A, (int64_t)2 * M * Kp, 1, 1.0f);
     fill_bf16(W, (int64_t)2 * Np * Kp, 2, 0.05f);
     fill_f32(bias, Np, 3, 0.1f);
     fill_f32(Cm, (int64_t)M * N, 4, 1.0f);
-    fill_f32((float*)stats, (int64_t)2 * M * (std::max(N, Kp) / 32 + 1), 5, 1.0f);
-    fill_f32(colsum, Np, 6, 0.1f);
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = Kp; p.W = W;
@@ -715,13 +660,6 @@ extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters,
         p.qkv_dim = D; p.heads = H; p.head_dim = 64; p.n_tok = n_tok; p.q_scale = 0.125f;
     } else {
         p.epi = EPI_F32; p.C = Cm; p.ldc = N; p.resid = Cm; p.ldr = N;
-    }
-    if (fold) {
-        if (epi == 0) {
-            p.split_out = G; p.split_ld = N; p.stats_out = stats;
-        } else {
-            p.ln_stats = stats; p.ln_np = Kp / 32; p.ln_colsum = colsum; p.ln_inv_d = 1.0f / Kp; p.ln_eps = 1e-6f;
-        }
     }
     hipEvent_t e0, e1;
     CWM_HIP_CHECK(hipEventCreate(&e0));

@@ -231,8 +231,6 @@ def test_qkv_epilogue_variants_agree_end_to_end():
     lib = _lib.get_lib()
     outs = {}
     try:
-        # (the direct epilogue exists for the stand-alone LayerNorm path only: compare the variants there)
-        _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
         for mode in ("parity", "fast"):
             m = build(TINY, seed, mode=mode)
             G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
@@ -250,54 +248,7 @@ def test_qkv_epilogue_variants_agree_end_to_end():
         _lib.check(lib.cwm_debug_set(b"gemm_staged", 1))
         _lib.check(lib.cwm_debug_set(b"gemm_direct", 1))
         _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
-        _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
     assert np.abs(outs[("parity", 11, 0)].numpy() - g["y_tokens"]).max() <= 2e-4
-
-
-@pytest.mark.parametrize("name,cfg_name", [("tiny_8x8_k4.npz", None), ("base8_k8_b2.npz", "base_8x8patch_2frames_1tube")])
-def test_layernorm_fold_matches_standalone_layernorm(name, cfg_name):
-    """LayerNorm folded into the GEMMs around it (producers emit split rows + partial statistics, consumers apply
-    rstd * (acc - mean * colsum) + bias') against the stand-alone LayerNorm kernels: same outputs within 1e-4
-    (both modes, every GEMM tile configuration), and both within tolerance of the reference."""
-    g = np.load(os.path.join(GOLDEN, name))
-    cfg = TINY if cfg_name is None else C.CONFIGS[cfg_name]
-    seed, x, mask = case_inputs(g, cfg)
-    lib = _lib.get_lib()
-    try:
-        for mode in ("parity", "fast"):
-            _lib.check(lib.cwm_debug_set(b"ln_fuse", 1))   # the fold state is allocated at model creation, only while the switch is on
-            m = build(cfg, seed, mode=mode)
-            G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
-            xp = G._preprocess(x.cuda())
-            y_first = m(xp, mask.cuda()).cpu()              # (creates the library handle with the switch on)
-            _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
-            y0 = m(xp, mask.cuda()).cpu()
-            _lib.check(lib.cwm_debug_set(b"ln_fuse", 1))
-            ys = {}
-            for tile in ((0, 1, 4) if cfg_name is None else (0,)):
-                _lib.check(lib.cwm_debug_set(b"gemm_tile", tile))
-                ys[tile] = m(xp, mask.cuda()).cpu()
-                err = (ys[tile] - y0).abs().max().item()
-                print(f"[ln fold {name} {mode} tile {tile}] fused vs stand-alone LayerNorm: {err:.2e}")
-                assert err <= (1e-4 if mode == "parity" else 6e-2), (mode, tile, err)
-            _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
-            assert torch.equal(m(xp, mask.cuda()).cpu(), ys[0])   # deterministic
-            if mode == "parity":
-                assert np.abs(ys[0].numpy() - g["y_tokens"]).max() <= (2e-4 if cfg_name is None else PARITY_TOL)
-            # a re-loaded LayerNorm weight must reach the folded copies
-            if cfg_name is None:
-                sd = m.state_dict()
-                sd["encoder.blocks.0.norm1.weight"] = sd["encoder.blocks.0.norm1.weight"] * 1.5
-                sd["decoder.norm.bias"] = sd["decoder.norm.bias"] + 0.25
-                m.load_state_dict(sd)
-                y_new = m(xp, mask.cuda()).cpu()
-                _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
-                y_new0 = m(xp, mask.cuda()).cpu()
-                assert (y_new - ys[0]).abs().max().item() > 1e-3
-                assert (y_new - y_new0).abs().max().item() <= (1e-4 if mode == "parity" else 6e-2)
-    finally:
-        _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
-        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
 
 
 def test_nothing_masked_returns_all_tokens():
@@ -317,11 +268,10 @@ def test_nothing_masked_returns_all_tokens():
 
 def test_last_decoder_block_pruning_is_exact():
     """The last decoder block computes queries / proj / MLP only for the Nm rows the head reads (vmae.py:250-251 discards the rest):
-    outputs are bit-identical to running the block in full, for the tiny model and for B/8 (both modes).  (Bitwise with the stand-alone
-    LayerNorm kernels and without split-K -- the pruned GEMMs have fewer rows, so the small-launch heuristic may split K differently and
-    re-associate the fp32 sums; with the LayerNorm fold the un-pruned run normalises its non-compact final rows with the stand-alone
-    kernel; and with every attention tile on the regular schedule: pruning changes WHICH query rows form the ragged last tile, whose
-    key-split schedule (attention_tail.h) rounds P at other values.  In those configurations the two agree to rounding.)"""
+    outputs are bit-identical to running the block in full, for the tiny model and for B/8 (both modes).  (Bitwise without split-K --
+    the pruned GEMMs have fewer rows, so the small-launch heuristic may split K differently and re-associate the fp32 sums -- and with
+    every attention tile on the regular schedule: pruning changes WHICH query rows form the ragged last tile, whose key-split
+    schedule (attention_tail.h) rounds P at other values.  In the default configuration the two agree to rounding.)"""
     lib = _lib.get_lib()
     cases = [(TINY, "tiny_8x8_k4.npz"), (C.CONFIGS["base_8x8patch_2frames_1tube"], "base8_k8_b2.npz")]
     try:
@@ -331,23 +281,14 @@ def test_last_decoder_block_pruning_is_exact():
             g = np.load(os.path.join(GOLDEN, name))
             seed, x, mask = case_inputs(g, cfg)
             for mode in ("parity", "fast"):
-                _lib.check(lib.cwm_debug_set(b"ln_fuse", 1))   # fold state exists only in models created with the switch on
                 m = build(cfg, seed, mode)
                 G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
-                m(G._preprocess(x.cuda()), mask.cuda())
-                for fuse in (0, 1):
-                    _lib.check(lib.cwm_debug_set(b"ln_fuse", fuse))
-                    outs = []
-                    for prune in (1, 0):
-                        _lib.check(lib.cwm_debug_set(b"prune_last_block", prune))
-                        outs.append(m(G._preprocess(x.cuda()), mask.cuda()).cpu())
-                    diff = (outs[0] - outs[1]).abs().max().item()
-                    if fuse == 0:
-                        assert torch.equal(outs[0], outs[1]), (name, mode, diff)
-                    else:
-                        assert diff <= (1e-4 if mode == "parity" else 3e-2), (name, mode, diff)
+                outs = []
+                for prune in (1, 0):
+                    _lib.check(lib.cwm_debug_set(b"prune_last_block", prune))
+                    outs.append(m(G._preprocess(x.cuda()), mask.cuda()).cpu())
+                assert torch.equal(outs[0], outs[1]), (name, mode, (outs[0] - outs[1]).abs().max().item())
         _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
-        _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
         _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
         for cfg, name in cases:  # library defaults (split-K where the heuristic takes it, key-split attention tails): equal to rounding
             g = np.load(os.path.join(GOLDEN, name))
@@ -361,7 +302,6 @@ def test_last_decoder_block_pruning_is_exact():
             assert (outs[0] - outs[1]).abs().max().item() <= 5e-5
     finally:
         _lib.check(lib.cwm_debug_set(b"prune_last_block", 1))
-        _lib.check(lib.cwm_debug_set(b"ln_fuse", 0))
         _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
         _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
 

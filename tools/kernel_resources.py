@@ -32,7 +32,10 @@ def resources(src, extra=()):
     with tempfile.TemporaryDirectory() as td:
         cmd = [build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Rpass-analysis=kernel-resource-usage", *extra, "-c",
                os.path.join(build.CSRC, src), "-o", os.path.join(td, "o.o")]
-        err = subprocess.run(cmd, capture_output=True, text=True).stderr
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        err = res.stderr
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, err[-3000:]))
     rows, cur = [], None
     for line in err.split("\n"):
         m = re.search(r"Function Name: (\S+)", line)

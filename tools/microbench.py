@@ -82,7 +82,7 @@ def main():
         for name, B, H, N in ATTN_SHAPES:
             for mode in ("fast", "parity"):
                 row = []
-                for kern in [int(v) for v in os.environ.get("ATTN_KERNELS", "1,2,3").split(",")]:
+                for kern in [int(v) for v in os.environ.get("ATTN_KERNELS", "1,3").split(",")]:
                     _lib.check(lib.cwm_debug_set(b"attn_kernel", kern))
                     best = 1e30
                     for _ in range(3):
