@@ -64,19 +64,32 @@ def timed_steps(G, x, mask, n_vis, steps, distributed):
     return dt
 
 
-def pmc_traffic(args, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (separate FETCH_SIZE /
-    WRITE_SIZE runs, gfx950 corrections applied: tools/summarize_profiles.py -> profiles/pmc_summary_latest.json); None if the
-    summary is absent or was taken for another workload / mode.  (The counters cannot be read from inside this process.)"""
+def pmc_profile(workload, mode, kernel):
+    """(HBM bytes per launch, MFMA-busy fraction, tag) of `kernel` from the committed rocprofv3 PMC passes of this same command on one
+    lane (separate FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES runs, gfx950 corrections applied: tools/summarize_profiles.py ->
+    profiles/pmc_summary_latest.json, one entry per workload / mode); Nones if there is no entry.  (The counters cannot be read from
+    inside this process.)"""
     path = os.path.join(ROOT, "profiles", "pmc_summary_latest.json")
     try:
         with open(path) as f:
-            summ = json.load(f)
-        if summ.get("workload") != args.workload or summ.get("mode") != args.mode:
-            return None, None
-        return summ["hbm_bytes_per_launch"].get(kernel), summ.get("tag")
-    except (OSError, KeyError, ValueError):
-        return None, None
+            entry = json.load(f)["entries"]["%s/%s" % (workload, mode)]
+        return entry["hbm_bytes_per_launch"].get(kernel), entry.get("mfma_busy", {}).get(kernel), entry.get("tag")
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None, None
+
+
+def profile_fields(workload, mode, kernel, frac):
+    """The roofline fields that come from the committed profile of this command, and the executed-work fraction."""
+    traffic, busy, tag = pmc_profile(workload, mode, kernel)
+    return {
+        "traffic": traffic, "mfma_busy": busy,
+        "executed_frac": (3.0 if mode == "parity" else 1.0) * frac,
+        "from_profile": {"tag": tag, "note": "traffic (HBM bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction) and mfma_busy "
+                                             "(SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)) are the committed rocprofv3 PMC passes of this "
+                                             "command on one lane (profiles/<tag>_pmc_summary.json); the counters cannot be read inside this process, so "
+                                             "they are the profile's numbers, not measurements of this run.  executed_frac = frac x the MFMA products per "
+                                             "algorithmic product (3 in parity mode)"},
+    }
 
 
 def edge_kernels(collect):
@@ -228,6 +241,8 @@ def run_imu(args, rank, local_rank, world, distributed):
 
     step()
     model.set_lanes(args.lanes)
+    if os.environ.get("CWM_CONJ_CTX_STREAM") == "0":  # profiling runs: the context stream's launches on the lane's own stream, so that no two
+        _lib.check(_lib.get_lib().cwm_debug_set(b"conj_ctx_stream", 0))  # kernels overlap and per-kernel durations mean what they say
     for _ in range(max(args.warmup, 1)):
         step()
     dt = region()
@@ -264,9 +279,12 @@ def run_imu(args, rank, local_rank, world, distributed):
                 "avg_launch_us": 1e3 * st["total_ms"] / max(st["launches"], 1), "share_of_step": st["total_ms"] / (1e3 * dt_one) if dt_one > 0 else None}
 
     dom = max(("gemm_wide", "gemm_narrow", "attention"), key=lambda k: stats[k]["total_ms"])
-    names = {"gemm_wide": "cwm::gemm8p_kernel", "gemm_narrow": "cwm::gemm_bf16_kernel<128x128>", "attention": "cwm::attention_pipe_kernel",
+    planes = 2 if args.mode == "parity" else 1
+    names = {"gemm_wide": "cwm::gemm8p_kernel<%d>" % planes, "gemm_narrow": "cwm::gemm_bf16_kernel<%d, 128, 128, 2, 4, 2>" % planes,
+             "attention": "cwm::attention_%s" % ("pipe_kernel<2, 4>" if planes == 2 else "kernel<1>"),
              "cross_attention": "cwm::cross_attn_mfma_kernel (+ combine)", "context_self_attention": "cwm::small_attn_mfma_kernel"}
-    out["roofline"] = dict(entry(stats[dom]), bound="mfma", kernel=names[dom], traffic=None, edge_kernels=edge,
+    dom_entry = entry(stats[dom])
+    out["roofline"] = dict(dom_entry, bound="mfma", kernel=names[dom], edge_kernels=edge, **profile_fields("imu4", args.mode, names[dom], dom_entry["frac"]),
                            region={"lanes": 1, "steps": args.steps, "ms_per_step": 1e3 * dt_one / args.steps, "value": B * n_gpus * args.steps / dt_one},
                            note="algorithmic FLOPs of the class's launches / their summed HIP-event durations in a one-lane kernel region (rank 0)",
                            other_kernel={names[k]: entry(v) for k, v in stats.items() if k != dom})
@@ -277,14 +295,41 @@ def run_imu(args, rank, local_rank, world, distributed):
         print(json.dumps(out))
 
 
+def count_gpus_without_hip():
+    """GPUs of this box from the KFD topology in sysfs (nodes with SIMDs), without a HIP call: torch.cuda.device_count() falls through to
+    hipGetDeviceCount on ROCm builds without amdsmi, which initialises the runtime in the caller.  *_VISIBLE_DEVICES lists cap the count.
+    None if sysfs has no topology (then the caller may still ask torch)."""
+    import glob
+
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for path in nodes:
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks with torch.distributed.run as a CHILD
-    process -- nothing in this process has touched the GPU yet (counting devices does not initialise it), and the parent only relays
-    the child's output and exit code.  Fails loudly when the box has fewer than N GPUs: a line must never claim more GPUs than it ran on."""
+    process -- the parent only counts the GPUs (from sysfs, no HIP call), relays the child's output and exit code; the ranks are always
+    fresh processes.  Fails loudly when the box has fewer than N GPUs: a line must never claim more GPUs than it ran on."""
     import socket
     import subprocess
 
-    have = torch.cuda.device_count()
+    have = count_gpus_without_hip()
+    if have is None:
+        have = torch.cuda.device_count()
     if have < args.gpus and os.environ.get("CWM_BENCH_ONE_DEVICE") != "1":
         sys.stderr.write("bench.py: --gpus %d requested but this box has %d GPU(s); refusing to measure fewer GPUs than asked for\n" % (args.gpus, have))
         return 2
@@ -410,37 +455,37 @@ def main():
         "model_frac_of_bf16_peak": flops_pair * value / 1e12 / (PEAK_BF16_TFLOPS * n_gpus),
     }
     planes = 2 if args.mode == "parity" else 1
-    kernels = {
-        "cwm::gemm8p_kernel<%d, 0>" % planes: gemm_wide,                           # 256x256 8-phase: encoder qkv, fc1, fc2 rounds
-        "cwm::gemm_bf16_kernel<%d, 128, 128, 2, 4, 2, 0>" % planes: gemm_narrow,  # 128x128, 8 waves: proj, every K < 512 GEMM, remainders
+    kernels = {  # (names as rocprofv3 prints them)
+        "cwm::gemm8p_kernel<%d>" % planes: gemm_wide,                          # 256x256 8-phase: qkv, fc1, whole rounds of fc2
+        "cwm::gemm_bf16_kernel<%d, 128, 128, 2, 4, 2>" % planes: gemm_narrow,  # 128x128, 8 waves: proj, narrow outputs, remainders
+        "cwm::attention_%s" % ("pipe_kernel<2, 4>" if planes == 2 else "kernel<1>"): attn,   # softmax(q k^T) v
     }
 
     def tflops(st):
         return st["total_flops"] / (st["total_ms"] * 1e-3) / 1e12 if st["total_ms"] > 0 else 0.0
 
-    dom = max(kernels, key=lambda k: kernels[k]["total_ms"])  # dominant kernel = most device time in the timed region
+    def kentry(k, v):
+        tf = tflops(v)
+        return dict({"achieved": tf, "frac": tf / PEAK_BF16_TFLOPS, "launches": v["launches"], "avg_launch_us": 1e3 * v["total_ms"] / max(v["launches"], 1),
+                     "share_of_step": v["total_ms"] / (1e3 * dt_one) if dt_one > 0 else None}, **profile_fields(args.workload, args.mode, k, tf / PEAK_BF16_TFLOPS))
+
+    dom = max(kernels, key=lambda k: kernels[k]["total_ms"])  # dominant kernel = most device time in the kernel region (attention included)
     st = kernels[dom]
     ach = tflops(st)
-    traffic, traffic_tag = pmc_traffic(args, dom)
     out["roofline"] = {
         "bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-        "traffic": traffic,
-        "traffic_from_profile": {"bytes_per_launch": traffic, "tag": traffic_tag,
-                                 "note": "HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/<tag>_pmc_summary.json: separate "
-                                         "FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections); the counters cannot be read inside this process, so this "
-                                         "is the profile's number, not a measurement of this run"},
+        **profile_fields(args.workload, args.mode, dom, ach / PEAK_BF16_TFLOPS),
         "edge_kernels": edge,
         "launches": st["launches"], "avg_launch_us": 1e3 * st["total_ms"] / max(st["launches"], 1),
         "share_of_step": st["total_ms"] / (1e3 * dt_one) if dt_one > 0 else None,
         "region": {"lanes": 1, "steps": args.steps, "ms_per_step": 1e3 * dt_one / args.steps, "value": B * n_gpus * args.steps / dt_one,
-                   "note": "kernel region: the same steps as the timed region, one lane, HIP events around every GEMM launch"},
-        "note": "algorithmic 2*M*N*K of this kernel's launches in the kernel region / their summed HIP-event durations (rank 0)"
-                + ("; parity mode executes 3x these FLOPs on the MFMA pipe" if args.mode == "parity" else ""),
+                   "note": "kernel region: the same steps as the timed region, one lane, HIP events around every GEMM / attention launch"},
+        "note": "algorithmic FLOPs (2*M*N*K per GEMM launch, 4*N^2*64 per (batch, head) of an attention launch) of this kernel's launches in the "
+                "kernel region / their summed HIP-event durations (rank 0)"
+                + ("; parity mode executes 3x these FLOPs on the MFMA pipe (executed_frac)" if args.mode == "parity" else ""),
         "all_gemm": {"achieved": tflops(gemm), "launches": gemm["launches"], "avg_launch_us": 1e3 * gemm["total_ms"] / max(gemm["launches"], 1),
                      "share_of_step": gemm["total_ms"] / (1e3 * dt_one) if dt_one > 0 else None},
-        "other_kernel": {k: {"achieved": tflops(v), "launches": v["launches"], "avg_launch_us": 1e3 * v["total_ms"] / max(v["launches"], 1),
-                             "share_of_step": v["total_ms"] / (1e3 * dt_one) if dt_one > 0 else None}
-                         for k, v in list(kernels.items()) + [("cwm::attention_%s" % ("pipe_kernel<2, 4>" if planes == 2 else "kernel<1>"), attn)] if k != dom},
+        "other_kernel": {k: kentry(k, v) for k, v in kernels.items() if k != dom},
     }
 
     if not args.no_secondary:

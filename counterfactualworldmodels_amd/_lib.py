@@ -112,6 +112,7 @@ class CwmConjForwardArgs(C.Structure):
         ("mode", C.c_int32),
         ("check", C.c_int32),
         ("stream", C.c_void_p),
+        ("y_ctx_tokens_dev", C.c_void_p),
     ]
 
 

@@ -211,8 +211,14 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
         """`n_vis` / `n_vis_context`: the caller knows that every row of `mask` / `mask_context` has exactly this many visible
         tokens (a rectangularised batch; `mask_context=None` means all visible): skips the host read-back of the row counts."""
         _lib.require_gpu()
-        if output_context or (output_main is False):
-            raise NotImplementedError("only the main-stream output (the configuration the demos use) is implemented")
+        # `_set_decoder_outputs` (conjoined_vmae.py:589-593): a flag that is given replaces the model's setting and STAYS replaced
+        if output_main is not None:
+            self._output_main = bool(output_main)
+        if output_context is not None:
+            self._output_context = bool(output_context)
+        want_main, want_ctx = self._output_main, self._output_context
+        if not want_main and not want_ctx:  # "return all the tokens from both streams" (:1010-1011): the same tuple in the padded model
+            want_main = want_ctx = True
         if x_context is None:
             raise RuntimeError("the IMU-conditioned predictor needs x_context [B,%d,%d]" % (self.cfg.ctx_in_chans, self.cfg.ctx_seq_len))
         if not x.is_cuda:
@@ -249,13 +255,17 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
             raise RuntimeError("every stream needs at least one visible token")
         n_out = Nt + c.main_max_pad - vmax
         y = torch.empty((B, n_out, m.out_dim), device=dev, dtype=torch.float32)
+        # the context stream's predictions: head(norm(x_c[:, -n:])) * ~null_mask over its masked + pad slots (conjoined_vmae.py:990-1002)
+        y_ctx = torch.empty((B, c.ctx_tokens + c.ctx_max_pad - vcmax, c.ctx_out_dim), device=dev, dtype=torch.float32) if want_ctx else None
         args_ = _lib.CwmConjForwardArgs(
             x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), int(normalize), mask.data_ptr(), B, vmax, ctx.data_ptr(), mc.data_ptr(),
-            vcmax, y.data_ptr(), _lib.mode_id(self.mode), int(check), _lib.current_stream_handle(dev))
+            vcmax, y.data_ptr(), _lib.mode_id(self.mode), int(check), _lib.current_stream_handle(dev), _lib.ptr(y_ctx))
         with torch.cuda.device(dev):
             _lib.check(_lib.get_lib().cwm_conj_forward(self._handle, C.byref(args_)))
         self._record_padding_state(mask, vis, vmax, mc, vis_c, vcmax)
-        return y
+        if want_main and want_ctx:
+            return y, y_ctx
+        return y if want_main else y_ctx
 
     def _record_padding_state(self, mask, vis, vmax, mask_ctx=None, vis_ctx=None, vmax_ctx=None):
         """The padding attributes the reference leaves set on BOTH streams after a forward until the wrapper resets them

@@ -535,6 +535,21 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
                 (rc = run_cross(L, m->dec_cross[k], A.x_dec, Nx, A.dec_dim, S.x_dec, Mx, S.dec_dim, B, planes, s, sc, m->ev_cross[lane], have_prev)))
                 return rc;
     }
+    // context output (forward(..., output_context=True), conjoined_decode :990-1002): head_ctx(norm_ctx(x_c[:, -n_out_c:])) * ~null_mask_ctx
+    if (a->y_ctx_tokens_dev) {
+        const int n_out_c = Mx - vc;
+        float* y_ctx = a->y_ctx_tokens_dev + (size_t)b0 * n_out_c * S.out_dim;
+        LayerNormParams lc;
+        memset(&lc, 0, sizeof(lc));
+        lc.x = S.x_dec; lc.ldx = S.dec_dim; lc.gamma = S.dec_norm_g; lc.beta = S.dec_norm_b; lc.eps = E.ln_eps; lc.D = S.dec_dim;
+        lc.rows = B * n_out_c; lc.rows_out_per_b = n_out_c; lc.rows_in_per_b = Mx; lc.in_offset = vc;
+        lc.out = S.sb.hbuf; lc.out_plane = (int64_t)B * n_out_c * S.dec_dim; lc.ldo = S.dec_dim;
+        if ((rc = E.run_layernorm(lc, planes, sc))) return rc;
+        GemmParams gc = gemm_base(S.sb.hbuf, S.dec_dim, S.head, B * n_out_c, planes);
+        gc.epi = EPI_F32; gc.C = y_ctx; gc.ldc = S.out_dim;
+        if ((rc = E.run_gemm(gc, planes, sc))) return rc;
+        if ((rc = launch_zero_pad_out_rows(y_ctx, S.perm, B, Mx, vc, n_out_c, S.n_tok, S.out_dim, sc))) return rc;
+    }
     if ((rc = main_follows_ctx())) return rc;  // the call's stream semantics cover the context stream's work too
 
     // main output: head(norm(x[:, -n_out:])) * ~null_mask   (conjoined_decode :984-1002)

@@ -133,6 +133,10 @@ typedef struct cwm_conj_forward_args {
     int32_t mode;
     int32_t check;
     void* stream;
+    /* optional (NULL: not computed): the context stream's predictions, out [B, ctx tokens + ctx_max_pad - n_vis_ctx_max, ctx_in_chans*ctx_tubelet],
+     * rows at masked pad slots are 0 -- `forward(..., output_context=True)` returns it, alone or in a tuple with y_tokens
+     * (conjoined_vmae.py:852-887, 990-1011) */
+    float* y_ctx_tokens_dev;
 } cwm_conj_forward_args;
 
 /* replaces: `self.predictor(self._preprocess(x), mask, x_context=..., mask_context=...)` (prediction.py:419-422) */

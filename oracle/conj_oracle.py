@@ -121,15 +121,17 @@ def imu_tokenize(W, spec: ConjSpec, imu_bcl: torch.Tensor, pre: str = "context_s
 # ----------------------------------------------------------------------------------------------
 # a17: the whole model
 # ----------------------------------------------------------------------------------------------
-def conj_forward(W: Dict[str, torch.Tensor], spec: ConjSpec, x_bcthw, mask, x_context, mask_context):
+def conj_forward(W: Dict[str, torch.Tensor], spec: ConjSpec, x_bcthw, mask, x_context, mask_context, output_context: bool = False):
     """x: [B,3,2,H,W] (what the wrapper's `_preprocess` hands the model), mask: bool [B,Nt],
     x_context: [B,6,L], mask_context: bool [B,L/16].  Returns the main-stream output
-    [B, Nt + P - vmax, 3*P*P] with rows at masked pad slots zeroed (conjoined_vmae.py:998-1002)."""
+    [B, Nt + P - vmax, 3*P*P] with rows at masked pad slots zeroed (conjoined_vmae.py:998-1002); with `output_context` the tuple
+    (main, context) of `forward(..., output_main=True, output_context=True)` (:990-1006): the context stream's head over ITS masked +
+    pad slots, [B, L/16 + Pc - vmax_c, 6*16], pad rows zeroed the same way."""
     mask, mask_context = mask.bool(), mask_context.bool()
     ms, B = spec.main, x_bcthw.shape[0]
     P, Pc = spec.main_max_pad, spec.ctx_max_pad
     full, null = padding_masks(mask, P)
-    full_c, _ = padding_masks(mask_context, Pc)
+    full_c, null_c = padding_masks(mask_context, Pc)
 
     # tokenise + pad + gather (pad_and_mask_input :125-134)
     m = "main_stream."
@@ -167,7 +169,12 @@ def conj_forward(W: Dict[str, torch.Tensor], spec: ConjSpec, x_bcthw, mask, x_co
         if i in spec.dec_cross:
             x, s = cross_block(x, s, W, f"decoder_conjoining_blocks.{i}-{i}.", spec.cross_heads)
     y = F.linear(_ln(x[:, -n_masked:], W, m + "decoder.norm."), W[m + "decoder.head.weight"], W[m + "decoder.head.bias"])
-    return y * (~null)[..., None].to(y)
+    y = y * (~null)[..., None].to(y)
+    if not output_context:
+        return y
+    n_masked_c = int(full_c[0].sum())
+    y_c = F.linear(_ln(s[:, -n_masked_c:], W, c + "decoder.norm."), W[c + "decoder.head.weight"], W[c + "decoder.head.bias"])
+    return y, y_c * (~null_c)[..., None].to(y_c)
 
 
 def predict(W, spec: ConjSpec, x_btchw, mask, x_context, mask_context, normalize: bool = True, frame=-1):

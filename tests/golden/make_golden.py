@@ -93,7 +93,7 @@ def run_model_case(ns, cfg, *, batch, k_vis, clump, seed, out_name, through_wrap
             std = torch.tensor(C.IMAGENET_STD).view(1, 3, 1, 1, 1)
             y_model = m((x.transpose(1, 2) - mean) / std, mask.clone())
     out["y_tokens"] = y_model.numpy()
-    if cfg.name == "tiny_8x8":
+    if cfg.name.startswith("tiny_"):
         out["x"] = x.numpy()
     np.savez_compressed(os.path.join(HERE, out_name), **out)
     print(f"[golden] {out_name}: y {tuple(y_model.shape)} std {y_model.std():.4f} ({time.time() - t0:.1f}s)")
@@ -525,6 +525,113 @@ def run_sharp_cases(ns, skip_large=False):
     print(f"[golden] conj_imu400_sharp_b1.npz {tuple(y.shape)} std {y.std():.4f} ({time.time() - t0:.1f}s)")
 
 
+TINY16 = C.VmaeConfig(name="tiny_16x16", img_size=(64, 64), patch=16, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=1, dec_heads=2)
+
+
+def run_round4_cases(ns, skip_large=False):
+    """Round 4 (VERDICT r3 "next" item 4): the surface holes, every output produced by the reference.
+    (a) P = 16: `base_16x16patch_2frames_1tube` (vmae.py:597-603) at full size and a tiny 16x16-patch model;
+    (b) the conjoined model's context-stream output: `forward(..., output_context=True)` -> (x, x_c) and output_main=False -> x_c
+        (conjoined_vmae.py:852-887, 990-1011), tiny (ragged visible counts, masked context tokens) and full size;
+    (c) BASELINE configs[3] at full size: the reference's own prompt construction over all 256 synthetic prompts (one rectangularisation,
+        torch seed 3) and its `predict` on three of them -- the first, the last and the first whose shift leaves the frame."""
+    # ---- (a) ------------------------------------------------------------------------------------------------------------
+    run_model_case(ns, TINY16, batch=2, k_vis=3, clump=1, seed=8, out_name="tiny_16x16_k3.npz")
+    run_model_case(ns, C.CONFIGS["base_16x16patch_2frames_1tube"], batch=2, k_vis=8, clump=1, seed=0, out_name="base16_k8_b2.npz")
+
+    # ---- (b) tiny: the inputs of conj_tiny.npz (B = 3, ragged visible counts, two rows with masked context tokens) -----------
+    cfg = TINY_CONJ
+    m = build_ref_conj(ns, cfg, 5)
+    g = np.random.Generator(np.random.PCG64(2))
+    B, n = 3, cfg.main.tokens_per_frame
+    x = torch.from_numpy(g.random((B, 2, 3, 32, 32), dtype=np.float32))
+    mask = torch.zeros(B, 2 * n, dtype=torch.bool)
+    mask[:, n:] = True
+    for b, vis in enumerate(([3, 9], [5], [6, 7, 16])):
+        mask[b, [n + v for v in vis]] = False
+    imu = torch.from_numpy((g.standard_normal((B, 6, cfg.ctx_seq_len)) * 0.1).astype(np.float32))
+    mc = torch.zeros(B, cfg.ctx_tokens, dtype=torch.bool)
+    mc[0, 1] = True
+    mc[1, 0] = True
+    mc[1, 3] = True
+    G = ns.prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2, seed=0)
+    out = {"x": x.numpy(), "mask": mask.numpy(), "imu": imu.numpy(), "mask_context": mc.numpy(), "seed": np.array(5)}
+    with torch.no_grad():
+        m._reset_padding_mask()
+        y, y_c = m(G._preprocess(x), mask.clone(), x_context=imu, mask_context=mc, output_main=True, output_context=True)
+        out["y_tokens"], out["y_ctx_tokens"] = y.numpy(), y_c.numpy()
+        out["ctx_null_mask"] = m.context_stream.null_mask.numpy()
+        m._reset_padding_mask()
+        y_c2 = m(G._preprocess(x), mask.clone(), x_context=imu, mask_context=mc, output_main=False, output_context=True)
+        assert torch.is_tensor(y_c2) and torch.equal(y_c2, y_c)
+        m._reset_padding_mask()
+        # the flags are sticky (`_set_decoder_outputs`, :589-593): a call without them still returns the context output alone
+        y_c3 = m(G._preprocess(x), mask.clone(), x_context=imu, mask_context=mc)
+        assert torch.is_tensor(y_c3) and torch.equal(y_c3, y_c)
+        m._reset_padding_mask()
+        both = m(G._preprocess(x), mask.clone(), x_context=imu, mask_context=mc, output_main=False, output_context=False)
+        assert isinstance(both, tuple) and torch.equal(both[0], y) and torch.equal(both[1], y_c)   # "all the tokens from both streams"
+    np.savez_compressed(os.path.join(HERE, "conj_tiny_ctx.npz"), **out)
+    print("[golden] conj_tiny_ctx.npz", out["y_tokens"].shape, out["y_ctx_tokens"].shape)
+
+    # ---- (c) 256 prompts on one frame pair: prompt construction by the reference, predict on three rows ------------------------
+    class DummyFlow(torch.nn.Module):
+        def forward(self, x, *a, **k):
+            return torch.zeros(x.shape[0], x.shape[1] - 1, 2, *x.shape[-2:])
+
+    cfg8 = C.CONFIGS["base_8x8patch_2frames_1tube"]
+    t0 = time.time()
+    mref = build_ref_model(ns, cfg8, 0)
+    Gf = ns.segmentation.FlowGenerator(predictor=mref, flow_model=DummyFlow(), imagenet_normalize_inputs=True, temporal_dim=2, seed=0)
+    table = S.synthetic_prompts(256, cfg8, 0)
+    n8, gw = cfg8.tokens_per_frame, cfg8.img_size[1] // cfg8.patch
+    x0 = torch.from_numpy(S.synthetic_frames(1, cfg8, 0))[:, 0:1]
+    xs = x0.expand(-1, 2, -1, -1, -1).clone()          # make_static_movie: frame 1 := frame 0 (prediction.py:731-739)
+    Sn = table.shape[0]
+    active = torch.ones(1, 2 * n8, Sn, dtype=torch.bool)
+    active[:, :n8] = False
+    active[0, n8 + torch.from_numpy(table[:, 0].astype(np.int64)) * gw + torch.from_numpy(table[:, 1].astype(np.int64)), torch.arange(Sn)] = False
+    passive = torch.ones(1, 2 * n8, Sn, dtype=torch.bool)
+    passive[:, :n8] = False
+    Gf.set_input(xs)
+    Gf.shifter.set_shapes(xs, mask=active[..., 0])
+    torch.manual_seed(3)
+    x_shift, mask_post = Gf.create_motion_counterfactuals(xs, masks=passive, active_patches=active, shifts=[[int(v[2]), int(v[3])] for v in table],
+                                                          num_samples=Sn, fix_passive=False, reset_shifts=True)
+    dest = table[:, 0:2] + table[:, 2:4]
+    oob = np.nonzero((dest < 0).any(1) | (dest[:, 0] >= cfg8.img_size[0] // cfg8.patch) | (dest[:, 1] >= gw))[0]
+    rows = [0, int(oob[0]), Sn - 1]
+    ys = []
+    with torch.no_grad():
+        for r in rows:
+            ys.append(Gf.predict(x_shift[r:r + 1], mask_post[r:r + 1].clone(), frame=-1))
+    ys = torch.cat(ys, 0)
+    np.savez_compressed(os.path.join(HERE, "prompts256_rows.npz"), rows=np.array(rows), mask_post_rows=mask_post[rows].numpy(),
+                        n_masked=mask_post.sum(-1).numpy().astype(np.int32), mask_post_digest=np.array([int(mask_post.sum()),
+                        int((mask_post * torch.arange(mask_post.shape[1])[None]).sum())]), y_rows_even=ys[:, :, :, ::2].numpy().copy(),
+                        seed=np.array(3))
+    print(f"[golden] prompts256_rows.npz rows {rows} y {tuple(ys.shape)} ({time.time() - t0:.1f}s)")
+    if skip_large:
+        return
+    # ---- (b) full size: B = 1, three masked context tokens ------------------------------------------------------------------
+    cfgc = C.CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"]
+    t0 = time.time()
+    m = build_ref_conj(ns, cfgc, 0)
+    x = torch.from_numpy(S.synthetic_frames(1, cfgc.main, 6))
+    mask = torch.from_numpy(S.synthetic_masks(1, cfgc.main, 4, 6))
+    imu = torch.from_numpy((np.random.Generator(np.random.PCG64(13)).standard_normal((1, 6, 400)) * 0.1).astype(np.float32))
+    mc = torch.zeros(1, 25, dtype=torch.bool)
+    mc[0, [2, 11, 24]] = True
+    mean = torch.tensor(C.IMAGENET_MEAN).view(1, 3, 1, 1, 1)
+    std = torch.tensor(C.IMAGENET_STD).view(1, 3, 1, 1, 1)
+    with torch.no_grad():
+        y, y_c = m((x.transpose(1, 2) - mean) / std, mask.clone(), x_context=imu, mask_context=mc, output_main=True, output_context=True)
+    np.savez_compressed(os.path.join(HERE, "conj_imu400_ctx_b1.npz"), mask=mask.numpy(), imu=imu.numpy(), mask_context=mc.numpy(),
+                        y_ctx_tokens=y_c.numpy(), y_tokens_digest=np.array([y.double().sum().item(), y.double().abs().sum().item()]),
+                        y_tokens_head=y[:, :8].numpy().copy(), seed=np.array(0), frames_seed=np.array(6))
+    print(f"[golden] conj_imu400_ctx_b1.npz y_ctx {tuple(y_c.shape)} std {y_c.std():.4f} ({time.time() - t0:.1f}s)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-large", action="store_true")
@@ -553,6 +660,9 @@ def main():
     if args.only == "sharp":
         run_sharp_cases(ns, args.skip_large)
         return
+    if args.only == "r4":
+        run_round4_cases(ns, args.skip_large)
+        return
     run_init_case(ns)
     run_flowstats_case(ns)
     run_shift_cases(ns)
@@ -568,6 +678,7 @@ def main():
     run_model_case(ns, base, batch=2, k_vis=8, clump=1, seed=0, out_name="base8_k8_b2.npz")
     run_model_case(ns, base, batch=1, k_vis=1, clump=1, seed=1, out_name="base8_k1_b1.npz")
     run_sharp_cases(ns, args.skip_large)
+    run_round4_cases(ns, args.skip_large)
     if not args.skip_large:
         large = C.CONFIGS["large_4x4patch_2frames_1tube"]
         run_model_case(ns, large, batch=1, k_vis=32, clump=2, seed=0, out_name="large4_k32_b1.npz",

@@ -86,6 +86,48 @@ def test_imu400_sharp_weights_golden():
     assert np.array_equal(np.abs(y).sum(-1) == 0, np.abs(g["y_tokens"]).sum(-1) == 0)
 
 
+def test_context_stream_output_goldens():
+    """`forward(..., output_context=True)` (conjoined_vmae.py:852-887, 990-1011): the context stream's predictions over its masked + pad
+    slots, alone or in a tuple with the main output, against the reference (tiny model: ragged visible counts, masked IMU tokens; full
+    size: three masked IMU tokens); the flags are sticky like the reference's `_set_decoder_outputs` (:589-593)."""
+    g = np.load(os.path.join(GOLDEN, "conj_tiny_ctx.npz"))
+    m = build(TINY_CONJ, int(g["seed"]))
+    G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+    x, mask, imu, mc = (torch.from_numpy(g[k]).cuda() for k in ("x", "mask", "imu", "mask_context"))
+    xp = G._preprocess(x)
+    y0 = m(xp, mask, x_context=imu, mask_context=mc)                       # default: main output only
+    assert torch.is_tensor(y0)
+    out = m(xp, mask, x_context=imu, mask_context=mc, output_main=True, output_context=True)
+    assert isinstance(out, tuple) and len(out) == 2
+    y, y_c = (t.cpu().numpy() for t in out)
+    assert torch.equal(out[0], y0)
+    assert y.shape == g["y_tokens"].shape and np.abs(y - g["y_tokens"]).max() <= 3e-4
+    assert y_c.shape == g["y_ctx_tokens"].shape and np.abs(y_c - g["y_ctx_tokens"]).max() <= 3e-4
+    assert np.array_equal(np.abs(y_c).sum(-1) == 0, g["ctx_null_mask"])     # zero rows = masked pad slots of the context stream
+    y_c2 = m(xp, mask, x_context=imu, mask_context=mc, output_main=False)    # context alone ...
+    assert torch.is_tensor(y_c2) and torch.equal(y_c2, out[1])
+    y_c3 = m(xp, mask, x_context=imu, mask_context=mc)                      # ... and the setting sticks
+    assert torch.is_tensor(y_c3) and torch.equal(y_c3, out[1])
+    both = m(xp, mask, x_context=imu, mask_context=mc, output_main=False, output_context=False)   # "all the tokens from both streams"
+    assert isinstance(both, tuple) and torch.equal(both[0], out[0]) and torch.equal(both[1], out[1])
+    m(xp, mask, x_context=imu, mask_context=mc, output_main=True)          # back to the default for whoever uses the model next
+    # full size
+    g = np.load(os.path.join(GOLDEN, "conj_imu400_ctx_b1.npz"))
+    cfg = C.CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"]
+    m = build(cfg, int(g["seed"]))
+    x = torch.from_numpy(S.synthetic_frames(1, cfg.main, int(g["frames_seed"])))
+    mask, imu, mc = (torch.from_numpy(g[k]).cuda() for k in ("mask", "imu", "mask_context"))
+    y, y_c = m(V.preprocess(x).cuda(), mask, x_context=imu, mask_context=mc, output_main=True, output_context=True)
+    err = np.abs(y_c.cpu().numpy() - g["y_ctx_tokens"]).max()
+    print(f"[conj ctx output, full size] max-abs vs reference {err:.2e}")
+    assert y_c.shape == (1, 28, 96) and err <= 1e-3
+    assert np.abs(y[:, :8].cpu().numpy() - g["y_tokens_head"]).max() <= 1e-3
+    yd = y.double()
+    assert abs(yd.abs().sum().item() - g["y_tokens_digest"][1]) <= 1e-4 * g["y_tokens_digest"][1]   # (the plain sum cancels: absolute bound)
+    assert abs(yd.sum().item() - g["y_tokens_digest"][0]) <= 1e-4 * yd.numel()
+    assert (y_c[0, 3:] == 0).all()
+
+
 def test_conj_errors():
     m = build(TINY_CONJ, 5)
     x = torch.zeros(2, 3, 2, 32, 32, device="cuda")

@@ -93,6 +93,31 @@ def test_imu400_sharp_weights_vs_reference():
     assert y.shape == g["y_tokens"].shape and err <= 1e-4, err
 
 
+def test_context_output_vs_reference():
+    """`forward(..., output_context=True)` (conjoined_vmae.py:852-887, 990-1011): the context stream's predictions, tiny model with ragged
+    visible counts and masked context tokens, and the full-size model with three masked IMU tokens."""
+    g = np.load(os.path.join(GOLDEN, "conj_tiny_ctx.npz"))
+    W = conj_weights(TINY_CONJ, int(g["seed"]))
+    x, mask, imu, mc = (torch.from_numpy(g[k]) for k in ("x", "mask", "imu", "mask_context"))
+    with torch.no_grad():
+        y, y_c = CO.conj_forward(W, TINY_SPEC, V.preprocess(x), mask, imu, mc, output_context=True)
+    assert y.shape == g["y_tokens"].shape and np.abs(y.numpy() - g["y_tokens"]).max() <= 1e-5
+    assert y_c.shape == g["y_ctx_tokens"].shape == (3, TINY_CONJ.ctx_tokens + TINY_CONJ.ctx_max_pad - 4, TINY_CONJ.ctx_out_dim)
+    assert np.abs(y_c.numpy() - g["y_ctx_tokens"]).max() <= 1e-5
+    assert np.array_equal((y_c.abs().sum(-1) == 0).numpy(), g["ctx_null_mask"])   # zero rows = the masked pad slots, nothing else
+    g = np.load(os.path.join(GOLDEN, "conj_imu400_ctx_b1.npz"))
+    cfg = C.CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"]
+    W = conj_weights(cfg, int(g["seed"]))
+    x = torch.from_numpy(S.synthetic_frames(1, cfg.main, int(g["frames_seed"])))
+    mask, imu, mc = (torch.from_numpy(g[k]) for k in ("mask", "imu", "mask_context"))
+    with torch.no_grad():
+        y, y_c = CO.conj_forward(W, CO.IMU400_BASE_4X4, V.preprocess(x), mask, imu, mc, output_context=True)
+    assert y_c.shape == g["y_ctx_tokens"].shape == (1, 28, 96)
+    assert np.abs(y_c.numpy() - g["y_ctx_tokens"]).max() <= 5e-5
+    assert np.abs(y[:, :8].numpy() - g["y_tokens_head"]).max() <= 5e-5
+    assert (y_c[0, 3:] == 0).all() and (y_c[0, :3].abs().sum(-1) > 0).all()   # 3 masked IMU tokens, then the 25 (masked) pad slots
+
+
 def test_host_mirror_schema_and_attributes():
     from counterfactualworldmodels_amd import conjoined_vmae as CV
 

@@ -161,28 +161,48 @@ def test_weight_sync_signature_sees_every_way_a_parameter_can_change():
     assert not m._params_unchanged()
 
 
-def test_bench_helpers_on_cpu():
-    """bench.py's host-side helpers that do not need a GPU: the committed-profile traffic lookup returns a (bytes, tag) pair for every
-    workload / mode (None, None when the profile is for another command), `--gpus N` without N GPUs and a launcher / flag mismatch exit 2."""
+def test_bench_helpers_on_cpu(tmp_path, monkeypatch):
+    """bench.py's host-side helpers that do not need a GPU: the committed-profile lookup returns (bytes, mfma busy, tag) for every
+    workload / mode (Nones when the profile holds no entry for the command), the executed-work fraction, the GPU count without a HIP call,
+    and `--gpus N` without N GPUs / a launcher-flag mismatch exit 2 -- deterministically, whatever the box has (the children see at
+    most one device)."""
+    import json
     import subprocess
     import sys
-    import types
 
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     import bench
 
-    for wl, mode in (("base8", "parity"), ("base8", "fast"), ("large4", "parity"), ("imu4", "parity")):
-        got = bench.pmc_traffic(types.SimpleNamespace(workload=wl, mode=mode), "cwm::gemm8p_kernel<2, 0>")
-        assert isinstance(got, tuple) and len(got) == 2
-        if (wl, mode) != ("base8", "parity"):
-            assert got == (None, None)
+    for wl, mode in (("base8", "parity"), ("base8", "fast"), ("large4", "parity"), ("imu4", "parity"), ("nope", "parity")):
+        got = bench.pmc_profile(wl, mode, "cwm::gemm8p_kernel<2>")
+        assert isinstance(got, tuple) and len(got) == 3
+        if wl == "nope":
+            assert got == (None, None, None)
+    # the committed summary carries every bench workload in parity mode (VERDICT r3 item 3: no null traffic on the three lines)
+    with open(os.path.join(ROOT, "profiles", "pmc_summary_latest.json")) as f:
+        entries = json.load(f)["entries"]
+    for wl in ("base8", "large4", "imu4"):
+        e = entries["%s/parity" % wl]
+        assert e["hbm_bytes_per_launch"] and all(v > 0 for v in e["hbm_bytes_per_launch"].values()), wl
+        assert e["mfma_busy"] and all(0.0 < v <= 1.0 for v in e["mfma_busy"].values()), wl
+    pf = bench.profile_fields("base8", "parity", "cwm::gemm8p_kernel<2>", 0.18)
+    assert abs(pf["executed_frac"] - 0.54) < 1e-12 and set(pf) == {"traffic", "mfma_busy", "executed_frac", "from_profile"}
+    assert bench.profile_fields("base8", "fast", "x", 0.3)["executed_frac"] == 0.3
     st = {"launches": 4, "total_ms": 0.1, "total_flops": 4 * 155.7e6}
     e = bench.edge_kernels(lambda kc: st if kc == bench._lib.KCLASS_LAYERNORM else {"launches": 0, "total_ms": 0.0, "total_flops": 0.0})
     assert set(e) == {"layernorm_kernel"} and abs(e["layernorm_kernel"]["achieved"] - 6228.0) < 1.0 and e["layernorm_kernel"]["unit"] == "GB/s"
-    env = dict(os.environ)
+    # GPU count from the KFD topology (no HIP call); the *_VISIBLE_DEVICES lists cap it
+    n = bench.count_gpus_without_hip()
+    assert n is None or n >= 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    n1 = bench.count_gpus_without_hip()
+    assert n1 is None or n1 <= 1
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="0", ROCR_VISIBLE_DEVICES="0", CUDA_VISIBLE_DEVICES="0")
     env.pop("WORLD_SIZE", None)
+    env.pop("CWM_BENCH_ONE_DEVICE", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env)
     assert r.returncode == 2 and "refusing" in r.stderr
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="1"))

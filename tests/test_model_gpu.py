@@ -14,6 +14,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TINY = C.VmaeConfig(name="tiny_8x8", img_size=(32, 32), patch=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128,
                     dec_depth=1, dec_heads=2)
 TINY_SPEC = O.VmaeSpec(img_size=(32, 32), patch=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=1, dec_heads=2)
+TINY16 = C.VmaeConfig(name="tiny_16x16", img_size=(64, 64), patch=16, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=1, dec_heads=2)
 PARITY_TOL = 1e-3  # BASELINE.json north_star: outputs within 1e-3 max-abs of the CPU reference
 
 
@@ -79,6 +80,59 @@ def test_base8_golden_parity_and_fast(name):
     # plain bf16 does not meet PARITY_TOL; its floor is 2x the measured error (2.5e-2 / 2.6e-2 on these goldens), so that the `secondary` bench
     # line cannot silently get worse
     assert errf <= 5e-2 and np.abs(yf - g["y_tokens"]).mean() <= 1.5e-2
+
+
+@pytest.mark.parametrize("name,cfg_name", [("tiny_16x16_k3.npz", None), ("base16_k8_b2.npz", "base_16x16patch_2frames_1tube")])
+def test_patch16_goldens(name, cfg_name):
+    """P = 16 on the HIP path (vmae.py:597-603 `base_16x16patch_2frames_1tube`: 392 tokens, patch-embed K = 768, head N = 768; and a tiny
+    16x16-patch model) against the reference's outputs: tokens through the model seam, frames through the fused `predict`."""
+    g = np.load(os.path.join(GOLDEN, name))
+    cfg = TINY16 if cfg_name is None else C.CONFIGS[cfg_name]
+    seed, x, mask = case_inputs(g, cfg)
+    for mode, tol in (("parity", 2e-4 if cfg_name is None else PARITY_TOL), ("fast", 6e-2)):
+        if cfg_name is None:
+            m = build(cfg, seed, mode=mode)
+        else:
+            m = vmae.base_16x16patch_2frames_1tube(mode=mode)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, seed).items()})
+            m = m.to("cuda:0").eval()
+            assert m.patch_size == (1, 16, 16) and m.mask_size == (2, 14, 14)
+        G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+        y = m(G._preprocess(x.cuda()), mask.cuda()).cpu().numpy()
+        err = np.abs(y - g["y_tokens"]).max()
+        print(f"[{name} {mode}] max-abs vs reference {err:.2e}")
+        assert y.shape == g["y_tokens"].shape and err <= tol, (mode, err)
+        video = G.predict(x.cuda(), mask.cuda().clone(), frame=None).cpu()
+        rows = video[:, 1, :, :: max(1, cfg.img_size[0] // 8)].numpy()
+        assert np.abs(rows - g["video_frame1_rows"]).max() <= tol
+        if mode == "parity":
+            v = video.double()
+            assert np.allclose([v.sum().item(), v.abs().sum().item(), (v ** 2).sum().item()], g["video_digest"], rtol=1e-5)
+
+
+def test_checkpoint_file_to_hip_path(tmp_path):
+    """f-3 end to end (prediction.py:81-107): a state-dict saved as `{"model": ...}` .pth, loaded through `predictor_load_path=` into a
+    predictor that held OTHER weights, must reach the packed weights of the library: HIP output = oracle output on the saved weights."""
+    sd = {k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(TINY, 11).items()}
+    path = str(tmp_path / "tiny_ckpt.pth")
+    torch.save({"model": sd, "epoch": 3}, path)
+    m = build(TINY, 12)                                                     # other weights, already packed by a forward
+    x = torch.from_numpy(S.synthetic_frames(2, TINY, 13))
+    mask = torch.from_numpy(S.synthetic_masks(2, TINY, 4, 13))
+    G0 = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+    before = G0.predict(x.cuda(), mask.cuda().clone(), frame=None).cpu()
+    G = prediction.PredictorBasedGenerator(predictor=m, predictor_load_path=path, imagenet_normalize_inputs=True, temporal_dim=2)
+    assert G._predictor_load_path == path
+    with torch.no_grad():
+        ref = O.predict(sd, TINY_SPEC, x, mask, frame=None)
+    out = G.predict(x.cuda(), mask.cuda().clone(), frame=None).cpu()
+    assert (out - ref).abs().max().item() <= 2e-4
+    assert (before - ref).abs().max().item() > 1e-2                         # the file's weights differ from the ones it replaced
+    # the plain state-dict form (no "model" key) and load_predictor on an existing wrapper
+    torch.save({k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(TINY, 12).items()}, path)
+    G.load_predictor(path)
+    back = G.predict(x.cuda(), mask.cuda().clone(), frame=None).cpu()
+    assert (back - before).abs().max().item() <= 1e-6
 
 
 @pytest.mark.parametrize("name", ["tiny_8x8_sharp.npz", "base8_sharp_b1.npz"])

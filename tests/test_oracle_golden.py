@@ -14,6 +14,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TINY = C.VmaeConfig(name="tiny_8x8", img_size=(32, 32), patch=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128,
                     dec_depth=1, dec_heads=2)
 TINY_SPEC = O.VmaeSpec(img_size=(32, 32), patch=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=1, dec_heads=2)
+TINY16 = C.VmaeConfig(name="tiny_16x16", img_size=(64, 64), patch=16, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=1, dec_heads=2)
+TINY16_SPEC = O.VmaeSpec(img_size=(64, 64), patch=16, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=1, dec_heads=2)
 
 
 def load(name):
@@ -57,6 +59,51 @@ def test_base8_full_size(name):
     assert err <= 2e-5, err
     rows = video[:, 1, :, :: cfg.img_size[0] // 8].numpy()
     assert np.abs(rows - g["video_frame1_rows"]).max() <= 2e-5
+
+
+def test_patch16_models():
+    """P = 16 (vmae.py:597-603 `base_16x16patch_2frames_1tube`: 392 tokens, patch-embed K = 768, head N = 768) and a tiny 16x16-patch model."""
+    g = load("tiny_16x16_k3.npz")
+    x, mask, (video, y) = oracle_case(g, TINY16, TINY16_SPEC)
+    assert np.array_equal(x.numpy(), g["x"]) and y.shape == g["y_tokens"].shape == (2, 13, 768)
+    assert np.abs(y.numpy() - g["y_tokens"]).max() <= 1e-5
+    assert np.abs(video[:, 1, :, ::8].numpy() - g["video_frame1_rows"]).max() <= 1e-5
+    g = load("base16_k8_b2.npz")
+    cfg = C.CONFIGS["base_16x16patch_2frames_1tube"]
+    _, _, (video, y) = oracle_case(g, cfg, O.SPECS[cfg.name])
+    assert y.shape == g["y_tokens"].shape == (2, 188, 768)
+    assert np.abs(y.numpy() - g["y_tokens"]).max() <= 2e-5
+    assert np.abs(video[:, 1, :, :: cfg.img_size[0] // 8].numpy() - g["video_frame1_rows"]).max() <= 2e-5
+
+
+def test_256_prompt_rows_vs_reference():
+    """BASELINE configs[3] at full size: the oracle's prompt construction over all 256 synthetic prompts (static movie, one active patch
+    each, ONE rectangularisation under torch seed 3) equals the reference's `create_motion_counterfactuals` masks, and its predictions of the
+    three captured rows (first, first out-of-frame shift, last) equal the reference's `predict`."""
+    g = load("prompts256_rows.npz")
+    cfg = C.CONFIGS["base_8x8patch_2frames_1tube"]
+    table = S.synthetic_prompts(256, cfg, 0)
+    n, gw = cfg.tokens_per_frame, cfg.img_size[1] // cfg.patch
+    x0 = torch.from_numpy(S.synthetic_frames(1, cfg, 0))[:, 0:1]
+    xs = x0.expand(-1, 2, -1, -1, -1).clone()
+    active = torch.ones(1, 2 * n, 256, dtype=torch.bool)
+    active[:, :n] = False
+    active[0, n + torch.from_numpy(table[:, 0].astype(np.int64)) * gw + torch.from_numpy(table[:, 1].astype(np.int64)), torch.arange(256)] = False
+    passive = torch.ones(1, 2 * n, 256, dtype=torch.bool)
+    passive[:, :n] = False
+    x_shift, ms = O.create_motion_counterfactuals(xs, passive, active, table[:, 2:4], cfg.patch)
+    torch.manual_seed(int(g["seed"]))
+    mask_post = O.rectangularize_masks_min(ms.clone())
+    rows = [int(r) for r in g["rows"]]
+    assert np.array_equal(mask_post.sum(-1).numpy(), g["n_masked"])
+    assert [int(mask_post.sum()), int((mask_post * torch.arange(mask_post.shape[1])[None]).sum())] == g["mask_post_digest"].tolist()
+    assert np.array_equal(mask_post[rows].numpy(), g["mask_post_rows"])
+    dest = table[rows[1], 0:2] + table[rows[1], 2:4]
+    assert (dest < 0).any() or (dest >= gw).any()          # the middle row's destination lies outside the frame
+    W = weights(cfg, 0)
+    with torch.no_grad():
+        ys = torch.cat([O.predict(W, O.SPECS[cfg.name], x_shift[r:r + 1], mask_post[r:r + 1], normalize=True, frame=-1) for r in rows], 0)
+    assert np.abs(ys[:, :, :, ::2].numpy() - g["y_rows_even"]).max() <= 2e-5
 
 
 def test_sharp_weights_full_size():

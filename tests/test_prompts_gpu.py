@@ -233,6 +233,14 @@ def test_256_prompts_sharded_driver_equals_one_unchunked_call():
     err = (y - y_one).abs().max().item()
     print(f"[prompts256] 8 x 32 rows vs one 256-row call: {err:.2e}")
     assert err <= 5e-5
+    # anchored on the reference: its own prompt construction over these 256 prompts (one rectangularisation under the same torch seed)
+    # and its `predict` on three of them -- the first, the first whose shift leaves the frame, the last (tests/golden/make_golden.py --only r4)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prompts256_rows.npz"))
+    rows = [int(r) for r in g["rows"]]
+    assert int(g["seed"]) == 3 and rows[0] == 0 and rows[-1] == 255
+    err_ref = np.abs(y[rows][:, :, :, ::2].cpu().numpy() - g["y_rows_even"]).max()
+    print(f"[prompts256] rows {rows} vs the reference's predict: {err_ref:.2e}")
+    assert err_ref <= 1e-3
     # the same prompts through the reference-shaped entry point (active patch masks + shifts)
     n = cfg.tokens_per_frame
     gw = cfg.img_size[1] // cfg.patch

@@ -1,4 +1,12 @@
-"""Summarise a tools/collect_profiles.sh output directory into profiles/<tag>_*.{csv,json} (run in the build container)."""
+"""Summarise a tools/collect_profiles.sh output directory (gpurun_out/prof_<tag>) into profiles/ (run in the build container):
+    python tools/summarize_profiles.py r4
+  profiles/<tag>_kernel_stats_bench_<workload>_<mode>.csv      rocprofv3 --stats of bench.py --lanes 1 (and *_parity_default: two lanes)
+  profiles/<tag>_bench_under_rocprof_<workload>_parity.json    the bench line of that very run (its HIP-event averages must agree)
+  profiles/<tag>_pmc_summary.json                              per workload and kernel: HBM bytes per launch, MFMA busy, clock
+  profiles/pmc_summary_latest.json                             what bench.py reads for roofline.traffic / mfma_busy
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM
+section) and is doubled here; WRITE_SIZE is exact for 16-byte-per-lane stores.  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE /
+8 XCDs x 1024 SIMDs)."""
 import collections
 import csv
 import glob
@@ -7,81 +15,103 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1d"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
+WORKLOADS = ("base8", "large4", "imu4")
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(src, pattern))
+    f = glob.glob(os.path.join(src, pattern), recursive=True)
     return f[0] if f else None
 
 
-for mode in ("parity", "fast", "parity_default"):
-    f = one("stats_%s/runc/*kernel_stats.csv" % mode)
-    if f:
-        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_bench_base8_%s.csv" % (tag, mode)))
-f = one("stats_b1/runc/*kernel_stats.csv")
-if f:
-    shutil.copy(f, os.path.join(dst, "%s_kernel_stats_latency_b1_parity.csv" % tag))
+def kname(raw):
+    return raw.split("(")[0].replace("void ", "").strip()
 
 
-def counters(d, kfilter):
-    f = one(d + "/runc/*counter_collection.csv")
+def counters(d):
+    """{(kernel, counter): [per-dispatch values]}, {kernel: {dispatch: ns}} of one PMC pass."""
+    f = one(d + "/**/*counter_collection.csv")
     agg, dur = collections.defaultdict(list), collections.defaultdict(dict)
     if not f:
         return agg, dur
     for r in csv.DictReader(open(f)):
-        if kfilter in r["Kernel_Name"]:
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
-            dur[k][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        k = kname(r["Kernel_Name"])
+        agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        dur[k][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return agg, dur
 
 
-out = {"tag": tag, "command": "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --no-prompts --lanes 1 (parity mode, B/8 batch 32; *_parity_default.csv: the same without --lanes 1)"}
-# HBM traffic of the GEMM kernels: FETCH_SIZE / WRITE_SIZE are in KiB-units of 1024 B; on gfx950 FETCH_SIZE reports
-# half of the bytes of a wide coalesced stream (MI355X_MICROARCH.md HBM section) -> doubled here.
-traffic = {}
-for d, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    agg, _ = counters(d, "gemm")
-    for (k, c), v in agg.items():
-        t = traffic.setdefault(k, {"launches": len(v)})
-        t[name + "_KiB_mean_raw"] = sum(v) / len(v)
-for k, t in traffic.items():
-    t["hbm_bytes_per_launch_corrected"] = (2.0 * t.get("FETCH_SIZE_KiB_mean_raw", 0.0) + t.get("WRITE_SIZE_KiB_mean_raw", 0.0)) * 1024.0
-out["gemm_hbm_traffic"] = traffic
-tot_l = sum(t["launches"] for t in traffic.values()) or 1
-out["gemm_hbm_bytes_per_launch_all"] = sum(t["hbm_bytes_per_launch_corrected"] * t["launches"] for t in traffic.values()) / tot_l
+for wl in WORKLOADS:
+    for mode in ("parity", "fast", "parity_default"):
+        f = one("stats_%s_%s/**/*kernel_stats.csv" % (wl, mode))
+        if f:
+            shutil.copy(f, os.path.join(dst, "%s_kernel_stats_bench_%s_%s.csv" % (tag, wl, mode)))
+    f = os.path.join(src, "bench_under_rocprof_%s_parity.json" % wl)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        shutil.copy(f, os.path.join(dst, "%s_bench_under_rocprof_%s_parity.json" % (tag, wl)))
+    else:
+        print("WARNING: no bench line captured under rocprofv3 for", wl)
+f = one("stats_b1/**/*kernel_stats.csv")
+if f:
+    shutil.copy(f, os.path.join(dst, "%s_kernel_stats_latency_b1_parity.csv" % tag))
 
-agg, dur = counters("pmc_mfma", "")
-mf = {}
-for (k, c), v in agg.items():
-    mf.setdefault(k, {})[c] = sum(v)
-for k, d in mf.items():
-    if "GRBM_GUI_ACTIVE" in d and d.get("SQ_VALU_MFMA_BUSY_CYCLES"):
-        cycles = d["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
-        d["mfma_util"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0)  # 256 CUs x 4 SIMDs
-        ns = sum(dur[k].values())
-        d["clock_GHz"] = cycles / ns if ns else None
-out["bench_kernels_mfma"] = {k: v for k, v in mf.items() if "mfma_util" in v}
+out = {"tag": tag, "command": "python3 bench.py --workload <w> --steps 5|3 --warmup 1 --no-cpu-baseline --no-secondary --no-prompts --lanes 1 (parity mode; "
+                              "imu4 with CWM_CONJ_CTX_STREAM=0: no two kernels overlap)", "workloads": {}}
+latest = {"entries": {}}
+for wl in WORKLOADS:
+    kernels = {}
+    for d, name in (("pmc_fetch_" + wl, "FETCH_SIZE"), ("pmc_write_" + wl, "WRITE_SIZE")):
+        agg, _ = counters(d)
+        for (k, c), v in agg.items():
+            if c == name and "cwm::" in k:
+                t = kernels.setdefault(k, {})
+                t["launches"] = len(v)
+                t[name + "_KiB_mean_raw"] = sum(v) / len(v)
+    for k, t in kernels.items():
+        t["hbm_bytes_per_launch_corrected"] = (2.0 * t.get("FETCH_SIZE_KiB_mean_raw", 0.0) + t.get("WRITE_SIZE_KiB_mean_raw", 0.0)) * 1024.0
+    agg, dur = counters("pmc_mfma_" + wl)
+    tot = collections.defaultdict(dict)
+    for (k, c), v in agg.items():
+        if "cwm::" in k:
+            tot[k][c] = sum(v)
+    for k, d in tot.items():
+        t = kernels.setdefault(k, {})
+        if d.get("GRBM_GUI_ACTIVE"):
+            cycles = d["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+            ns = sum(dur[k].values())
+            t.update(mfma_busy=d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cycles * 1024.0), clock_GHz=cycles / ns if ns else None,
+                     total_us_in_pmc_pass=ns / 1e3, SQ_WAIT_ANY_share=(d.get("SQ_WAIT_ANY", 0.0) / d["SQ_WAVE_CYCLES"]) if d.get("SQ_WAVE_CYCLES") else None)
+    if not kernels:
+        continue
+    out["workloads"][wl] = dict(sorted(kernels.items(), key=lambda kv: -kv[1].get("total_us_in_pmc_pass", 0.0)))
+    latest["entries"]["%s/parity" % wl] = {
+        "tag": tag, "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, separate passes)" % tag,
+        "hbm_bytes_per_launch": {k: t["hbm_bytes_per_launch_corrected"] for k, t in kernels.items() if t.get("hbm_bytes_per_launch_corrected")},
+        "mfma_busy": {k: t["mfma_busy"] for k, t in kernels.items() if t.get("mfma_busy")}}
 
 for mode in ("fast", "parity"):
-    agg, dur = counters("pmc_attn_l4dec_" + mode, "attention")
-    d = {}
-    for (k, c), v in agg.items():
-        d[c] = v[-1]
-    if d:
-        ns = list(list(dur.values())[0].values())[-1]
+    agg, dur = counters("pmc_attn_l4dec_" + mode)
+    d = {c: v[-1] for (k, c), v in agg.items() if "attention" in k}
+    durs = [v for k, v in dur.items() if "attention" in k]
+    if d and durs:
+        ns = list(durs[0].values())[-1]
         cycles = d["GRBM_GUI_ACTIVE"] / 8.0
-        d.update(duration_us=ns / 1e3, clock_GHz=cycles / ns, mfma_util=d["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0),
+        d.update(duration_us=ns / 1e3, clock_GHz=cycles / ns, mfma_busy=d["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0),
                  algorithmic_TFLOPs=4.0 * 8 * 8 * 6272 * 6272 * 64 / ns / 1e3)
         out["attention_vit_l4_decoder_B8_H8_N6272_" + mode] = d
 json.dump(out, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
-# what bench.py reads for roofline.traffic (same command: base8 workload, parity mode)
-latest = {"tag": tag, "workload": "base8", "mode": "parity", "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag,
-          "hbm_bytes_per_launch": {k: t["hbm_bytes_per_launch_corrected"] for k, t in traffic.items()}}
-json.dump(latest, open(os.path.join(dst, "pmc_summary_latest.json"), "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+if latest["entries"]:
+    json.dump(latest, open(os.path.join(dst, "pmc_summary_latest.json"), "w"), indent=1)
+for wl, ks in out["workloads"].items():
+    for k, t in ks.items():
+        print("%-7s %-60s launches %4s  HBM %7.1f MB/launch  mfma busy %s  clock %s" % (
+            wl, k[:60], t.get("launches"), t.get("hbm_bytes_per_launch_corrected", 0) / 1e6,
+            "%.3f" % t["mfma_busy"] if t.get("mfma_busy") is not None else "-", "%.2f" % t["clock_GHz"] if t.get("clock_GHz") else "-"))
+for mode in ("fast", "parity"):
+    d = out.get("attention_vit_l4_decoder_B8_H8_N6272_" + mode)
+    if d:
+        print("L/4 decoder attention %-6s %.1f us  %.1f TFLOP/s  mfma busy %.3f" % (mode, d["duration_us"], d["algorithmic_TFLOPs"], d["mfma_busy"]))
