@@ -533,6 +533,9 @@ int launch_small_attention_mfma(const SmallAttnParams& p, int planes, hipStream_
 
 // (head_dim 192 against more than 32 context tokens would need more than 256 registers in role B: that shape stays on the VALU kernels)
 bool cross_attention_mfma_ok(int head_dim, int M) { return (head_dim == 32 || head_dim == 96 || head_dim == 192) && M >= 1 && M <= (head_dim == 192 ? 32 : 64); }
+// ... and the kernel's 32-bit element offsets must hold the lane's projections (B rows of N tokens, 4 * heads * head_dim elements each):
+// beyond it (about 100 samples per lane at N = 6336, D = 768) the caller falls back to the VALU kernels instead of failing the forward
+bool cross_attention_mfma_fits(int B, int N, int heads, int head_dim) { return N >= 1 && (int64_t)B * N * 4 * heads * head_dim < (1ll << 31); }
 size_t cross_attention_mfma_partial_floats(int B, int heads, int M, int head_dim) { return (size_t)B * heads * kCrossSplit2 * M * (head_dim + 4); }
 
 template <int PLANES, int NDB, int MT>
@@ -561,7 +564,7 @@ int launch_cross_attention_mfma_roles(const CrossAttnParams& p, int planes, hipS
     // (a null stream handle is a valid stream: the role mask, not the handle, says what to launch)
     CWM_REQUIRE(cross_attention_mfma_ok(p.head_dim, p.M), "cross_attention (MFMA): head_dim %d / M %d not supported", p.head_dim, p.M);
     CWM_REQUIRE(p.qk_op && p.v_op && p.qk_src && p.v_src && p.y && p.y_src && p.partial, "cross_attention (MFMA): null argument");
-    CWM_REQUIRE(p.N >= 1 && (int64_t)p.B * p.N * 4 * p.heads * p.head_dim < (1ll << 31), "cross_attention (MFMA): problem too large for 32-bit offsets");
+    CWM_REQUIRE(cross_attention_mfma_fits(p.B, p.N, p.heads, p.head_dim), "cross_attention (MFMA): problem too large for 32-bit offsets");
     const int ndb = p.head_dim / 32, mt = p.M > 32 ? 2 : 1;
 #define CWM_CROSS_CASE(PL, NDB, MT) \
     if (planes == PL && ndb == NDB && mt == MT) return launch_cross_mfma_t<PL, NDB, MT>(p, stream_a, stream_b, roles);

@@ -289,7 +289,7 @@ int run_cross(ConjLane& L, const CrossW& C, float* x, int N, int ci, float* src,
     const int rows = B * N, rows_s = B * M;
     int rc;
     // main-stream projections: operand layout (bf16 hi [, lo] planes, the same 4 bytes per element as fp32) for the MFMA kernel
-    const bool mfma = g_conj_attn && cross_attention_mfma_ok(hd, M) && (2 * D) % 32 == 0;
+    const bool mfma = g_conj_attn && cross_attention_mfma_ok(hd, M) && cross_attention_mfma_fits(B, N, heads, hd) && (2 * D) % 32 == 0;
     const bool two = sc != s && mfma;
     if (sc != s && !two) {  // VALU fallback: one chain on s, bracketed by the context stream
         CWM_HIP_CHECK(hipEventRecord(ev[1], sc));

@@ -75,7 +75,8 @@ struct Engine {
         float* slabs;
         unsigned* counts;
     };
-    std::map<hipStream_t, SplitKWs> splitk_ws;  // one split-K workspace per stream this engine launches on (batch lanes run concurrently)
+    static constexpr size_t kMaxSplitKStreams = 8;
+    std::map<hipStream_t, SplitKWs> splitk_ws;  // one split-K workspace per stream that has launched a split GEMM (batch lanes run concurrently); created lazily, capped
 
     ~Engine();
     int alloc(void** p, size_t bytes, bool zero, bool workspace);

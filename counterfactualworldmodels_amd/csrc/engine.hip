@@ -66,6 +66,10 @@ Engine::~Engine() {
     (void)hipDeviceSynchronize();
     for (void* p : allocs) (void)hipFree(p);
     for (void* p : ws_allocs) (void)hipFree(p);
+    for (auto& kv : splitk_ws) {
+        (void)hipFree(kv.second.slabs);
+        (void)hipFree(kv.second.counts);
+    }
     for (auto& t : timers)
         for (auto& e : t.pool) {
             (void)hipEventDestroy(e.a);
@@ -277,20 +281,32 @@ int Engine::timer_end(EventPair* e, hipStream_t s) {
 int Engine::run_gemm(const GemmParams& p_in, int planes, hipStream_t s) {
     GemmParams p = p_in;
     p.overlapped = overlapped;
-    {   // every launch carries this stream's split-K workspace: the remainder rows of a mixed-tiling launch can be a small, deep
-        // launch (fc2 of a single-lane batch) even when the whole GEMM is not
-        auto it = splitk_ws.find(s);
-        if (it == splitk_ws.end()) {
-            SplitKWs w = {nullptr, nullptr};
-            if (int rc = splitk_workspace_alloc(&w.slabs, &w.counts)) return rc;
-            allocs.push_back(w.slabs);
-            allocs.push_back(w.counts);
-            it = splitk_ws.emplace(s, w).first;
-        }
-        p.sk2_slabs = it->second.slabs;
-        p.sk2_count = it->second.counts;
-    }
     const int cfg = gemm_choose_tile(p, planes);
+    {   // a launch (or the 128x128 remainder of a mixed-tiling launch: fc2 of a single-lane batch) that takes the deep-ring kernel's split-K
+        // path carries this stream's workspace, created on first need (32 MB + counters; at most kMaxSplitKStreams per engine: a caller
+        // that rotates streams evicts the oldest)
+        GemmParams big, rest;
+        const bool split = (cfg == 1 && gemm_splitk_parts(p, planes) > 1) ||
+                           (cfg == 6 && gemm_mixed_split(p, &big, &rest) && gemm_splitk_parts(rest, planes) > 1);
+        if (split) {
+            auto it = splitk_ws.find(s);
+            if (it == splitk_ws.end()) {
+                if (splitk_ws.size() >= kMaxSplitKStreams) {
+                    // (the evicted stream may still have a launch in flight that reads its workspace: let it finish first)
+                    auto victim = splitk_ws.begin();
+                    CWM_HIP_CHECK(hipStreamSynchronize(victim->first));
+                    (void)hipFree(victim->second.slabs);
+                    (void)hipFree(victim->second.counts);
+                    splitk_ws.erase(victim);
+                }
+                SplitKWs w = {nullptr, nullptr};
+                if (int rc = splitk_workspace_alloc(&w.slabs, &w.counts, s)) return rc;
+                it = splitk_ws.emplace(s, w).first;
+            }
+            p.sk2_slabs = it->second.slabs;
+            p.sk2_count = it->second.counts;
+        }
+    }
     GemmParams part[2];
     int cfgs[2] = {cfg, 0}, nparts = 1;
     part[0] = p;

@@ -2,7 +2,8 @@
 // samples right after the predictor path.
 //
 // Replaces (cwm/models/segmentation.py):
-//   FlowGenerator.compute_flow_corrs             :479-547  ds x ds average pool, ChannelMSE against zeros (utils.py:510-513),
+//   FlowGenerator.compute_flow_corrs             :479-547  ds x ds average pool, ChannelMSE against zeros (utils.py:510-513), the optional
+//                                                          prologues (:519-538: Spearman argsort, thresholds, normalise, z-score),
 //                                                          torch.cov / torch.corrcoef over the samples, NaN -> 0
 //   FlowGenerator.compute_flow_samples_magnitude :250-255
 //   FlowGenerator.compute_mean_motion_map        :257-276
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
                 float c = v[r];
                 if (!use_cov && j + r < P) {
                     c = c * si * inv_std[(size_t)b * P + j + r];
-                    c = fminf(1.0f, fmaxf(-1.0f, c));  // torch.corrcoef clips to [-1, 1]
+                    // torch.corrcoef clips to [-1, 1] and keeps a NaN (a constant row: 0 * inf) a NaN; fminf / fmaxf would turn it into -1
+                    if (c == c) c = fminf(1.0f, fmaxf(-1.0f, c));
                 }
                 o[r] = (c != c) ? 0.f : c;  // NaN -> 0 (segmentation.py:541)
             }
@@ -136,6 +138,89 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
             }
         }
     }
+}
+
+// ---- feature prologues of compute_flow_corrs (segmentation.py:519-538), in place on x[b][p][s] ------------------------------------
+// The reference applies them to flow_inp_b = x[b] as a [P, S] matrix: the Spearman form replaces every ROW (position) by
+// argsort over its samples; the threshold / range / normalise / z-score forms use statistics over dim 0 -- over the P POSITIONS,
+// separately for every sample column s.
+
+// argsort of every row over its S samples, as floats (`torch.argsort(flow_inp[b], -1).float()`, :521): out[rank of element j] = j.
+// One wave per row; rank = #(smaller) + #(equal with a lower index): the stable order (torch's default sort is not stable, so rows
+// with exactly tied values are the one place where the reference's own output is implementation-defined).
+__global__ __launch_bounds__(256) void flow_argsort_rows_kernel(float* __restrict__ x, int rows, int S) {
+    extern __shared__ float srow[];  // [4 waves][S]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    float* mine = srow + (size_t)wave * S;
+    if (row < rows)
+        for (int s = lane; s < S; s += 64) mine[s] = x[(size_t)row * S + s];
+    __syncthreads();
+    if (row >= rows) return;
+    for (int j = lane; j < S; j += 64) {
+        const float v = mine[j];
+        int rank = 0;
+        for (int k = 0; k < S; ++k) {
+            const float u = mine[k];
+            rank += (u < v || (u == v && k < j)) ? 1 : 0;
+        }
+        x[(size_t)row * S + rank] = (float)j;
+    }
+}
+
+// per column (b, s): {min, max, mean, unbiased std} over the P positions -> st[b][s]; sums in float64 (mean first, then the
+// squared deviations: two passes over a column that stays in L2)
+__global__ __launch_bounds__(256) void flow_colstats_kernel(const float* __restrict__ x, int P, int S, float4* __restrict__ st) {
+    __shared__ float rmn[4][64], rmx[4][64];
+    __shared__ double rs[4][64];
+    const int b = blockIdx.y, s = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const bool in = s < S;
+    const float* xb = x + (size_t)b * P * S + (in ? s : 0);
+    float mn = INFINITY, mx = -INFINITY;
+    double sum = 0.0;
+    if (in)
+        for (int p = rg; p < P; p += 4) {
+            const float v = xb[(size_t)p * S];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+            sum += (double)v;
+        }
+    rmn[rg][threadIdx.x & 63] = mn;
+    rmx[rg][threadIdx.x & 63] = mx;
+    rs[rg][threadIdx.x & 63] = sum;
+    __syncthreads();
+    const int c = threadIdx.x & 63;
+    const double mean = (rs[0][c] + rs[1][c] + rs[2][c] + rs[3][c]) / (double)P;
+    __syncthreads();
+    double sq = 0.0;
+    if (in)
+        for (int p = rg; p < P; p += 4) {
+            const double d = (double)xb[(size_t)p * S] - mean;
+            sq += d * d;
+        }
+    rs[rg][c] = sq;
+    __syncthreads();
+    if (rg == 0 && in) {
+        const double var = (rs[0][c] + rs[1][c] + rs[2][c] + rs[3][c]) / (double)(P - 1);
+        st[(size_t)b * S + s] = make_float4(fminf(fminf(rmn[0][c], rmn[1][c]), fminf(rmn[2][c], rmn[3][c])),
+                                            fmaxf(fmaxf(rmx[0][c], rmx[1][c]), fmaxf(rmx[2][c], rmx[3][c])), (float)mean, (float)sqrt(var));
+    }
+}
+
+// elementwise forms; op: 1 x * (x > a), 2 (x > a), 3 ((x - min) > a * (max - min)), 4 x / max(colmax, eps), 5 (x - mean) / max(std, eps)
+__global__ void flow_apply_kernel(float* __restrict__ x, int64_t total, int P, int S, int op, float a, float eps, const float4* __restrict__ st) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float v = x[i];
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (op >= 3) c = st[(i / ((int64_t)P * S)) * S + (i % S)];
+    float o;
+    if (op == 1) o = v * ((v > a) ? 1.0f : 0.0f);
+    else if (op == 2) o = (v > a) ? 1.0f : 0.0f;
+    else if (op == 3) o = ((v - c.x) > a * (c.y - c.x)) ? 1.0f : 0.0f;
+    else if (op == 4) o = v / fmaxf(c.y, eps);
+    else o = (v - c.z) / fmaxf(c.w, eps);
+    x[i] = o;
 }
 
 // ---- motion maps ---------------------------------------------------------------------------------------------------------
@@ -247,6 +332,42 @@ extern "C" int cwm_flow_cov(const float* x_dev, int B, int P, int S, int row0, i
     hipLaunchKernelGGL(flow_center_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x_dev, rows, S, xc_work_dev, inv_std_work_dev);
     const dim3 grid((unsigned)((P + 127) / 128), (unsigned)((nrows + 127) / 128), (unsigned)B);
     hipLaunchKernelGGL(flow_cov_kernel, grid, dim3(256), 0, s, xc_work_dev, inv_std_work_dev, P, S, row0, nrows, use_covariance ? 1 : 0, out_dev);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int cwm_flow_transform(float* x_dev, int B, int P, int S, int spearman, int thresh_mode, float thresh, int normalize, int zscore, float eps,
+                                  float* stats_work_dev, void* stream) {
+    CWM_REQUIRE(x_dev && B > 0 && P > 0 && S > 0, "cwm_flow_transform: bad argument");
+    CWM_REQUIRE(thresh_mode >= 0 && thresh_mode <= 3, "cwm_flow_transform: thresh_mode must be 0 (none), 1 (x * (x > t)), 2 (x > t) or 3 (range threshold)");
+    CWM_REQUIRE(!(thresh_mode == 3 || normalize || zscore) || stats_work_dev, "cwm_flow_transform: the column statistics need the [B][S][4] work buffer");
+    CWM_REQUIRE(!spearman || S <= 4096, "cwm_flow_transform: Spearman ranks support at most 4096 samples (S=%d)", S);
+    CWM_REQUIRE(!zscore || P > 1, "cwm_flow_transform: z-scores need more than one position");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * P * S;
+    const unsigned eblocks = (unsigned)((total + 255) / 256);
+    float4* st = reinterpret_cast<float4*>(stats_work_dev);
+    const dim3 sgrid((unsigned)((S + 63) / 64), (unsigned)B);
+    if (spearman) {
+        const size_t smem = (size_t)4 * S * sizeof(float);
+        if (smem > 48 * 1024)
+            if (int rc = cwm_set_max_lds((const void*)flow_argsort_rows_kernel, (int)smem)) return rc;
+        hipLaunchKernelGGL(flow_argsort_rows_kernel, dim3((unsigned)((B * P + 3) / 4)), dim3(256), smem, s, x_dev, B * P, S);
+    }
+    if (thresh_mode == 1 || thresh_mode == 2) {
+        hipLaunchKernelGGL(flow_apply_kernel, dim3(eblocks), dim3(256), 0, s, x_dev, total, P, S, thresh_mode, thresh, eps, st);
+    } else if (thresh_mode == 3) {
+        hipLaunchKernelGGL(flow_colstats_kernel, sgrid, dim3(256), 0, s, x_dev, P, S, st);
+        hipLaunchKernelGGL(flow_apply_kernel, dim3(eblocks), dim3(256), 0, s, x_dev, total, P, S, 3, thresh, eps, st);
+    }
+    if (normalize) {
+        hipLaunchKernelGGL(flow_colstats_kernel, sgrid, dim3(256), 0, s, x_dev, P, S, st);
+        hipLaunchKernelGGL(flow_apply_kernel, dim3(eblocks), dim3(256), 0, s, x_dev, total, P, S, 4, 0.f, eps, st);
+    }
+    if (zscore) {
+        hipLaunchKernelGGL(flow_colstats_kernel, sgrid, dim3(256), 0, s, x_dev, P, S, st);
+        hipLaunchKernelGGL(flow_apply_kernel, dim3(eblocks), dim3(256), 0, s, x_dev, total, P, S, 5, 0.f, eps, st);
+    }
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -532,14 +532,24 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
 
 // Split-K workspace of the deep-ring kernel: kSplitKSlots fp32 slabs of one 128x128 tile + arrival counters (zeroed once; the kernel
 // leaves them at zero).  One workspace serves ONE stream at a time: the engine keeps one per stream it launches on (engine.hip).
-int splitk_workspace_alloc(float** slabs, unsigned** counts) {
+int splitk_workspace_alloc(float** slabs, unsigned** counts, hipStream_t stream) {
     CWM_HIP_CHECK(hipMalloc((void**)slabs, (size_t)kSplitKSlots * 128 * 128 * sizeof(float)));
     CWM_HIP_CHECK(hipMalloc((void**)counts, kSplitKSlots * sizeof(unsigned)));
-    CWM_HIP_CHECK(hipMemset(*counts, 0, kSplitKSlots * sizeof(unsigned)));
-    // the memset runs on the null stream; the kernels that use the counters run on non-blocking streams (batch lanes), which do
-    // not wait for it: make it complete here (allocation happens once per stream)
-    CWM_HIP_CHECK(hipDeviceSynchronize());
+    // zeroed ON THE STREAM that will use the counters: ordered before the first launch there without a device-wide synchronisation
+    // (the kernels leave the counters at zero, so this runs once per workspace)
+    CWM_HIP_CHECK(hipMemsetAsync(*counts, 0, kSplitKSlots * sizeof(unsigned), stream));
     return 0;
+}
+
+// Does this launch take the split-K path of the deep-ring kernel?  (the engine creates a stream's workspace only then)
+int gemm_splitk_parts(const GemmParams& p, int planes) {
+    if (g_gemm_debug & (4 | 32)) return 1;
+    const int tiles128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const int cus = gemm_cu_count();
+    if (tiles128 > cus) return 1;
+    const int nk_all = p.K / (64 / planes);
+    const int sk = std::min(std::min(cus / tiles128, nk_all / 12), 8);
+    return sk >= 3 ? sk : 1;
 }
 
 int gemm_cu_count() {
@@ -699,8 +709,7 @@ static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t strea
         // fill the idle CUs of a latency-bound launch by cutting K: only where it pays (measured, ViT-B/8 batch 1: fc2 65 -> 32 us with
         // 6 parts, decoder fc2 36 -> 26 us; two parts of a K = 768 qkv projection LOSE 6 us to the hand-off) -- at least three parts of at
         // least 12 K tiles each; the parts of a tile are reduced in a fixed order (deterministic)
-        const int nk_all = p.K / (64 / planes);
-        int sk = std::min(std::min(cus / tiles128, nk_all / 12), 8);
+        const int sk = gemm_splitk_parts(p, planes);
         if (sk >= 3) {
             if (!p.sk2_slabs) {
                 // callers without a workspace of their own (the stand-alone entry points, cwm_linear): one workspace per (device,
@@ -714,7 +723,7 @@ static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t strea
                 auto it = table.find(std::make_pair(dev, stream));
                 if (it == table.end()) {
                     Ws w = {nullptr, nullptr};
-                    if (int rc = splitk_workspace_alloc(&w.slabs, &w.counts)) return rc;
+                    if (int rc = splitk_workspace_alloc(&w.slabs, &w.counts, stream)) return rc;
                     it = table.emplace(std::make_pair(dev, stream), w).first;
                 }
                 p.sk2_slabs = it->second.slabs;

@@ -53,7 +53,8 @@ struct GemmParams {
 };
 
 constexpr int kSplitKSlots = 512;  // >= CUs: a split launch has at most one part per CU
-int splitk_workspace_alloc(float** slabs, unsigned** counts);
+int splitk_workspace_alloc(float** slabs, unsigned** counts, hipStream_t stream);  // counters zeroed on `stream`
+int gemm_splitk_parts(const GemmParams& p, int planes);  // K ranges the deep-ring 128x128 kernel would cut this launch into (1: no split-K)
 int launch_gemm(const GemmParams& p, int planes, hipStream_t stream);
 int gemm_choose_tile(const GemmParams& p, int planes);
 bool gemm_mixed_split(const GemmParams& p, GemmParams* big, GemmParams* rest);  // tile configuration 6
@@ -203,6 +204,7 @@ size_t cross_attention_partial_floats(int B, int heads, int M, int head_dim);
 int launch_cross_attention_mfma(const CrossAttnParams& p, int planes, hipStream_t stream);  // MFMA kernel: qk_op / v_op, partial scratch
 int launch_cross_attention_mfma_roles(const CrossAttnParams& p, int planes, hipStream_t stream_a, hipStream_t stream_b, int roles);  // bit 0: main update on stream_a, bit 1: context update on stream_b
 bool cross_attention_mfma_ok(int head_dim, int M);
+bool cross_attention_mfma_fits(int B, int N, int heads, int head_dim);  // the MFMA kernel's 32-bit offsets hold this lane (else: the VALU kernels)
 size_t cross_attention_mfma_partial_floats(int B, int heads, int M, int head_dim);
 extern int g_conj_ctx_stream;  // 1 (default): the IMU-conditioned model runs its context stream's blocks on a side stream between cross blocks
 extern int g_conj_attn;  // 1 (default): MFMA cross / small attention where the shapes allow; 0: the fp32 VALU kernels ("conj_attn" switch)

@@ -67,13 +67,37 @@ def feature_cov_rows(x: torch.Tensor, row0: int, nrows: int, use_covariance: boo
     return out
 
 
+def transform_features(x: torch.Tensor, do_spearman=False, thresh=None, binarize=False, normalize=False, zscore=False, range_thresh=None,
+                       eps: float = 1e-12) -> torch.Tensor:
+    """The optional prologues of `compute_flow_corrs` on the pooled features x [B,P,S], in the reference's order (segmentation.py:519-538):
+    Spearman argsort over the samples of every position; `thresh` (x * (x > t), or (x > t) with `binarize`), else `range_thresh`
+    (((x - min) > r * (max - min)) per sample column, min / max over the positions); `normalize` (x / max over positions); `zscore`
+    ((x - mean) / std over positions).  In place on a contiguous copy; returns it."""
+    if not (do_spearman or thresh is not None or range_thresh is not None or normalize or zscore):
+        return x
+    _require_cuda(x, "transform_features")
+    x = x.contiguous()
+    B, P, S = x.shape
+    mode, t = 0, 0.0
+    if thresh is not None:
+        mode, t = (2 if binarize else 1), float(thresh)
+    elif range_thresh is not None:
+        mode, t = 3, float(range_thresh)
+    work = torch.empty((B, S, 4), device=x.device, dtype=torch.float32) if (mode == 3 or normalize or zscore) else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.get_lib().cwm_flow_transform(x.data_ptr(), B, P, S, int(bool(do_spearman)), mode, t, int(bool(normalize)), int(bool(zscore)),
+                                                    float(eps), _lib.ptr(work), _lib.current_stream_handle(x.device)))
+    return x
+
+
 def compute_flow_corrs(flow_samples, flow_samples_swap=None, downsample=1, take_top_k=None, do_spearman=False, distance_func=None,
                        thresh=None, use_covariance=False, eps=1e-12, binarize=False, normalize=False, zscore=False, range_thresh=None,
                        rows: Optional[Tuple[int, int]] = None):
     """[B,C,H,W,S] -> [B,1,H/ds,W/ds,H/ds,W/ds] covariance or correlation of the pooled flow magnitude over the samples
     (segmentation.py:479-547).  `rows=(row0, nrows)` returns only that slab [B,nrows,P] of the flattened [P,P] matrix."""
-    if do_spearman or thresh is not None or binarize or normalize or zscore or range_thresh is not None or distance_func is not None:
-        raise NotImplementedError("compute_flow_corrs: only the default statistics path (ChannelMSE features, cov / corrcoef) runs on the device")
+    if distance_func is not None:
+        raise NotImplementedError("compute_flow_corrs: the features are the reference's default distance_func, utils.ChannelMSE(dim=1), "
+                                  "computed on the device; another callable cannot be run there")
     B, Cc, H, W, S = flow_samples.shape
     if S == 0:  # segmentation.py:495-499
         flow_samples = torch.zeros(list(flow_samples.shape)[:-1] + [1], device=flow_samples.device, dtype=torch.float32)
@@ -85,6 +109,8 @@ def compute_flow_corrs(flow_samples, flow_samples_swap=None, downsample=1, take_
         x = torch.cat([x, flow_features(flow_samples_swap[..., :K], downsample)], -1)
     P = x.shape[1]
     ds = int(downsample or 1)
+    x = transform_features(x, do_spearman=do_spearman, thresh=thresh, binarize=binarize, normalize=normalize, zscore=zscore,
+                           range_thresh=range_thresh, eps=eps)
     if rows is not None:
         return feature_cov_rows(x, rows[0], rows[1], use_covariance)
     return feature_cov_rows(x, 0, P, use_covariance).view(B, 1, H // ds, W // ds, H // ds, W // ds)

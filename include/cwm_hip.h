@@ -219,6 +219,13 @@ int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int
  *                     replaces: segmentation.py:273-275.  Split from the sum so that sample shards can be all-reduced in between. */
 int cwm_flow_features(const float* flows_dev, const int64_t* strides, int B, int C, int H, int W, int S, int downsample,
                       float* x_dev, void* stream);
+/* cwm_flow_transform  the optional prologues of compute_flow_corrs on the pooled features, in place, in the reference's order
+ *                     (segmentation.py:519-538; x[b] is its [P, S] matrix): spearman: every row -> argsort over its samples (as floats);
+ *                     thresh_mode 1: x * (x > thresh), 2: (x > thresh), 3: ((x - min_P) > thresh * (max_P - min_P)) ("range_thresh");
+ *                     normalize: x / max(max_P, eps); zscore: (x - mean_P) / max(std_P, eps), statistics over the P positions per sample.
+ *                     stats_work_dev: [B][S][4] floats (needed by mode 3, normalize, zscore) */
+int cwm_flow_transform(float* x_dev, int B, int P, int S, int spearman, int thresh_mode, float thresh, int normalize, int zscore, float eps,
+                       float* stats_work_dev, void* stream);
 int cwm_flow_cov(const float* x_dev, int B, int P, int S, int row0, int nrows, int use_covariance, float* xc_work_dev,
                  float* inv_std_work_dev, float* out_dev, void* stream);
 int cwm_flow_motion_sum(const float* flows_dev, const int64_t* strides, int B, int C, int H, int W, int S,

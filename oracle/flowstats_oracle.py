@@ -47,16 +47,31 @@ def flow_features(flow_samples: torch.Tensor, downsample: int = 1) -> torch.Tens
     return x.reshape(B, -1, S)
 
 
-def compute_flow_corrs(flow_samples: torch.Tensor, downsample: int = 1, use_covariance: bool = False) -> torch.Tensor:
+def compute_flow_corrs(flow_samples: torch.Tensor, downsample: int = 1, use_covariance: bool = False, do_spearman: bool = False, thresh=None,
+                       eps: float = 1e-12, binarize: bool = False, normalize: bool = False, zscore: bool = False, range_thresh=None) -> torch.Tensor:
     """[B,C,H,W,S] -> [B,1,H/ds,W/ds,H/ds,W/ds]: covariance (torch.cov, unbiased) or Pearson correlation (torch.corrcoef) of the
-    pooled flow magnitude over the S samples, NaN -> 0 (segmentation.py:479-547, default arguments otherwise)."""
+    pooled flow magnitude over the S samples, NaN -> 0 (segmentation.py:479-547), with the optional prologues of :519-538 on the
+    [P, S] feature matrix of every batch element (statistics over dim 0 = the positions)."""
     B, C, H, W, S = flow_samples.shape
     if S == 0:
         flow_samples = torch.zeros(list(flow_samples.shape)[:-1] + [1], dtype=torch.float32)
     x = flow_features(flow_samples, downsample)
     out = []
     for b in range(B):
-        c = torch.cov(x[b]) if use_covariance else torch.corrcoef(x[b])
+        xb = torch.argsort(x[b], -1).float() if do_spearman else x[b]                      # :520-523
+        if thresh is not None and binarize is False:                                        # :525-526
+            xb = xb * (xb > thresh).float()
+        elif thresh is not None:                                                            # :527-528
+            xb = (xb > thresh).float()
+        elif range_thresh is not None:                                                      # :529-532
+            xb = xb - xb.amin(0, True)
+            xb = (xb > (range_thresh * xb.amax(0, True))).float()
+        if normalize:                                                                       # :534-535
+            xb = xb / xb.amax(0, True).clamp(min=eps)
+        if zscore:                                                                          # :536-538
+            mn, sd = xb.mean(0), xb.std(0).clamp(min=eps)
+            xb = (xb - mn[None]) / sd[None]
+        c = torch.cov(xb) if use_covariance else torch.corrcoef(xb)
         c[torch.isnan(c)] = 0
         out.append(c)
     ds = downsample

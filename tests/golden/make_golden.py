@@ -453,6 +453,18 @@ def flowstats_inputs(seed=0, shape=(2, 2, 16, 16, 12)):
     return fl
 
 
+FLOW_OPTION_CASES = {
+    "thresh_cov": dict(thresh=1.5, use_covariance=True),
+    "thresh_binarize_corr": dict(thresh=1.5, binarize=True),
+    "range_thresh_cov": dict(range_thresh=0.4, use_covariance=True),
+    "normalize_cov": dict(normalize=True, use_covariance=True),
+    "zscore_corr": dict(zscore=True),
+    "spearman_corr": dict(do_spearman=True),
+    "spearman_zscore_cov": dict(do_spearman=True, zscore=True, use_covariance=True),
+    "thresh_normalize_zscore_cov": dict(thresh=0.5, normalize=True, zscore=True, use_covariance=True),
+}
+
+
 def run_flowstats_case(ns):
     """`compute_flow_corrs` / `compute_mean_motion_map` / `compute_flow_samples_magnitude` of the reference
     (cwm/models/segmentation.py:250-276, 479-547) on seeded random flows."""
@@ -477,6 +489,12 @@ def run_flowstats_case(ns):
     out["cov_one_sample"] = FG.compute_flow_corrs(fl[..., :1], downsample=2, use_covariance=True).numpy()
     np.savez_compressed(os.path.join(HERE, "flowstats.npz"), **out)
     print("flowstats.npz written")
+    # round 4: the optional prologues (segmentation.py:519-538), one fixture per option and two combinations
+    opt = {"seed": 0}
+    for name, kw in FLOW_OPTION_CASES.items():
+        opt[name] = FG.compute_flow_corrs(fl, downsample=2, **kw).numpy()
+    np.savez_compressed(os.path.join(HERE, "flowstats_options.npz"), **opt)
+    print("flowstats_options.npz written", {k: v.shape for k, v in opt.items() if k != "seed"})
 
 
 def run_init_case(ns):

@@ -67,11 +67,43 @@ def test_sample_major_layout_and_ragged_sizes_match_oracle():
     assert (out - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
 
 
+def test_option_prologues_match_reference_outputs():
+    """compute_flow_corrs with its optional prologues on the device (segmentation.py:519-538; `cwm_flow_transform`): thresh, binarize,
+    range_thresh, normalize, zscore and the Spearman argsort, alone and combined, against the reference's own outputs; a strided
+    sample-major input and the row-slab form go through the same prologue."""
+    from make_golden import FLOW_OPTION_CASES
+
+    g = np.load(os.path.join(GOLDEN, "flowstats_options.npz"))
+    fl = _golden_inputs().cuda()
+    for name, kw in FLOW_OPTION_CASES.items():
+        out = FS.compute_flow_corrs(fl, downsample=2, **kw).cpu().numpy()
+        ref = g[name]
+        err = np.abs(out - ref).max()
+        assert out.shape == ref.shape and err <= TOL * max(1.0, np.abs(ref).max()), (name, err)
+    # binary / rank features are exact small integers: the statistics of those cases agree to the last bits of the fp32 sums
+    x = FS.flow_features(fl, 2)
+    xb = FS.transform_features(x.clone(), thresh=1.5, binarize=True)
+    assert set(torch.unique(xb).tolist()) <= {0.0, 1.0} and torch.equal(xb, (x > 1.5).float())
+    xr = FS.transform_features(x.clone(), do_spearman=True)
+    assert torch.equal(xr.cpu(), torch.argsort(x.cpu(), dim=-1, stable=True).float())
+    # ragged sizes (S not a multiple of 64, P not of 4), strided input, row slab
+    gen = torch.Generator().manual_seed(5)
+    raw = torch.randn(2 * 37, 2, 12, 20, generator=gen)
+    dev = raw.cuda().view(2, 37, 2, 12, 20).permute(0, 2, 3, 4, 1)
+    view = raw.view(2, 37, 2, 12, 20).permute(0, 2, 3, 4, 1).contiguous()
+    for kw in (dict(range_thresh=0.3, normalize=True), dict(zscore=True, use_covariance=True), dict(do_spearman=True, use_covariance=True)):
+        out = FS.compute_flow_corrs(dev, downsample=4, **kw).cpu()
+        ref = FO.compute_flow_corrs(view, 4, **kw)
+        assert (out - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item()), kw
+    slab = FS.compute_flow_corrs(dev, downsample=4, zscore=True, use_covariance=True, rows=(3, 7)).cpu()
+    full = FO.compute_flow_corrs(view, 4, zscore=True, use_covariance=True).reshape(2, 15, 15)
+    assert (slab - full[:, 3:10]).abs().max().item() <= TOL * max(1.0, full.abs().max().item())
+
+
 def test_unsupported_options_fail_loudly():
     fl = torch.zeros(1, 2, 8, 8, 4, device="cuda")
-    for kw in ({"do_spearman": True}, {"thresh": 0.1}, {"zscore": True}, {"normalize": True}, {"range_thresh": 0.5}):
-        with pytest.raises(NotImplementedError):
-            FS.compute_flow_corrs(fl, **kw)
+    with pytest.raises(NotImplementedError):
+        FS.compute_flow_corrs(fl, distance_func=lambda a, b: (a - b).abs().mean(1, True))   # only the reference's default features run on the device
     with pytest.raises(RuntimeError):
         FS.compute_flow_corrs(torch.zeros(1, 2, 8, 8, 4))   # CPU tensor: no fallback
 

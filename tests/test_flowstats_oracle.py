@@ -36,6 +36,21 @@ def test_oracle_matches_reference_outputs():
     assert np.array_equal(one, g["cov_one_sample"]) and not one.any()
 
 
+def test_option_prologues_match_reference_outputs():
+    """The optional prologues of compute_flow_corrs (segmentation.py:519-538: thresh / binarize / range_thresh / normalize / zscore /
+    Spearman argsort, alone and combined) against the reference's own outputs for each (tests/golden/flowstats_options.npz)."""
+    from make_golden import FLOW_OPTION_CASES
+
+    g = np.load(os.path.join(GOLDEN, "flowstats_options.npz"))
+    fl = _inputs()
+    for name, kw in FLOW_OPTION_CASES.items():
+        out = FO.compute_flow_corrs(fl, 2, **kw).numpy()
+        assert out.shape == g[name].shape and np.array_equal(out, g[name]), name
+    # the options change the result (the fixtures exercise them)
+    base = FO.compute_flow_corrs(fl, 2, True).numpy()
+    assert all(np.abs(g[k] - base).max() > 1e-3 for k in ("thresh_cov", "range_thresh_cov", "normalize_cov", "spearman_zscore_cov"))
+
+
 def test_covariance_properties():
     """Size-independent properties used again at full size on the GPU: symmetry, non-negative diagonal, constant sample rows
     have zero variance, sharding the samples and adding the sufficient statistics reproduces the covariance."""
