@@ -7,18 +7,17 @@
 
 namespace cwm {
 
-// Query tile / (batch, head) of this workgroup for a grid of (nqb, nbh) workgroups of `rows` query rows.  Speed only -- the mapping
+// Query tile / (batch, head) of work item L (dispatch order) of nqb x nbh items of `rows` query rows each.  Speed only -- the mapping
 // is a bijection, any placement is correct:
 //  * all query tiles of one (batch, head) go to ONE XCD (workgroups are dealt round-robin over the 8 XCDs by their linear id), so its
 //    K / V tiles are fetched into one L2 instead of up to eight (ViT-B/8 encoder: 7 tiles per head, 405 KB of K / V per head)
 //  * inside an XCD the ragged last query tile of every head (N = 792: 24 of 128 rows, one active wave) is dispatched after all full
 //    tiles, so that those light workgroups fill the tail of the launch instead of being spread through it
-__device__ __forceinline__ void attn_tile_of_block(int nq, int rows, bool remap, int& qt, int& bh) {
-    const int nqb = gridDim.x, nbh = gridDim.y;
-    qt = blockIdx.x;
-    bh = blockIdx.y;
+__device__ __forceinline__ void attn_tile_of_item(int L, int nqb, int nbh, int nq, int rows, bool remap, int& qt, int& bh) {
+    qt = L % nqb;
+    bh = L / nqb;
     if (nbh % 8 != 0 || !remap) return;
-    const int L = blockIdx.y * nqb + blockIdx.x, xcd = L & 7, idx = L >> 3, per = nbh >> 3;
+    const int xcd = L & 7, idx = L >> 3, per = nbh >> 3;
     const int light = (nqb > 1 && (nq - (nqb - 1) * rows) * 2 <= rows) ? 1 : 0;  // last tile at most half full
     const int heavy = nqb - light;
     if (idx < per * heavy) {
@@ -28,6 +27,10 @@ __device__ __forceinline__ void attn_tile_of_block(int nq, int rows, bool remap,
         bh = xcd * per + (idx - per * heavy);
         qt = nqb - 1;
     }
+}
+// (the same for a 2-D grid of (nqb, nbh) workgroups: linear id = dispatch order)
+__device__ __forceinline__ void attn_tile_of_block(int nq, int rows, bool remap, int& qt, int& bh) {
+    attn_tile_of_item(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, nq, rows, remap, qt, bh);
 }
 
 __device__ __forceinline__ int lds_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }

@@ -18,7 +18,11 @@
 // computed in iteration t - 1) and V(t+1) (slot of V(t-1)), and ends with vmcnt(0) + one workgroup barrier, a whole
 // tile of work later.
 #include "attention_tail.h"
+#include <algorithm>
 #include <cstdio>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace cwm {
 
@@ -33,6 +37,7 @@ __device__ unsigned long long g_pipe_blocks[8192 * 8];
 namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr int kKsplitMaxWgs = 512;  // workgroups of a key-split tail round (at most one round of slots on MI355X)
 
 template <int PLANES>
 struct PipeWave {
@@ -258,10 +263,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
     const int qcol = lane & 31, hh = lane >> 5;
     const int N = p.n_tok;
     const int NQ = p.n_q > 0 ? p.n_q : N;
+    const int nkt_all = (N + 63) / 64;
+    // work item of this workgroup (1-D grid in dispatch order).  Key-split tail round: the items of a last round that would fill at most half of
+    // the chip's workgroup slots are cut into ks_parts key ranges each, one workgroup per range, so that the round ends after 1 / ks_parts of a
+    // workgroup period instead of a whole one (ViT-L/4 decoder, batch 8: 3136 items on 512 slots = 6.125 rounds -> 6 + 1/8)
+    int item = blockIdx.x, kt0 = 0, nkt = nkt_all, part = -1;
+    if (p.ks_parts > 0 && item >= p.ks_main) {
+        const int sidx = item - p.ks_main;
+        item = p.ks_main + sidx / p.ks_parts;
+        part = sidx - (sidx / p.ks_parts) * p.ks_parts;
+        kt0 = nkt_all * part / p.ks_parts;
+        nkt = nkt_all * (part + 1) / p.ks_parts;  // this workgroup's key tiles: [kt0, nkt)
+    }
     int qt, bh;
-    attn_tile_of_block(NQ, 32 * NW, p.remap != 0, qt, bh);
+    attn_tile_of_item(item, p.ks_nqb, p.batch * p.heads, NQ, 32 * NW, p.remap != 0, qt, bh);
     if constexpr (NW == 4) {
-        if (attention_is_split_tail(p, qt, gridDim.x, NQ)) {  // ragged last tile of <= 32 rows: the four waves split the keys (attention_tail.h)
+        if (attention_is_split_tail(p, qt, p.ks_nqb, NQ)) {  // ragged last tile of <= 32 rows: the four waves split the keys (attention_tail.h)
             attention_tail_block<PLANES>(p, smem, bh, qt * 128, NQ);
             return;
         }
@@ -379,18 +396,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
 #else
 #define PROF_ARGS
 #endif
-    const int nkt = (N + 63) / 64;
     f32x16 sa[2], sb[2];
-    stage_k(0);
-    stage_v(0);
-    if (nkt > 1) stage_k(1);
+    stage_k(kt0);
+    stage_v(kt0);
+    if (kt0 + 1 < nkt) stage_k(kt0 + 1);
     CWM_TILE_END();
-    if (active) qk_plain<PLANES>(w, smem, sa);
+    if (active) qk_plain<PLANES>(w, smem + (kt0 & 1) * SLOT_BYTES, sa);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();  // K(0) is re-staged by tile 0
+    __builtin_amdgcn_s_barrier();  // K(kt0) is re-staged by the first tile
     __builtin_amdgcn_sched_barrier(0);
 
-    int kt = 0;
+    int kt = kt0;
     for (; kt + 4 < nkt; kt += 2) {  // tiles staged here (up to K(kt + 3)) are never the last one: no row clamp
         CWM_TILE(true, sa, sb, kt, std::false_type{});
         CWM_TILE(true, sb, sa, kt + 1, std::false_type{});
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
     pacc[4] = __builtin_amdgcn_s_memtime() - t_begin;
     pacc[5] = __builtin_amdgcn_s_memrealtime() - r_begin;
     {
-        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+        const int bid = blockIdx.x;
         if (wave == 0 && lane == 0 && bid < 8192) {
             g_pipe_blocks[bid * 8 + 0] = r_begin;
             g_pipe_blocks[bid * 8 + 1] = r_begin + pacc[5];
@@ -430,8 +446,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         for (int i = 0; i < 8; ++i) g_pipe_prof[i] = pacc[i];
 #endif
 
-    // ---- normalise and store O[q][h*64 + d] ----------------------------------------------------------
     const float l_tot = w.l_run + __shfl_xor(w.l_run, 32, 64);
+    if (part >= 0) {
+        // ---- key-split tail round: leave (O^T unnormalised, running max, sum) of this key range for attention_combine_kernel ----
+        const int q = q0 + qcol;
+        if (q < NQ) {
+            float* rec = p.ks_scratch + (((size_t)(item - p.ks_main) * p.ks_parts + part) * 128 + (wave * 32 + qcol)) * 68;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(rec + db * 32 + 8 * g + 4 * hh) =
+                        f32x4{w.oacc[db][4 * g], w.oacc[db][4 * g + 1], w.oacc[db][4 * g + 2], w.oacc[db][4 * g + 3]};
+            if (hh == 0) {
+                rec[64] = w.m_run;
+                rec[65] = l_tot;
+            }
+        }
+        return;
+    }
+    // ---- normalise and store O[q][h*64 + d] ----------------------------------------------------------
     const float inv = 1.0f / l_tot;
     const int q = q0 + qcol;
     if (q < NQ) {
@@ -475,14 +509,94 @@ int attention_pipe_prof(int i) {
 int attention_pipe_prof(int) { return -1; }
 #endif
 
+// Merge of the key ranges of the split items: one wave per query row, lane d.  O = sum_j O_j e^(m_j - m) / sum_j l_j e^(m_j - m), parts in
+// ascending order (deterministic); then the bf16 (hi, lo) split and the store of attention_pipe_kernel's epilogue.
+template <int PLANES>
+__global__ __launch_bounds__(256) void attention_combine_kernel(const AttnParams p) {
+    const int wave = threadIdx.x >> 6, d = threadIdx.x & 63;
+    const int N = p.n_tok, NQ = p.n_q > 0 ? p.n_q : N;
+    const int sitem = blockIdx.x / 32, qrow = (blockIdx.x % 32) * 4 + wave;
+    int qt, bh;
+    attn_tile_of_item(p.ks_main + sitem, p.ks_nqb, p.batch * p.heads, NQ, 128, p.remap != 0, qt, bh);
+    const int q = qt * 128 + qrow;
+    if (q >= NQ) return;
+    const float* rec = p.ks_scratch + (((size_t)sitem * p.ks_parts) * 128 + qrow) * 68;
+    float m = -INFINITY;
+    for (int j = 0; j < p.ks_parts; ++j) m = fmaxf(m, rec[(size_t)j * 128 * 68 + 64]);
+    float o = 0.f, l = 0.f;
+    for (int j = 0; j < p.ks_parts; ++j) {
+        const float* r = rec + (size_t)j * 128 * 68;
+        const float wgt = __builtin_amdgcn_exp2f((r[64] - m) * kLog2e);
+        o = fmaf(r[d], wgt, o);
+        l = fmaf(r[65], wgt, l);
+    }
+    const float v = o / l;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    bf16* dst = p.o + a_pos<PLANES>((int64_t)b * NQ + q, p.ldo, h * 64 + d);
+    const bf16 hi = (bf16)v;
+    *dst = hi;
+    if constexpr (PLANES == 2) dst[kLoOffset] = (bf16)(v - (float)hi);
+}
+
+int g_attn_ksplit = 1;
+
+// scratch of the key-split tail round: at most one round of partial workgroups (512 x 128 queries x 68 floats = 17.8 MB), one buffer per
+// (device, stream) -- the batch lanes launch concurrently --, created on first need
+static int ksplit_scratch(hipStream_t stream, float** out) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, float*> table;
+    int dev = 0;
+    CWM_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = table.find(std::make_pair(dev, stream));
+    if (it == table.end()) {
+        float* buf = nullptr;
+        CWM_HIP_CHECK(hipMalloc((void**)&buf, (size_t)kKsplitMaxWgs * 128 * 68 * sizeof(float)));
+        it = table.emplace(std::make_pair(dev, stream), buf).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
 template <int PLANES, int NW>
-static int launch_pipe(const AttnParams& p, hipStream_t stream) {
+static int launch_pipe(const AttnParams& p_in, hipStream_t stream) {
+    AttnParams p = p_in;
     const int nq = p.n_q > 0 ? p.n_q : p.n_tok;
-    const dim3 grid((nq + 32 * NW - 1) / (32 * NW), p.batch * p.heads);
+    const int nqb = (nq + 32 * NW - 1) / (32 * NW), nbh = p.batch * p.heads;
+    const int64_t n_items = (int64_t)nqb * nbh;
+    CWM_REQUIRE(n_items < (1ll << 30), "attention: too many (query tile, batch, head) work items");
+    p.ks_nqb = nqb;
+    p.ks_main = (int)n_items;
+    p.ks_parts = 0;
+    p.ks_scratch = nullptr;
+    int extra = 0;
+    if (NW == 4 && g_attn_ksplit) {
+        // a last round that fills at most a quarter of the slots (two workgroups per CU) costs most of a workgroup period for a fraction of a
+        // round's work: split its items' keys.  Measured (profiles/r4_microbench_attn_ksplit.log): ViT-L/4 decoder (3136 items = 6 rounds + 64,
+        // 8 ranges) 1646 -> 1597 us parity, 766 -> 753 us fast; a last round of 128 items in 4 ranges (ViT-L/4 encoder) gains nothing -- the
+        // rounds are not in lockstep, so a tail costs less than the slot arithmetic says --, hence the quarter.  Not together with the
+        // ragged-tile key split of attention_tail.h (those light tiles already fill the tail).
+        const int slots = 2 * gemm_cu_count(), nkt = (p.n_tok + 63) / 64;
+        const int rem = (int)(n_items % slots);
+        const int last_rows = nq - (nqb - 1) * 128;
+        const bool ragged_split = p.tail_split && nqb > 1 && last_rows <= 32 && p.n_tok > 128;
+        if (n_items >= slots && rem > 0 && rem * 4 <= slots && !ragged_split) {
+            int parts = std::min(8, slots / rem);
+            while (parts > 1 && nkt / parts < 6) --parts;   // every key range keeps >= 6 tiles: its prologue and the merge stay small
+            if (parts >= 2 && rem * parts <= kKsplitMaxWgs) {
+                if (int rc = ksplit_scratch(stream, &p.ks_scratch)) return rc;
+                p.ks_main = (int)(n_items - rem);
+                p.ks_parts = parts;
+                extra = rem * parts - rem;
+            }
+        }
+    }
     const size_t smem = (size_t)4 * (64 * 64 * 2) * PLANES;  // 2 K slots + 2 V slots
     if (smem > 48 * 1024)
         if (int rc = cwm_set_max_lds((const void*)attention_pipe_kernel<PLANES, NW>, (int)smem)) return rc;
-    hipLaunchKernelGGL((attention_pipe_kernel<PLANES, NW>), grid, dim3(64 * NW), smem, stream, p);
+    hipLaunchKernelGGL((attention_pipe_kernel<PLANES, NW>), dim3((unsigned)(n_items + extra)), dim3(64 * NW), smem, stream, p);
+    if (p.ks_parts > 0)
+        hipLaunchKernelGGL((attention_combine_kernel<PLANES>), dim3((unsigned)((n_items - p.ks_main) * 32)), dim3(256), 0, stream, p);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }

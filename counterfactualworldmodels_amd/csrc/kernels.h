@@ -77,6 +77,11 @@ struct AttnParams {
     int n_tok, heads, batch;
     int remap;       // set by launch_attention: XCD-aware workgroup -> (query tile, head) mapping (attention_device.h; "attn_remap" switch)
     int q_off, n_q;  // queries = rows [q_off, q_off + n_q) of every (batch, head); n_q == 0: all n_tok.  O rows are b * n_q + (q - q_off)
+    // key-split tail round (attention_pipe.hip, "attn_ksplit" switch), set by launch_attention_pipe: work items [0, ks_main) run whole; each of the
+    // remaining items is cut into ks_parts key ranges, one workgroup each, which leave (O^T unnormalised, max, sum) in ks_scratch for
+    // attention_combine_kernel.  ks_parts == 0: off
+    int ks_main, ks_parts, ks_nqb;
+    float* ks_scratch;  // [items - ks_main][ks_parts][128 queries][68]: O[64], max, sum, -, -
     int tail_split;  // set by launch_attention: a ragged last query tile of at most 32 rows splits the KEYS over its four waves (attention_tail.h; "attn_tail" switch)
 };
 
@@ -84,6 +89,7 @@ int launch_attention(const AttnParams& p, int planes, hipStream_t stream);
 int attention_pipe_prof(int i);  // per-phase s_memtime totals of block 0 wave 0 (builds with -DCWM_ATTN_PROF only)
 int launch_attention_pipe(const AttnParams& p, int planes, hipStream_t stream);  // attention_pipe.hip; arguments checked by launch_attention
 extern int g_attn_remap;   // 1 (default): attn_tile_of_block's XCD-aware mapping; 0: plain (blockIdx.x, blockIdx.y)
+extern int g_attn_ksplit;  // 1 (default): a last round of workgroups that fills at most a quarter of the chip splits its items' KEYS over the idle slots (attention_pipe.hip)
 extern int g_attn_tail;    // 1 (default): key-split schedule for a ragged last query tile of <= 32 rows; 0: the regular schedule for every tile
 extern int g_attn_kernel;  // 0 auto, 1: 4-wave kernel, 2: 8-wave staggered kernel
 

@@ -591,6 +591,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
         g_prune_last_block = value;
         return CWM_OK;
     }
+    if (!strcmp(key, "attn_ksplit")) {
+        g_attn_ksplit = value;
+        return CWM_OK;
+    }
     if (!strcmp(key, "attn_tail")) {
         g_attn_tail = value;
         return CWM_OK;

@@ -308,8 +308,10 @@ def test_attention_variants_are_bitwise_equal_to_4wave_kernel(gu, kern):
              (8, 792, 12), (6, 1568, 6)]
     try:
         # (the key-split schedule of a ragged last query tile, attention_tail.h, re-associates the key sum and exists in the 4-wave
-        # workgroups only: this cross-check runs every tile on the regular schedule; the split has its own test below)
+        # workgroups only: this cross-check runs every tile on the regular schedule; the split has its own test below.  Likewise the key-split
+        # tail round of the pipelined kernel, "attn_ksplit")
         _lib.check(lib.cwm_debug_set(b"attn_tail", 0))
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 0))
         for mode in ("parity", "fast"):
             for (B, N, H) in cases:
                 qkv = rnd(B, N, 3 * H * 64, seed=N + 1)
@@ -324,6 +326,7 @@ def test_attention_variants_are_bitwise_equal_to_4wave_kernel(gu, kern):
     finally:
         _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))
         _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1))
 
 
 def test_attention_key_split_of_the_ragged_last_tile(gu):
@@ -335,6 +338,7 @@ def test_attention_key_split_of_the_ragged_last_tile(gu):
     lib = _lib.get_lib()
     cases = [(2, 129, 1), (1, 160, 2), (2, 785, 1), (2, 792, 12), (1, 1568, 6), (8, 792, 12), (1, 897, 2), (1, 3104, 1)]
     try:
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 0))   # (the other key split, of a whole tail ROUND, would take over where this one is switched off)
         for mode in ("parity", "fast"):
             for (B, N, H) in cases:
                 qkv = rnd(B, N, 3 * H * 64, seed=N + 3)
@@ -361,3 +365,51 @@ def test_attention_key_split_of_the_ragged_last_tile(gu):
     finally:
         _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))
         _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1))
+
+
+def test_attention_key_split_tail_round(gu):
+    """attention_pipe.hip, "attn_ksplit": when the last round of workgroups would fill at most half of the chip's slots, its work items
+    are cut into key ranges (one workgroup each, partial (O, max, sum) records merged by attention_combine_kernel).  Rows of the split
+    items may differ from the unsplit schedule by the fp32 re-association of the key sum and by where the rounding of P falls; every
+    other row is bit-identical; both agree with the dense-softmax reference.  Shapes: 621 items = 1 round + 109 (3 key ranges of 6 tiles,
+    a 76-row last query tile with an idle wave), 576 items = 1 round + 64 (2 ranges), and the ViT-L/4 decoder launch itself (3136 items =
+    6 rounds + 64, 8 ranges) -- on / off only, plus one head against the dense reference."""
+    lib = _lib.get_lib()
+    try:
+        for mode in ("parity", "fast"):
+            for (B, N, H) in [(23, 1100, 3), (9, 1024, 8)]:
+                qkv = rnd(B, N, 3 * H * 64, seed=N + 5)
+                qkv[0, N - 5, H * 64:H * 64 + 64] = qkv[0, 7, :64] * 6.0  # late spike: the last key range holds the maximum of query 7
+                if mode == "fast":
+                    _lib.check(lib.cwm_debug_set(b"attn_kernel", 3))       # (fast mode takes the pipelined kernel from 2048 tokens on)
+                outs = []
+                for ks in (0, 1):
+                    _lib.check(lib.cwm_debug_set(b"attn_ksplit", ks))
+                    outs.append(gu.attention(qkv, H, mode=mode))
+                assert torch.equal(gu.attention(qkv, H, mode=mode), outs[1])            # deterministic
+                d = (outs[0] - outs[1]).abs()
+                assert d.max().item() <= (1e-4 if mode == "parity" else 1e-2), (mode, B, N, H, d.max().item())
+                changed = (d.amax(-1) > 0).sum().item()                                 # the split really ran, on rows of the last round's items only
+                rem = (-(-N // 128) * B * H) % 512                                        # work items of the last round (512 slots on MI355X)
+                assert 0 < changed <= rem * 128, (mode, B, N, H, changed)
+                err = (outs[1] - ref_attention(qkv, H)).abs().max().item()
+                assert err <= (5e-4 if mode == "parity" else 5e-2), (mode, B, N, H, err)
+        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))
+        B, N, H = 8, 6272, 8
+        qkv = rnd(B, N, 3 * H * 64, seed=77)
+        for mode in ("parity", "fast"):
+            outs = []
+            for ks in (0, 1):
+                _lib.check(lib.cwm_debug_set(b"attn_ksplit", ks))
+                outs.append(gu.attention(qkv, H, mode=mode))
+            d = (outs[0] - outs[1]).abs()
+            assert d.max().item() <= (1e-4 if mode == "parity" else 1e-2), (mode, d.max().item())
+            assert 0 < (d.amax(-1) > 0).sum().item() <= 64 * 128
+            one = qkv[3:4].reshape(1, N, 3, H, 64)[:, :, :, 5].reshape(1, N, 192)       # batch 3, head 5 through the dense reference
+            ref = ref_attention(one, 1)
+            err = (outs[1][3:4, :, 5 * 64:6 * 64] - ref).abs().max().item()
+            assert err <= (5e-4 if mode == "parity" else 5e-2), (mode, err)
+    finally:
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1))
+        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))

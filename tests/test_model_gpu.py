@@ -331,6 +331,7 @@ def test_last_decoder_block_pruning_is_exact():
     try:
         _lib.check(lib.cwm_debug_set(b"gemm_debug", 32))
         _lib.check(lib.cwm_debug_set(b"attn_tail", 0))
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 0))
         for cfg, name in cases:
             g = np.load(os.path.join(GOLDEN, name))
             seed, x, mask = case_inputs(g, cfg)
@@ -344,6 +345,7 @@ def test_last_decoder_block_pruning_is_exact():
                 assert torch.equal(outs[0], outs[1]), (name, mode, (outs[0] - outs[1]).abs().max().item())
         _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
         _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1))
         for cfg, name in cases:  # library defaults (split-K where the heuristic takes it, key-split attention tails): equal to rounding
             g = np.load(os.path.join(GOLDEN, name))
             seed, x, mask = case_inputs(g, cfg)
@@ -358,6 +360,7 @@ def test_last_decoder_block_pruning_is_exact():
         _lib.check(lib.cwm_debug_set(b"prune_last_block", 1))
         _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
         _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1))
 
 
 def test_two_lanes_match_one_lane_and_report_mask_errors_of_both():
