@@ -154,6 +154,7 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p] * 6,
     ),
+    "cwm_gemm_tile_override": (C.c_int, [C.c_int] * 6),
     "cwm_flow_features": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "cwm_flow_cov": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 4),
     "cwm_flow_transform": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

@@ -23,8 +23,10 @@
 //   columns of one row
 // * fused epilogues (bias, residual(+row map), exact-erf GELU, bf16 hi/lo split, Q / K / V head scatter), staged through LDS so
 //   that every global access is an unconditional 16-byte lane access forming whole row segments (gemm_device.h)
+#include <atomic>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <utility>
 
 #include "gemm_device.h"
@@ -492,6 +494,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
     GEMM_PROF_MAIN();
     // (the balancing barrier above is also the point where every wave is done reading the operand tiles)
     if (p.direct) {
+        // (Building this table in the kernel's prologue, behind the operand ring, and dropping the barrier pair that only protects the ring --
+        // so that every wave goes from its last MFMA straight to its stores -- measured equal on every GEMM shape and 0.7-1 % SLOWER on the
+        // step, profiles/r4_ab_gemm_prologue_table.log: the epilogue is bound by the output stores, not by its start-up.)
         int4* tab = reinterpret_cast<int4*>(smem);
         epilogue_row_table(p, tab, m0, 256, tid);
         __syncthreads();
@@ -596,10 +601,41 @@ int launch_gemm_tile(const GemmParams& p_in, int planes, int cfg, hipStream_t st
 
 int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) { return launch_gemm_checked(p_in, planes, 0, stream); }
 
-// Tile configuration for a launch: g_gemm_tile (development switch) if set, else per shape.
+// Per-shape overrides of the tile choice (cwm_gemm_tile_override: the tuning hook behind tools/autotune_step.py).  All configurations
+// give bit-identical results (tests/test_kernels_gpu.py), so an override can only change the speed.
+namespace {
+struct TileKey {
+    int M, N, K, epi, ovl;
+    bool operator<(const TileKey& o) const { return std::tie(M, N, K, epi, ovl) < std::tie(o.M, o.N, o.K, o.epi, o.ovl); }
+};
+std::mutex g_tile_mu;
+std::map<TileKey, int> g_tile_overrides;
+std::atomic<int> g_tile_override_count{0};
+}  // namespace
+
+int gemm_tile_override(int M, int N, int K, int epi, int overlapped, int cfg) {
+    std::lock_guard<std::mutex> lock(g_tile_mu);
+    if (M <= 0) {
+        g_tile_overrides.clear();
+    } else if (cfg == 0) {
+        g_tile_overrides.erase(TileKey{M, N, K, epi, overlapped ? 1 : 0});
+    } else {
+        CWM_REQUIRE(cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 6, "gemm_tile_override: unknown tile configuration %d", cfg);
+        g_tile_overrides[TileKey{M, N, K, epi, overlapped ? 1 : 0}] = cfg;
+    }
+    g_tile_override_count.store((int)g_tile_overrides.size());
+    return 0;
+}
+
+// Tile configuration for a launch: g_gemm_tile (development switch) if set, else a per-shape override, else the measured rule.
 int gemm_choose_tile(const GemmParams& p, int planes) {
     (void)planes;
-    int cfg = g_gemm_tile;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase, 6: 4 + 1 by rows
+    int cfg = g_gemm_tile;
+    if (cfg == 0 && g_tile_override_count.load(std::memory_order_relaxed) > 0) {
+        std::lock_guard<std::mutex> lock(g_tile_mu);
+        auto it = g_tile_overrides.find(TileKey{p.M, p.N, p.K, p.epi, p.overlapped ? 1 : 0});
+        if (it != g_tile_overrides.end()) cfg = it->second;
+    }  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase, 6: 4 + 1 by rows
     if (cfg == 0) {
         // Measured on MI355X (tools/microbench.py gemm / gemm_mid / gemm_l4: B/8 at batch 8, 16, 32 and L/4 batch 8, both modes;
         // profiles/r1n_*, r1o_*, r1p_* logs).  The 256x256 8-phase kernel has the fastest main loop (~1.6 PFLOP/s of executed MFMA

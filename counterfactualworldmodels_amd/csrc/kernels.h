@@ -59,6 +59,7 @@ int launch_gemm(const GemmParams& p, int planes, hipStream_t stream);
 int gemm_choose_tile(const GemmParams& p, int planes);
 bool gemm_mixed_split(const GemmParams& p, GemmParams* big, GemmParams* rest);  // tile configuration 6
 int launch_gemm_tile(const GemmParams& p, int planes, int cfg, hipStream_t stream);  // 1: 128x128 ... 4: 256x256 8-phase (see g_gemm_tile)
+int gemm_tile_override(int M, int N, int K, int epi, int overlapped, int cfg);  // per-shape tile choice (cfg 0: remove, M <= 0: clear all)
 int gemm_cu_count();  // compute units of the current device, rounded down to a multiple of the 8 XCDs (256 on MI355X)
 int gemm_prof_dump();  // builds with -DCWM_GEMM_PROF: per-workgroup timers of gemm8p_kernel -> /tmp/gemm_blocks.bin
 extern int g_gemm_debug;

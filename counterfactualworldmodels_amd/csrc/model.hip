@@ -631,6 +631,8 @@ extern "C" int cwm_debug_set(const char* key, int value) {
     return CWM_ERR_INVALID;
 }
 
+extern "C" int cwm_gemm_tile_override(int M, int N, int K, int epi, int overlapped, int cfg) { return gemm_tile_override(M, N, K, epi, overlapped, cfg); }
+
 extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters, double* avg_us) {
     CWM_REQUIRE(avg_us && M > 0 && N > 0 && K > 0 && iters > 0, "cwm_bench_gemm: bad argument");
     CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_bench_gemm: bad mode");

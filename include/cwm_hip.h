@@ -259,6 +259,11 @@ int cwm_allgather(cwm_comm* c, const void* send_dev, void* recv_dev, size_t byte
 int cwm_allgatherv(cwm_comm* c, const void* send_dev, void* recv_dev, const size_t* offsets, const size_t* counts, void* stream);
 int cwm_allreduce_sum_f32(cwm_comm* c, float* buf_dev, size_t count, void* stream);
 
+/* Tuning hook (tools/autotune_step.py): fix the output-tile configuration of every GEMM launch of one shape -- M, N, K as launched (K padded to
+ * 64), epi 0 fp32 / 1 bf16+GELU / 2 bf16 / 3 QKV scatter, overlapped = inside a two-lane forward -- to cfg 1 (128x128), 4 (256x256 8-phase) or 6 (4 for
+ * the whole rounds + 1 for the remaining rows); cfg 0 removes the entry, M <= 0 clears the table.  Every configuration gives bit-identical results. */
+int cwm_gemm_tile_override(int M, int N, int K, int epi, int overlapped, int cfg);
+
 /* ---- diagnostics: single-kernel micro-benchmarks on random operands (tools/microbench.py) ---------
  * epi: 0 = fp32 out + bias + in-place residual (proj/fc2 form), 1 = bias + GELU -> bf16 (fc1 form),
  *      3 = QKV head scatter (N must be 3*64*heads, M = batch*n_tok with n_tok = M / batch).
