@@ -9,11 +9,13 @@ namespace cwm {
 // ---------------------------------------------------------------------------------------------
 // LayerNorm (eps 1e-6, affine) -> bf16 hi(/lo) planes.  Reference: nn.LayerNorm call sites
 // VideoMAE/utils.py:148-149 (norm1/norm2), vmae.py:172 (encoder.norm), :251 (decoder.norm on the
-// last Nm tokens).  One wave per row, row kept in registers (16-byte loads, 8-byte stores), two-pass mean/variance in fp32.
+// last Nm tokens).  One wave per row, row kept in registers (16-byte loads and stores), two-pass mean/variance in fp32.
 // ---------------------------------------------------------------------------------------------
 template <int PLANES>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p) {
-    constexpr int MAXI = 4;  // D <= 1024: lane l owns elements 4 l + 256 i .. + 3 (16-byte loads, 8-byte stores per plane)
+    constexpr int MAXI = 2;  // D <= 1024: lane l owns elements 8 l + 512 i .. + 7 (two 16-byte loads; ONE 16-byte store per plane: round 4 --
+                             // 8-byte stores ran at 0.55-0.7 of the 16-byte rate, MI355X_MICROARCH.md; 8 consecutive k never straddle a
+                             // 32-k [hi | lo] block)
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= p.rows) return;
@@ -23,59 +25,65 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
         in_row = b * p.rows_in_per_b + p.in_offset + (r - b * p.rows_out_per_b);
     }
     const float* x = p.x + (size_t)in_row * p.ldx;
-    f32x4 v[MAXI];
+    f32x4 v[MAXI][2];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-        const int idx = lane * 4 + i * 256;
+        const int idx = lane * 8 + i * 512;
         if (idx < p.D) {
-            v[i] = *reinterpret_cast<const f32x4*>(x + idx);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            v[i][0] = *reinterpret_cast<const f32x4*>(x + idx);
+            v[i][1] = *reinterpret_cast<const f32x4*>(x + idx + 4);
+            s += ((v[i][0][0] + v[i][0][1]) + (v[i][0][2] + v[i][0][3])) + ((v[i][1][0] + v[i][1][1]) + (v[i][1][2] + v[i][1][3]));
         } else {
-            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            v[i][0] = v[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     const float mean = wave_sum_dpp(s) / (float)p.D;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-        const int idx = lane * 4 + i * 256;
+        const int idx = lane * 8 + i * 512;
         if (idx < p.D) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a = v[i][e] - mean;
-                sq += a * a;
-            }
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = v[i][h][e] - mean;
+                    sq += a * a;
+                }
         }
     }
     const float rstd = rsqrtf(wave_sum_dpp(sq) / (float)p.D + p.eps);
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-        const int idx = lane * 4 + i * 256;
+        const int idx = lane * 8 + i * 512;
         if (idx < p.D) {
-            bf16* out = p.out + a_pos<PLANES>(r, p.ldo, idx);  // 4 consecutive k never straddle a 32-k [hi | lo] block
-            const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + idx);
-            const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + idx);
-            f32x4 y;
-            bf16x4 hv, lv;
+            bf16* out = p.out + a_pos<PLANES>(r, p.ldo, idx);
+            bf16x8 hv, lv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                y[e] = (v[i][e] - mean) * rstd * g[e] + be[e];
-                bf16 h, l;
-                split_bf16(y[e], h, l);
-                hv[e] = h;
-                lv[e] = l;
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + idx + 4 * h);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + idx + 4 * h);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = (v[i][h][e] - mean) * rstd * g[e] + be[e];
+                    bf16 hh, ll;
+                    split_bf16(y[e], hh, ll);
+                    hv[4 * h + e] = hh;
+                    lv[4 * h + e] = ll;
+                }
+                if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)r * p.D + idx + 4 * h) = y;
             }
-            *reinterpret_cast<bf16x4*>(out) = hv;
-            if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(out + kLoOffset) = lv;
-            if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)r * p.D + idx) = y;
+            *reinterpret_cast<bf16x8*>(out) = hv;
+            if constexpr (PLANES == 2) *reinterpret_cast<bf16x8*>(out + kLoOffset) = lv;
         }
     }
 }
 
 int launch_layernorm(const LayerNormParams& p, int planes, hipStream_t stream) {
-    CWM_REQUIRE(p.D % 4 == 0 && p.D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", p.D);
-    CWM_REQUIRE(p.ldx % 4 == 0 && p.ldo % 4 == 0, "layernorm: row strides must be multiples of 4");
+    CWM_REQUIRE(p.D % 8 == 0 && p.D <= 1024, "layernorm: D=%d must be a multiple of 8 and <= 1024", p.D);
+    CWM_REQUIRE(p.ldx % 4 == 0 && p.ldo % 8 == 0, "layernorm: row strides must be multiples of 4 (input) / 8 (output)");
     const int blocks = (p.rows + 3) / 4;
     if (g_gemm_debug & 8) return 0;  // ablation (cwm_debug_set "gemm_debug" bit 3): what the step would cost without any LayerNorm launch
     if (planes == 1)
