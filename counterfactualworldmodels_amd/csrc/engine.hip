@@ -32,7 +32,7 @@ int cwm_set_max_lds(const void* kernel, int bytes) {
     done.insert({dev, kernel});
     return 0;
 }
-extern "C" const char* cwm_version(void) { return "cwm_hip 0.4.0 gfx950"; }
+extern "C" const char* cwm_version(void) { return "cwm_hip 0.5.0 gfx950"; }
 #ifndef CWM_SRC_HASH
 #define CWM_SRC_HASH "unknown"
 #endif

@@ -148,8 +148,8 @@ int cwm_conj_timing_collect(cwm_conj_model* m, int kclass, struct cwm_kernel_sta
 /* ---- timing hooks (bench.py roofline): HIP events around every launch of one kernel class ------ */
 #define CWM_KCLASS_GEMM 0        /* every GEMM launch */
 #define CWM_KCLASS_ATTENTION 1
-#define CWM_KCLASS_GEMM_WIDE 2   /* the GEMM launches that ran the 256x256 8-phase kernel (K >= 512, wide N: encoder qkv, fc1, fc2) */
-#define CWM_KCLASS_GEMM_NARROW 3 /* ... the 128x128 kernels (proj, K < 512, head, patch embed); both enabled / collected with class 0 */
+#define CWM_KCLASS_GEMM_WIDE 2   /* the GEMM launches that ran the 256x256 8-phase kernel (wide N with at least half a round of tiles: qkv, fc1, whole rounds of fc2) */
+#define CWM_KCLASS_GEMM_NARROW 3 /* ... the 128x128 kernels (proj, narrow N, head, patch embed, mixed-tiling remainders); both enabled / collected with class 0 */
 /* HBM-bound edge kernels (SURVEY.md 8d "reported separately as achieved GB/s"): for these classes `total_flops` holds the
  * algorithmic BYTES of the launches (each input element read once, each output element written once), not FLOPs */
 #define CWM_KCLASS_LAYERNORM 4    /* rows * D * (4 read + 2 * planes written) */
@@ -275,17 +275,18 @@ int cwm_bench_attention(int B, int H, int N, int mode, int iters, double* avg_us
 int cwm_bench_gemm_gapped(int M, int N, int K, int mode, int epi, int iters, int gap_us, double* avg_us);
 /* development switches (PROCESS-WIDE, not per model handle: for tests and measurements, never for production use -- a second
  * model in the same process sees the same values): "gemm_tile" (0 automatic per shape, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase,
- * 5: persistent stream-K 8-phase, 6: 8-phase rounds + 128x128 remainder rows), "gemm_staged" (0: direct per-fragment epilogue),
+ * 6: 8-phase rounds + 128x128 remainder rows), "gemm_direct" (1, default: bf16-output epilogues store 16 bytes per lane straight from the accumulators;
+ * 2: the fp32-output epilogues too; 0: every epilogue through the LDS staging buffer), "gemm_staged" (0: the per-fragment epilogue of round 1),
  * "gemm_debug" (bit mask of ablations / A-B switches: 1 skip the epilogue's global stores, 2 skip the epilogue, 4 no 4-stage ring for small launches, 8 skip every
  * LayerNorm launch (timing only), 16 small launches on 4 instead of 8 waves, 32 no split-K, 64 the 128x128 kernel as 4-wave workgroups, 128 the one-lane tile
- * choice also inside a two-lane call, 256 the round-1 thresholds of the tile choice), "attn_kernel" (0 automatic, 1: 4-wave, 2: staggered 8-wave, 3: software-pipelined 4-wave),
+ * choice also inside a two-lane call, 512 bf16-output GEMMs with K < 512 stay on 128x128 tiles), "attn_kernel" (0 automatic, 1: 4-wave, 3: software-pipelined 4-wave),
  * "attn_remap" (0: plain workgroup order instead of one XCD per (batch, head) with the ragged query tiles last), "attn_tail" (0: the regular schedule
- * also for a ragged last query tile of <= 32 rows instead of splitting its keys over the four waves),
- * "prune_last_block" (0: run the last decoder block over all tokens), "ln_fuse" (1: LayerNorm folded into the GEMMs around it instead of the
- * stand-alone LayerNorm kernels -- measured slower, off by default; a model carries the fold state only if it was CREATED while the switch was on),
+ * also for a ragged last query tile of <= 32 rows instead of splitting its keys over the four waves), "attn_ksplit" (0: a nearly empty last round of
+ * workgroups runs its items whole instead of cutting them into key ranges),
+ * "prune_last_block" (0: run the last decoder block over all tokens),
  * "conj_attn" (0: the fp32 VALU cross / context attention kernels of the IMU-conditioned model instead of the MFMA ones), "conj_ctx_stream" (0: the
- * context stream's blocks on the lane's own stream instead of a side stream between cross blocks); queries: "sk_error" (non-zero return = a stream-K hand-off
- * wait timed out), "attn_prof" / "gemm_prof" (per-workgroup timers of builds with -DCWM_ATTN_PROF / -DCWM_GEMM_PROF) */
+ * context stream's blocks on the lane's own stream instead of a side stream between cross blocks); queries: "attn_prof" / "gemm_prof" (per-workgroup
+ * timers of builds with -DCWM_ATTN_PROF / -DCWM_GEMM_PROF) */
 int cwm_debug_set(const char* key, int value);
 
 const char* cwm_last_error(void);
