@@ -391,7 +391,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, Frag frag, 
                 for (int j = 0; j < 2; ++j) {
                     const int n = nb + j * 16 + fq * 4;
                     const bool ok = p.resid && info.x >= 0 && n < p.N;
-                    const gf32x4* src = ok ? (const gf32x4*)(p.resid + (size_t)info.y * p.ldr + n) : trash;
+                    const gf32x4* src = ok ? (const gf32x4*)(p.resid + (size_t)max(info.y, 0) * p.ldr + n) : trash;
                     rv[i][j] = *src;
                 }
             }
@@ -411,7 +411,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, Frag frag, 
                     const bool ok = info.x >= 0 && n < p.N;
                     f32x4 v = frag(pi, i, j) + bias[pi][j];
                     if (ok && p.resid) v += rv[pi & 1][i][j];
-                    gf32x4* dst = ok ? (gf32x4*)(p.C + (size_t)info.x * p.ldc + n) : trash;
+                    gf32x4* dst = ok ? (gf32x4*)(p.C + (size_t)max(info.x, 0) * p.ldc + n) : trash;
                     if (!(p.debug & 1)) *dst = v;
                     else asm volatile("" ::"v"(v), "v"(dst));
                 }
@@ -456,7 +456,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, Frag frag, 
                 }
             }
             const bool ok = info.x >= 0 && n < p.N;
-            bf16* d = base + (size_t)info.x * row_mul;
+            bf16* d = base + (size_t)max(info.x, 0) * row_mul;  // (info.x < 0: a row past M -- the lane stores to the trash buffer instead)
             gbf16x8* dh = ok ? (gbf16x8*)d : (gbf16x8*)trash;
             gbf16x8* dl = ok ? (gbf16x8*)(d + lo_off) : (gbf16x8*)trash;
             if (p.debug & 1) {
