@@ -119,8 +119,13 @@ __device__ __forceinline__ void pv_step(PipeWave<PLANES>& w, const f32x16 (&sc)[
 //   kbase: LDS image of K(t+1); va0 / va1: LDS addresses of this lane's V(t) transposed-read blocks (d halves)
 //   dma(i): issues LDS-DMA piece i (< NDMA) of the tiles staged in this iteration -- one per slot at the head of phase
 //   A: issued back to back they hold the wave for ~60 cycles each (measured: ~500 cycles per tile)
+//   half: the sequence's LAST key tile holds at most 32 keys (every model shape: N = 792, 1568, 3168 are 32 mod 64 or less), i.e. its
+//   second key block is all padding.  HAS_NEXT: that tile is the NEXT one -- its S MFMAs of key block 1 are skipped (the values are set to
+//   -inf by the last tile anyway); !HAS_NEXT: it is THIS one -- k-steps 2 / 3 of P V (P exactly 0) are skipped.  Bit-identical: an
+//   accumulator that only ever adds products to +0 is never -0, so adding the +-0 products changes no bit.
 template <int PLANES, bool HAS_NEXT, int NDMA, typename Dma>
-__device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], f32x16 (&sn)[2], const char* kbase, unsigned va0, unsigned va1, int kt, int N, Dma&& dma
+__device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], f32x16 (&sn)[2], const char* kbase, unsigned va0, unsigned va1, int kt, int N, bool half,
+                                          Dma&& dma
 #ifdef CWM_ATTN_PROF
     , bool prof, unsigned long long (&pacc)[8], unsigned long long& tlast
 #endif
@@ -175,7 +180,7 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
         for (int m = 0; m < NM; ++m) {
             const int slot = g * NM + m;
             if (slot < NDMA) dma(slot);
-            if constexpr (HAS_NEXT) {
+            if (HAS_NEXT && !(kb == 1 && half)) {
                 if constexpr (PLANES == 2) {
                     if (m == 0) sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g][PLANES - 1], w.qf[0][sx], sn[kb], 0, 0, 0);
                     if (m == 1) sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g][0], w.qf[PLANES - 1][sx], sn[kb], 0, 0, 0);
@@ -234,6 +239,14 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
     __builtin_amdgcn_sched_barrier(0);
     lds_wait_v_step<NRD, PLANES>(vr0);
     pv_step<PLANES, 0>(w, sc, vr0, ph0, pl0, ph1, pl1);
+    if constexpr (!HAS_NEXT) {
+        if (half) {
+            lds_wait_v_step<0, PLANES>(vr1);
+            pv_step<PLANES, 1>(w, sc, vr1, ph1, pl1, ph0, pl0);
+            PROF_T(2);
+            return;
+        }
+    }
     lds_read_v_step<2, PLANES>(vr0, va0, va1);
     lds_wait_v_step<NRD, PLANES>(vr1);
     pv_step<PLANES, 1>(w, sc, vr1, ph1, pl1, ph0, pl0);
@@ -378,7 +391,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         PROF_T(0);                                                                                                                     \
         if (active) {                                                                                                                  \
             pipe_tile<PLANES, HAS_NEXT, 2 * NP>(w, SC, SN, smem + (((KT) + 1) & 1) * SLOT_BYTES, v_addr[0] + ((KT)&1) * SLOT_BYTES,             \
-                                        v_addr[1] + ((KT)&1) * SLOT_BYTES, (KT), N, dma PROF_ARGS);                                    \
+                                        v_addr[1] + ((KT)&1) * SLOT_BYTES, (KT), N,                                                    \
+                                        decltype(CLAMP)::value && half_last && (KT) + (HAS_NEXT ? 2 : 1) == nkt, dma PROF_ARGS);        \
         } else {                                                                                                                       \
             if (more_k) stage_k((KT) + 2);                                                                                             \
             if (HAS_NEXT) stage_v((KT) + 1);                                                                                           \
@@ -396,6 +410,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
 #else
 #define PROF_ARGS
 #endif
+    // the sequence's last key tile is in this workgroup's range and at most half full (pipe_tile: `half`)
+    const bool half_last = nkt == nkt_all && ((N - 1) & 63) < 32;
     f32x16 sa[2], sb[2];
     stage_k(kt0);
     stage_v(kt0);

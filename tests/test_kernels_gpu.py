@@ -79,7 +79,7 @@ def ref_attention(qkv, H):
 
 
 @pytest.mark.parametrize("mode", ["parity", "fast"])
-@pytest.mark.parametrize("B,N,H", [(1, 64, 1), (2, 40, 2), (1, 128, 2), (2, 200, 3), (1, 792, 2), (1, 785, 1), (1, 1568, 1), (1, 3168, 1),
+@pytest.mark.parametrize("B,N,H", [(1, 64, 1), (2, 40, 2), (1, 96, 1), (1, 97, 1), (1, 128, 2), (2, 200, 3), (1, 792, 2), (1, 785, 1), (1, 1568, 1), (1, 3168, 1),
                                    (1, 6272, 1), (1, 6336, 2), (8, 792, 1), (2, 1568, 4)])  # L/4 decoder, IMU decoder (padded), XCD-mapped grids (B*H % 8 == 0)
 def test_attention_matches_dense_softmax(gu, mode, B, N, H):
     qkv = rnd(B, N, 3 * H * 64, seed=N)
