@@ -26,6 +26,11 @@ import numpy as np
 if lib.cwm_debug_set(b"attn_prof", 1000) == 0:
     nblk = B * H * ((N + 127) // 128)
     r = np.fromfile("/tmp/attn_blocks.bin", dtype=np.uint64).reshape(-1, 8)[:nblk].astype(np.int64)
+    n_all = len(r)
+    xcd_of = (np.arange(n_all) & 7)[r[:, 0] > 0]  # workgroups are dealt round-robin over the XCDs by linear id
+    r = r[r[:, 0] > 0]  # workgroups of the ragged query tile (attention_tail.h) leave no record
+    nblk = len(r)
+    print("workgroups with a record: %d of %d" % (nblk, n_all))
     t0 = r[:, 0].min()
     start, end, cyc, hw = (r[:, 0] - t0) / 100.0, (r[:, 1] - t0) / 100.0, r[:, 2], r[:, 3]
     dur = end - start
@@ -37,6 +42,15 @@ if lib.cwm_debug_set(b"attn_prof", 1000) == 0:
     # concurrency: number of blocks alive over time
     ts = np.linspace(0, end.max(), 13)[1:-1]
     print("  alive blocks at", " ".join("%.0fus:%d" % (t, ((start <= t) & (end > t)).sum()) for t in ts))
+    print("  sum of workgroup durations / 512 slots: %.1f us; last start %.1f us; ends: p50 %.1f  p90 %.1f  p99 %.1f  max %.1f us" % (
+        dur.sum() / 512, start.max(), *np.percentile(end, [50, 90, 99]), end.max()))
+    for x in range(8):
+        sel = xcd_of == x
+        st, en, du = start[sel], end[sel], dur[sel]
+        o = np.argsort(st)
+        print("  XCD %d: n %4d  mean duration %.1f us  clock %.2f GHz  first-64 mean %.1f  last end %.1f us  busy slot-time %.1f us of 64 slots  starts #64/#128/#192/#256: %s" % (
+            x, sel.sum(), du.mean(), (cyc[sel] / du).mean() / 1e3, du[o[:64]].mean(), en.max(), du.sum() / 64,
+            " ".join("%.1f" % st[o[k]] for k in (64, 128, 192, 256) if k < len(o))))
     print("  distinct (xcc, se, cu) ids:", len(set((int(h) >> 8) & 0xfffff for h in hw)))
     ph = r[:, 4:8] / float(nkt)
     print("  per-workgroup phase cycles per tile (wave 0): median stage/DMA %.0f  phase A %.0f  phase B %.0f  wait+barrier %.0f   (p90: %.0f %.0f %.0f %.0f)" % (
