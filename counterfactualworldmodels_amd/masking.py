@@ -17,6 +17,8 @@ class RectangularizeMasks:
         assert truncation_mode in ["min", "max", "mean", "full", "none", None], truncation_mode
         self._mode = truncation_mode
         self.last_num_masked = None
+        self.spin_wait = True  # poll for the device -> host copy of the masks instead of blocking on it (see _to_host)
+        self._event = None
 
     def set_mode(self, mode):
         self._mode = mode
@@ -27,7 +29,19 @@ class RectangularizeMasks:
         if getattr(self, "_stage", None) is None or self._stage.numel() < n:
             self._stage = torch.empty(max(n, 1 << 16), dtype=torch.bool, pin_memory=True)
         host = self._stage[:n].view(masks.shape)
-        host.copy_(masks)
+        if self.spin_wait:
+            # The copy waits for everything queued on the stream (the previous call's forward: milliseconds).  A blocking wait parks the thread,
+            # and the host code that follows it -- all of it between this read-back and the call's first kernel launch -- then runs on a core
+            # that has just left a sleep state: measured 190 us for what takes 40 us on a busy core (tools/wrap_host_profile.py), an idle GPU
+            # for as long.  Polling the event keeps the core awake; `spin_wait = False` restores the blocking copy.
+            host.copy_(masks, non_blocking=True)
+            if self._event is None:
+                self._event = torch.cuda.Event()
+            self._event.record(torch.cuda.current_stream(masks.device))
+            while not self._event.query():
+                pass
+        else:
+            host.copy_(masks)
         return host
 
     def __call__(self, masks: torch.Tensor) -> torch.Tensor:
@@ -44,7 +58,7 @@ class RectangularizeMasks:
         # `torch.randperm(n)` draws from the global CPU generator wherever the mask lives, and `torch.where` lists the same positions.
         work = self._to_host(masks) if masks.is_cuda else masks
         rows = work.numpy()  # (shares memory with `work`; the row edits are index arithmetic on <= Nt bytes: numpy, no thread-pool spin-up)
-        counts = np.count_nonzero(rows, axis=1).tolist()
+        counts = rows.view(np.uint8).sum(axis=1, dtype=np.int32).tolist()  # (bool rows as bytes: half the time of count_nonzero(axis=1))
         if self._mode == "min":
             target = min(counts)
         elif self._mode == "max":

@@ -48,6 +48,8 @@ class _RectBatch:
     mask: torch.Tensor
     n_masked: Optional[int]
     row_kwargs: Dict[str, object] = field(default_factory=dict)
+    weights_synced: bool = False          # `_as_rect` ran the predictor's sync_weights() already (before the mask read-back)
+    out: Optional[torch.Tensor] = None    # output video allocated there too (fused path)
 
     @property
     def rows(self) -> int:
@@ -260,14 +262,16 @@ class PredictorBasedGenerator(nn.Module):
         Nt = batch.mask.shape[1]
         n_vis = None if batch.n_masked is None else Nt - batch.n_masked
         fused = self._uses_fused_path(extra_args, batch.row_kwargs)
-        out = torch.empty(batch.x.shape, device=batch.x.device, dtype=torch.float32) if fused else None
+        out = None
+        if fused:
+            out = batch.out if batch.out is not None else torch.empty(batch.x.shape, device=batch.x.device, dtype=torch.float32)
         pieces = []
         for r0 in range(0, R, step):
             r1 = min(r0 + step, R)
             xs, ms = batch.x[r0:r1], batch.mask[r0:r1]
             if fused:
                 self.predictor.predict_video(xs, ms, normalize=self.imagenet_normalize_inputs, n_vis=n_vis, check=n_vis is None,
-                                             out_video=out[r0:r1])
+                                             out_video=out[r0:r1], weights_synced=batch.weights_synced)
                 continue
             kw = {k: (v[r0:r1] if isinstance(v, torch.Tensor) else v) for k, v in batch.row_kwargs.items()}
             if n_vis is not None and isinstance(self.predictor, ConjoinedPaddedVisionTransformer):
@@ -283,14 +287,22 @@ class PredictorBasedGenerator(nn.Module):
                 self.reset_padding_masks()  # like the reference, prediction.py:451-452)
         return out if fused else (pieces[0] if len(pieces) == 1 else torch.cat(pieces, 0))
 
-    def _as_rect(self, x, mask, row_kwargs=None) -> _RectBatch:
+    def _as_rect(self, x, mask, row_kwargs=None, extra_args=(), for_video=False) -> _RectBatch:
         """Equalise the masked count over the rows the way the reference does for every multi-row call (prediction.py:421):
         in place, on torch's global RNG, and -- the one host sync -- remember the count."""
+        # Host work that does not depend on the mask goes FIRST: the read-back below waits for everything queued on the stream (the previous
+        # call's forward), and whatever the host still has to do after it delays this call's first kernel launch by as much (measured:
+        # 230 us between the read-back and the first launch, 90 of them the walk over the parameters in sync_weights; tools/wrap_gap.py)
+        synced, out = False, None
+        if for_video and x.is_cuda and x.dim() == 5 and self._uses_fused_path(extra_args, row_kwargs or {}):
+            self.predictor.sync_weights(x.device)
+            synced = True
+            out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
         n_masked = None
         if x.size(0) > 1:
             mask = self.mask_rectangularizer(mask)
             n_masked = self.mask_rectangularizer.last_num_masked
-        return _RectBatch(x, mask, n_masked, dict(row_kwargs or {}))
+        return _RectBatch(x, mask, n_masked, dict(row_kwargs or {}), synced, out)
 
     @staticmethod
     def _select_frame(video, frame):
@@ -306,7 +318,7 @@ class PredictorBasedGenerator(nn.Module):
         mask = self.generate_mask(x) if mask is None else mask
         self.set_image_size(x.shape[-2:])
         self.inp_shape = x.shape
-        video = self._run_rect_batch(self._as_rect(x, mask, kwargs), extra_args=args)
+        video = self._run_rect_batch(self._as_rect(x, mask, kwargs, args, for_video=True), extra_args=args)
         if reset_masks:
             self.reset_padding_masks()
         return self._select_frame(video, frame)

@@ -268,13 +268,14 @@ class PretrainVisionTransformer(WeightSync, nn.Module):
         self._loaded = {}
         self._plist = None
 
-    def _run(self, x, strides, normalize, mask, n_vis, want_video, xraw=None, check=True, out_tokens=None, out_video=None):
+    def _run(self, x, strides, normalize, mask, n_vis, want_video, xraw=None, check=True, out_tokens=None, out_video=None, weights_synced=False):
         _lib.require_gpu()
         if not x.is_cuda:
             raise RuntimeError("PretrainVisionTransformer.forward needs a CUDA/HIP tensor (no CPU fallback); got %s" % x.device)
         lib = _lib.get_lib()
         dev = x.device
-        self.sync_weights(dev)
+        if not weights_synced or self._handle is None or self._handle_device != dev:
+            self.sync_weights(dev)
         c = self.cfg
         B = x.shape[0]
         Nt = c.num_tokens
@@ -330,14 +331,17 @@ class PretrainVisionTransformer(WeightSync, nn.Module):
 
     @torch.no_grad()
     def predict_video(self, x_btchw, mask, normalize: bool = True, n_vis: Optional[int] = None, check: bool = True,
-                      out_tokens: Optional[torch.Tensor] = None, out_video: Optional[torch.Tensor] = None):
+                      out_tokens: Optional[torch.Tensor] = None, out_video: Optional[torch.Tensor] = None, weights_synced: bool = False):
         """Fused wrapper path: raw [B,T,C,H,W] frames in [0,1] -> (tokens [B,Nm,C*P*P], video
         [B,T,C,H,W]) = `_preprocess` + forward + `pred_patches_to_video`
         (prediction.py:304-312, :419-422, :245-259) in one library call."""
         if x_btchw.dim() != 5 or x_btchw.shape[2] != self.cfg.in_chans or x_btchw.shape[1] != self.cfg.num_frames:
             raise RuntimeError("expected x of shape [B,%d,%d,H,W], got %s" % (self.cfg.num_frames, self.cfg.in_chans, tuple(x_btchw.shape)))
         x, strides = self._frame_strides(x_btchw, 2, 1)
-        return self._run(x, strides, normalize, mask, n_vis, True, xraw=x, check=check, out_tokens=out_tokens, out_video=out_video)
+        # (weights_synced: the caller has just run sync_weights() itself -- the wrapper does, BEFORE its mask read-back, so that the walk over the
+        # parameters overlaps the previous call's kernels instead of delaying this call's first launch)
+        return self._run(x, strides, normalize, mask, n_vis, True, xraw=x, check=check, out_tokens=out_tokens, out_video=out_video,
+                         weights_synced=weights_synced)
 
     # ---- execution options ----------------------------------------------------------------------------
     def set_lanes(self, lanes: int):
