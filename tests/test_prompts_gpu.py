@@ -274,6 +274,15 @@ def test_rectangulariser_on_device_masks_is_bit_exact_and_in_place():
             out = r(md)
             assert out.data_ptr() == md.data_ptr() and torch.equal(out.cpu(), ref)
             assert r.last_num_masked == int(ref[0].sum()) and (ref.sum(-1) == r.last_num_masked).all()
+            # the read-back polls an event by default (masking.py _to_host); the blocking copy gives the same masks, also behind queued work
+            torch.manual_seed(77)
+            mb = m.cuda()
+            busy = torch.randn(2048, 2048, device="cuda")
+            for _ in range(4):
+                busy = busy @ busy * 1e-3
+            rb = RectangularizeMasks(mode)
+            rb.spin_wait = False
+            assert torch.equal(rb(mb).cpu(), ref) and rb.last_num_masked == r.last_num_masked
 
 
 def test_rccl_comm_single_rank_on_device():
