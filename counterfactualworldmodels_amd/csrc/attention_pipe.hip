@@ -432,8 +432,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         CWM_TILE(true, sb, sa, kt + 1, std::true_type{});
     }
     // ONE instance of the last tile: with two (S in sa after an odd count, in sb after an even one) hipcc merged the two paths through
-    // copies of the S and O accumulators and spilled around them; an even count moves its S values over instead (32 v_mov, once)
-    // ONE instance of the last tile: with two (S in sa after an odd count, in sb after an even one) hipcc merged the two paths through
     // copies of the S and O accumulators and spilled around them (256 VGPRs + 5 dwords of scratch; now 222, none); an even count moves
     // its S values over instead (32 v_mov, once per workgroup).  Same-box A/B: profiles/r4_ab_attention_no_spill.log (equal within noise).
     if (kt + 2 == nkt) {

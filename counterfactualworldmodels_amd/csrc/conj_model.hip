@@ -581,7 +581,7 @@ extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* 
     hipStream_t s = (hipStream_t)a->stream;
 
     // two lanes as in cwm_forward (model.hip): the halves share n_vis_max / n_vis_ctx_max, so the padded layout of every row is unchanged
-    const bool two = m->lanes >= 2 && B >= 2 && (int64_t)(B / 2) * vm >= 6000;
+    const bool two = m->lanes >= 2 && B >= 2 && (int64_t)(B / 2) * vm >= kMinLaneRowsConj;
     const int B0 = two ? (B + 1) / 2 : B;
     if (two) {
         if (!m->lane_stream) {

@@ -45,7 +45,6 @@ struct LaneWs {
     float *x_enc, *x_dec;
     StreamBuffers sb;
 };
-constexpr int kMinLaneRows = 6000;  // encoder rows (batch elements x visible tokens) a lane must have: below, the GEMM grids no longer fill the chip
 
 namespace {
 

@@ -345,7 +345,7 @@ class PretrainVisionTransformer(WeightSync, nn.Module):
 
     # ---- execution options ----------------------------------------------------------------------------
     def set_lanes(self, lanes: int):
-        """1: every kernel on the current stream; 2 (library default): batches whose halves keep >= 6000 encoder rows run as two half batches on two HIP
+        """1: every kernel on the current stream; 2 (library default): batches whose halves keep >= 3000 encoder rows (ViT-B/8: batch >= 8) run as two half batches on two HIP
         streams (forked / joined inside the library), which fills the idle time between dependent kernels."""
         if self._handle is None:
             raise RuntimeError("run a forward pass (or sync_weights) before set_lanes")

@@ -92,7 +92,7 @@ typedef struct cwm_forward_args {
 int cwm_forward(cwm_model* m, const cwm_forward_args* args);
 
 /* Batch lanes (no counterpart in the reference: an execution option of this library).  lanes = 2 (default): a call with
- * batch >= 2 whose halves keep >= 6000 encoder rows (ViT-B/8: batch >= 16; ViT-L/4: batch >= 4) runs as two half batches, the first on args->stream and the second on a stream owned by the model, forked and joined
+ * batch >= 2 whose halves keep >= 3000 encoder rows (ViT-B/8: batch >= 8; ViT-L/4: batch >= 2) runs as two half batches, the first on args->stream and the second on a stream owned by the model, forked and joined
  * with events inside cwm_forward, so the caller sees ordinary stream semantics; results are those of the single-lane call up to the
  * kernel choice per GEMM shape (fp32 re-association, < 1e-5).  lanes = 1: everything on args->stream. */
 int cwm_model_set_lanes(cwm_model* m, int lanes); /* 1 .. 4; more than two lanes measured slower on MI355X */
@@ -141,7 +141,7 @@ typedef struct cwm_conj_forward_args {
 
 /* replaces: `self.predictor(self._preprocess(x), mask, x_context=..., mask_context=...)` (prediction.py:419-422) */
 int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* args);
-int cwm_conj_set_lanes(cwm_conj_model* m, int lanes); /* as cwm_model_set_lanes; the halves keep the call's n_vis_max / n_vis_ctx_max */
+int cwm_conj_set_lanes(cwm_conj_model* m, int lanes); /* as cwm_model_set_lanes (here the halves must keep >= 12000 encoder rows: batch >= 8); the halves keep the call's n_vis_max / n_vis_ctx_max */
 int cwm_conj_timing_enable(cwm_conj_model* m, int kclass, int enable);
 int cwm_conj_timing_collect(cwm_conj_model* m, int kclass, struct cwm_kernel_stats* out);
 
