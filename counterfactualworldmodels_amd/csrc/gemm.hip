@@ -656,7 +656,12 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
             const int64_t tiles = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
             const int cus = gemm_cu_count();
             if (tiles < cus) {
-                cfg = tiles * 2 >= cus ? 4 : 1;
+                // one partial round: from half the CUs up.  Inside a two-lane call the other lane fills the idle CUs, and the launches whose tile is long (K >= 1024:
+                // fc2) or whose epilogue is the direct one (bf16 outputs) win on the 8-phase kernel from 0.4 of the CUs (tools/autotune_step.py and
+                // tools/batch_sweep.py, round 4: ViT-B/8 batch 24 -- fc2 = 114 tiles -- 13.03 -> 12.53 ms per step, batch 8 -- qkv = 117 tiles -- 5.12 -> 5.09;
+                // 75 and 93 tiles (batch 16, 20) measure equal or worse, 57 and 39 lose)
+                const bool long_or_direct = bf16_out || p.K >= 1024;
+                cfg = (tiles * 2 >= cus || (p.overlapped && long_or_direct && tiles * 5 >= cus * 2)) ? 4 : 1;
             } else if (p.overlapped && !(g_gemm_debug & 128)) {
                 // two batch lanes: the other lane's kernels take the CUs a partly filled last round leaves idle, so the kernel with the
                 // fastest main loop wins regardless of the fill (B/8 batch 32 as 2 x 16: +2 % over the single-lane rule below)

@@ -41,7 +41,7 @@ def run(steps=20):
 
 
 # the GEMM shapes of one lane (engine.hip run_block / model.hip forward_lane): (name, M, N, K, epi)
-two = lanes >= 2 and (B // 2) * nv >= 6000
+two = lanes >= 2 and (B // 2) * nv >= 3000  # engine.h kMinLaneRows
 Bl = (B + 1) // 2 if two else B
 De, Dd, Nt, Nm = cfg.enc_dim, cfg.dec_dim, cfg.num_tokens, cfg.num_tokens - nv
 r64 = lambda v: (v + 63) // 64 * 64
