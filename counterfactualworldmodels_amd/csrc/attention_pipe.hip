@@ -240,21 +240,31 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
     lds_wait_v_step<NRD, PLANES>(vr0);
     pv_step<PLANES, 0>(w, sc, vr0, ph0, pl0, ph1, pl1);
     if constexpr (!HAS_NEXT) {
-        if (half) {
+        // Last tile (once per workgroup).  The branch on `half` must NOT sit between an asm LDS read and its wait: hipcc takes the asm's output registers
+        // for written when the statement issues, and at a control-flow merge it is free to move them -- a first form of this code (branch right here, with
+        // k-step 1's fragments still in flight) made it copy 16 fragment registers ~85 instructions after the reads and BEFORE the wait.  Right as long as
+        // the LDS answers faster than that; beside another kernel's LDS traffic (two batch lanes) one wave in ~10^5 multiplied stale registers (ViT-L/4
+        // batch 8: 5 % of the forwards wrong in one sample).  tools/asm_lds_lint.py checks the ISA for this (tests/test_host_logic.py).
+        lds_wait_v_step<0, PLANES>(vr1);
+        pv_step<PLANES, 1>(w, sc, vr1, ph1, pl1, ph0, pl0);
+        if (!half) {
+            lds_read_v_step<2, PLANES>(vr0, va0, va1);
+            lds_read_v_step<3, PLANES>(vr1, va0, va1);
+            lds_wait_v_step<NRD, PLANES>(vr0);
+            pv_step<PLANES, 2>(w, sc, vr0, ph0, pl0, ph1, pl1);
             lds_wait_v_step<0, PLANES>(vr1);
-            pv_step<PLANES, 1>(w, sc, vr1, ph1, pl1, ph0, pl0);
-            PROF_T(2);
-            return;
+            pv_step<PLANES, 3>(w, sc, vr1, ph1, pl1, ph0, pl0);
         }
+    } else {
+        lds_read_v_step<2, PLANES>(vr0, va0, va1);
+        lds_wait_v_step<NRD, PLANES>(vr1);
+        pv_step<PLANES, 1>(w, sc, vr1, ph1, pl1, ph0, pl0);
+        lds_read_v_step<3, PLANES>(vr1, va0, va1);
+        lds_wait_v_step<NRD, PLANES>(vr0);
+        pv_step<PLANES, 2>(w, sc, vr0, ph0, pl0, ph1, pl1);
+        lds_wait_v_step<0, PLANES>(vr1);
+        pv_step<PLANES, 3>(w, sc, vr1, ph1, pl1, ph0, pl0);
     }
-    lds_read_v_step<2, PLANES>(vr0, va0, va1);
-    lds_wait_v_step<NRD, PLANES>(vr1);
-    pv_step<PLANES, 1>(w, sc, vr1, ph1, pl1, ph0, pl0);
-    lds_read_v_step<3, PLANES>(vr1, va0, va1);
-    lds_wait_v_step<NRD, PLANES>(vr0);
-    pv_step<PLANES, 2>(w, sc, vr0, ph0, pl0, ph1, pl1);
-    lds_wait_v_step<0, PLANES>(vr1);
-    pv_step<PLANES, 3>(w, sc, vr1, ph1, pl1, ph0, pl0);
     PROF_T(2);
 }
 

@@ -547,13 +547,23 @@ int splitk_workspace_alloc(float** slabs, unsigned** counts, hipStream_t stream)
 }
 
 // Does this launch take the split-K path of the deep-ring kernel?  (the engine creates a stream's workspace only then)
+// Tile height of the deep-ring kernel for a launch with at most one 128x128 tile per CU: 64 rows when the 128-row grid would leave half of the
+// CUs idle (batch 1: 792 rows = 7 row tiles, the last one 24 rows; qkv 126 tiles on 256 CUs -> 13 x 18 = 234 tiles of half the work each).
+// "gemm_debug" bit 8 keeps 128.
+static int deep_tile_rows(const GemmParams& p) {
+    const int tiles128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+    return (tiles128 * 2 <= gemm_cu_count() && p.M > 64 && !(g_gemm_debug & 256)) ? 64 : 128;
+}
+
 int gemm_splitk_parts(const GemmParams& p, int planes) {
     if (g_gemm_debug & (4 | 32)) return 1;
     const int tiles128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
     const int cus = gemm_cu_count();
     if (tiles128 > cus) return 1;
+    const int bm = deep_tile_rows(p);
+    const int tiles = ((p.M + bm - 1) / bm) * ((p.N + 127) / 128);
     const int nk_all = p.K / (64 / planes);
-    const int sk = std::min(std::min(cus / tiles128, nk_all / 12), 8);
+    const int sk = std::min(std::min(cus / tiles, nk_all / 12), 8);
     return sk >= 3 ? sk : 1;
 }
 
@@ -774,11 +784,14 @@ static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t strea
         }
     }
     if (deep) {
-        const size_t smem = (size_t)4 * (128 + 128) * 128;
+        static const kern_t deep64[2] = {gemm_bf16_kernel<1, 64, 128, 1, 4, 4>, gemm_bf16_kernel<2, 64, 128, 1, 4, 4>};  // 4 waves of 64x32
+        const int bm = deep_tile_rows(p);
+        const size_t smem = (size_t)4 * (bm + 128) * 128;
         const bool w8 = !(g_gemm_debug & 16);  // 8 waves of 64x32 (two per SIMD cover each other's LDS / barrier latency); bit 4: 4 waves
-        kern_t k = w8 ? deep128w8[planes - 1] : deep128[planes - 1];
+        kern_t k = bm == 64 ? deep64[planes - 1] : w8 ? deep128w8[planes - 1] : deep128[planes - 1];
+        const int tiles = ((p.M + bm - 1) / bm) * ((p.N + 127) / 128);
         if (int rc = cwm_set_max_lds((const void*)k, (int)smem)) return rc;
-        hipLaunchKernelGGL(k, dim3(tiles128 * p.splitk), dim3(w8 ? 512 : 256), smem, stream, p);
+        hipLaunchKernelGGL(k, dim3(tiles * p.splitk), dim3(bm == 64 ? 256 : w8 ? 512 : 256), smem, stream, p);
         CWM_HIP_CHECK(hipGetLastError());
         return 0;
     }

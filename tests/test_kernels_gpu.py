@@ -241,7 +241,7 @@ def test_gemm_deep_ring_and_split_k_small_launches(gu):
     over the idle CUs with a last-arriver reduction in fixed part order: bit-identical to the double-buffered kernel without a split,
     deterministic under repetition with it (a stale slab or a re-staged tile read too early shows up as a mismatch), every epilogue."""
     lib = _lib.get_lib()
-    shapes = [(792, 768, 3072), (1568, 384, 1536), (792, 2304, 768), (300, 272, 2048), (130, 48, 4096), (1000, 256, 64)]
+    shapes = [(792, 768, 3072), (1568, 384, 1536), (792, 2304, 768), (300, 272, 2048), (130, 48, 4096), (1000, 256, 64), (3168, 768, 768), (40, 384, 768)]
     try:
         for mode in ("parity", "fast"):
             for (M, N, K) in shapes:
@@ -253,9 +253,11 @@ def test_gemm_deep_ring_and_split_k_small_launches(gu):
                 for rep in range(3):
                     out = (gu.linear(a, w, b, resid=r, mode=mode), gu.linear(a, w, b, gelu=True, mode=mode))
                     assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), (mode, M, N, K, rep)
-                _lib.check(lib.cwm_debug_set(b"gemm_debug", 32 + 16))    # deep ring, 4 waves
-                out = (gu.linear(a, w, b, resid=r, mode=mode), gu.linear(a, w, b, gelu=True, mode=mode))
-                assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), (mode, M, N, K, "4 waves")
+                # (these shapes leave half of the CUs without a 128x128 tile, so the deep ring above ran its 64x128 tile; bit 8 keeps 128 rows)
+                for bits, what in ((32 + 256, "128-row tiles, 8 waves"), (32 + 256 + 16, "128-row tiles, 4 waves")):
+                    _lib.check(lib.cwm_debug_set(b"gemm_debug", bits))
+                    out = (gu.linear(a, w, b, resid=r, mode=mode), gu.linear(a, w, b, gelu=True, mode=mode))
+                    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), (mode, M, N, K, what)
                 _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))          # default: + split-K where the heuristic takes it
                 first = (gu.linear(a, w, b, resid=r, mode=mode), gu.linear(a, w, b, gelu=True, mode=mode))
                 for rep in range(6):
