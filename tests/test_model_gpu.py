@@ -205,8 +205,8 @@ def test_bench_batch_properties():
     # the first two rows of the B=32 synthetic batch are exactly the golden B=2 inputs
     assert np.array_equal(mask[:2].cpu().numpy(), g["mask"])
     assert np.abs(y[:2].cpu().numpy() - g["y_tokens"]).max() <= PARITY_TOL
-    y2 = m(xp, mask, n_vis=792)
-    assert torch.equal(y, y2)  # deterministic
+    for rep in range(30):  # deterministic, run after run (a timing-dependent fault shows up as a rare difference: DESIGN.md 4.9 (5d))
+        assert torch.equal(y, m(xp, mask, n_vis=792)), rep
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
     yp = m(xp[perm], mask[perm], n_vis=792)
     assert (yp - y[perm]).abs().max().item() <= 1e-5  # batch-permutation equivariance
