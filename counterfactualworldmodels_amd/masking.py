@@ -6,6 +6,9 @@ input in place, and both behaviours are kept so seeded runs reproduce the refere
 """
 from __future__ import annotations
 
+import os
+import time
+
 import numpy as np
 import torch
 
@@ -17,7 +20,7 @@ class RectangularizeMasks:
         assert truncation_mode in ["min", "max", "mean", "full", "none", None], truncation_mode
         self._mode = truncation_mode
         self.last_num_masked = None
-        self.spin_wait = True  # poll for the device -> host copy of the masks instead of blocking on it (see _to_host)
+        self.spin_wait = os.environ.get("CWM_SPIN_WAIT", "1") != "0"  # poll for the device -> host copy of the masks instead of blocking on it (see _to_host)
         self._event = None
 
     def set_mode(self, mode):
@@ -39,7 +42,7 @@ class RectangularizeMasks:
                 self._event = torch.cuda.Event()
             self._event.record(torch.cuda.current_stream(masks.device))
             while not self._event.query():
-                pass
+                time.sleep(0)  # (gives the GIL away between two polls -- other Python threads of the process keep running -- without parking the core)
         else:
             host.copy_(masks)
         return host

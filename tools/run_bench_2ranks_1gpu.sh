@@ -5,7 +5,7 @@
 # a valid JSON line with n_gpus == N, and that without the test hooks the same command refuses to run on a box with fewer GPUs.
 N=${1:-2}
 echo "# without the hooks: must fail loudly (exit 2) on a 1-GPU box"
-python bench.py --gpus $N --steps 2 --warmup 1; echo "exit code $?"
+timeout 120 python bench.py --gpus $N --steps 2 --warmup 1; echo "exit code $?"
 export CWM_BENCH_ONE_DEVICE=1 CWM_BENCH_BACKEND=gloo CWM_COMM=torch
-python bench.py --gpus $N --steps 3 --warmup 1 --no-secondary 2>/dev/null | tail -1
-python bench.py --gpus $N --steps 2 --warmup 1 --workload prompts256 2>/dev/null | tail -1
+timeout 150 python bench.py --gpus $N --steps 3 --warmup 1 --no-secondary 2>/dev/null | tail -1
+timeout 150 python bench.py --gpus $N --steps 2 --warmup 1 --workload prompts256 2>/dev/null | tail -1
