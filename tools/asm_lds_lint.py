@@ -10,7 +10,7 @@ traffic (two batch lanes) one wave in ~10^5 read stale fragments (ViT-L/4 batch 
     python tools/asm_lds_lint.py            # compiles attention_pipe.hip, exits 1 on a hit
 
 Rule checked, per kernel: between a `ds_read_b64_tr_b16 vX` and the first `s_waitcnt lgkmcnt(N)` that covers it (LDS returns in order: a wait for
-N leaves the N youngest reads outstanding), no instruction may read vX."""
+N leaves the N youngest reads outstanding), no instruction may read vX -- or write it."""
 import os
 import re
 import subprocess
@@ -60,6 +60,10 @@ def lint_isa(text):
             for r in _regs(a):
                 if r in pending:
                     hits.append((kernel, i + 1, l, r, i - pending[r]))
+        if not stores and not op.startswith("s_"):  # ... nor may anything else be written there (the late LDS data would land on top of it)
+            for r in _regs(args[0]):
+                if r in pending:
+                    hits.append((kernel, i + 1, l + "   [overwrites]", r, i - pending[r]))
     return hits
 
 
