@@ -404,3 +404,23 @@ def test_two_lanes_match_one_lane_and_report_mask_errors_of_both():
         tail = ys[B - 1].clone()                               # last row = end of the second lane
     s.synchronize()
     assert torch.equal(tail, y2[B - 1])
+
+
+@pytest.mark.parametrize("B", [8, 9, 13])
+def test_mid_batches_run_two_lanes(B):
+    """Round 4 lowered the lane split to 3000 encoder rows per half (engine.h kMinLaneRows: ViT-B/8 from batch 8) and lets partly filled rounds inside a
+    two-lane call take the 8-phase kernel: the mid batches therefore run other kernels than both batch 32 and batch 1.  Two lanes against one lane
+    (<= 5e-5: kernel choice and split-K re-associate fp32 sums), rows 0-1 against the reference's golden pair, and bit-stable over repetitions."""
+    g = np.load(os.path.join(GOLDEN, "base8_k8_b2.npz"))
+    cfg = C.CONFIGS["base_8x8patch_2frames_1tube"]
+    m = build(cfg, 0, "parity")
+    x = O.preprocess(torch.from_numpy(S.synthetic_frames(B, cfg, 0))).cuda()
+    mask = torch.from_numpy(S.synthetic_masks(B, cfg, 8, 0)).cuda()
+    y2 = m(x, mask, n_vis=792)
+    assert np.abs(y2[:2].cpu().numpy() - g["y_tokens"]).max() <= PARITY_TOL
+    for rep in range(10):
+        assert torch.equal(m(x, mask, n_vis=792), y2), rep
+    m.set_lanes(1)
+    y1 = m(x, mask, n_vis=792)
+    m.set_lanes(2)
+    assert (y2 - y1).abs().max().item() <= 5e-5
