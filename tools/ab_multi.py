@@ -18,7 +18,7 @@ nv = cfg.tokens_per_frame + kv
 lib = _lib.get_lib()
 m.predict_video(x, mask, n_vis=nv)
 m.set_lanes(lanes)
-DEFAULTS = {"ln_tail": 1, "gemm_debug": 0, "gemm_tile": 0, "attn_ksplit": 1, "attn_tail": 1}
+DEFAULTS = {"gemm_debug": 0, "gemm_tile": 0, "attn_ksplit": 1, "attn_tail": 1}
 def run():
     for _ in range(5): m.predict_video(x, mask, n_vis=nv, check=False)
     torch.cuda.synchronize(); t0 = time.perf_counter()
