@@ -67,6 +67,7 @@ struct StreamBuffers {
 // cwm_conj_forward).  Measured (tools/lane_threshold.py, round 4): ViT-B/8 batch 8 / 10 / 14 (3168 / 3960 / 5544 rows per half) -6 / -7.5 / -10 % with
 // two lanes, batch 6 (2376) +3 %; ViT-L/4 batch 2 (3168) -7 %.  (Rounds 1-3 used 6000: batch >= 16.)
 constexpr int kMinLaneRows = 3000;
+extern int g_min_lane_rows;  // = kMinLaneRows; cwm_debug_set "min_lane_rows" moves it (tools/lane_threshold.py)
 // The IMU-conditioned model (its lanes carry a context stream each: four queues): batch 2 / 3 / 4 / 6 are 5.3 / 4.3 / 2.5 / 2.8 % SLOWER on two lanes,
 // batch 8 / 12 / 16 2.3 / 1.4 / 1.0 % faster (3172 visible rows per sample; rounds 1-3 split from batch 4)
 constexpr int kMinLaneRowsConj = 12000;

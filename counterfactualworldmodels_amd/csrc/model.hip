@@ -163,6 +163,7 @@ extern "C" int cwm_model_load_weight(cwm_model* m, const char* key, const float*
 extern "C" int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen) { return m->eng.missing_weights(buf, buflen); }
 
 static int g_prune_last_block = 1;
+int cwm::g_min_lane_rows = cwm::kMinLaneRows;
 // (Rounds 2-3 carried a form with every LayerNorm folded into the GEMMs around it -- parity-tested, measured slower: the 4 bytes / element
 // a producer GEMM then adds to its store-bound epilogue cost more than the LayerNorm launch they replace, DESIGN.md section 4.6 -- never the
 // default and removed in round 4.)
@@ -281,7 +282,7 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     // Batch lanes: between two dependent kernels the queue idles ~6 us (x 136 kernels = 5 % of a batch-32 step) and every kernel ends in a
     // partially filled round of workgroups; further, independent slices of the batch on other queues fill both.
     int n_lanes = 1;
-    while (n_lanes < m->lanes && n_lanes < B && (int64_t)(B / (n_lanes + 1)) * Nv >= kMinLaneRows) ++n_lanes;
+    while (n_lanes < m->lanes && n_lanes < B && (int64_t)(B / (n_lanes + 1)) * Nv >= g_min_lane_rows) ++n_lanes;
     const bool two = n_lanes >= 2;
     int first[cwm_model::kMaxLanes + 1];
     for (int l = 0; l <= n_lanes; ++l) first[l] = (int)(((int64_t)B * l + n_lanes - 1) / n_lanes);  // lane l owns batch elements [first[l], first[l+1])
@@ -588,6 +589,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
     if (!strcmp(key, "attn_prof")) return attention_pipe_prof(value);  // query (profiling builds)
     if (!strcmp(key, "prune_last_block")) {
         g_prune_last_block = value;
+        return CWM_OK;
+    }
+    if (!strcmp(key, "min_lane_rows")) {  // encoder rows per half batch from which cwm_forward runs two lanes (default: engine.h kMinLaneRows)
+        g_min_lane_rows = value;
         return CWM_OK;
     }
     if (!strcmp(key, "attn_ksplit")) {

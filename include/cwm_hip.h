@@ -280,7 +280,7 @@ int cwm_bench_gemm_gapped(int M, int N, int K, int mode, int epi, int iters, int
  * "gemm_debug" (bit mask of ablations / A-B switches: 1 skip the epilogue's global stores, 2 skip the epilogue, 4 no 4-stage ring for small launches, 8 skip every
  * LayerNorm launch (timing only), 16 small launches on 4 instead of 8 waves, 32 no split-K, 64 the 128x128 kernel as 4-wave workgroups, 128 the one-lane tile
  * choice also inside a two-lane call, 256 small launches keep 128-row tiles where the default takes 64x128 ones, 512 bf16-output GEMMs with K < 512 stay on 128x128 tiles), "attn_kernel" (0 automatic, 1: 4-wave, 3: software-pipelined 4-wave),
- * "attn_remap" (0: plain workgroup order instead of one XCD per (batch, head) with the ragged query tiles last), "attn_tail" (0: the regular schedule
+ * "min_lane_rows" (encoder rows per half batch from which cwm_forward splits into two lanes; default 3000), "attn_remap" (0: plain workgroup order instead of one XCD per (batch, head) with the ragged query tiles last), "attn_tail" (0: the regular schedule
  * also for a ragged last query tile of <= 32 rows instead of splitting its keys over the four waves), "attn_ksplit" (0: a nearly empty last round of
  * workgroups runs its items whole instead of cutting them into key ranges),
  * "prune_last_block" (0: run the last decoder block over all tokens),

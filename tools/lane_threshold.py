@@ -24,4 +24,4 @@ for B in [int(b) for b in os.environ.get("BATCHES", "4,6,8,10,12,14,16").split("
             torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 20)
         res.append(best)
     print("B=%2d (%5d encoder rows per half)  one lane %.3f ms   two lanes %.3f ms   ratio %.3f" % (B, (B // 2) * nv, 1e3 * res[0], 1e3 * res[1], res[1] / res[0]), flush=True)
-_lib.check(lib.cwm_debug_set(b"min_lane_rows", 6000))
+_lib.check(lib.cwm_debug_set(b"min_lane_rows", 3000))  # engine.h kMinLaneRows
