@@ -406,10 +406,12 @@ def main():
     model.predict_video(x, mask, normalize=True, n_vis=n_vis, check=True)  # validates the synthetic masks once (device-side row check)
     for _ in range(max(args.warmup, 1)):
         G.predict(x, mask, frame=None)
+    checksum_before = float(G.predict(x, mask, frame=None).double().sum())  # (untimed) the same step again after the timed region must give the same bits
     torch.cuda.synchronize()
 
     # ---- timed region: `value` -------------------------------------------------------------------------------------------------
     dt = timed_steps(G, x, mask, n_vis, args.steps, distributed)
+    checksum_after = float(G.predict(x, mask, frame=None).double().sum())
 
     # ---- kernel region: the same K steps on ONE lane with a HIP event pair around every GEMM launch -> `roofline`.  With two lanes a
     # launch shares the chip with whatever the other lane runs, so its duration says nothing about the kernel; here launches are alone.
@@ -453,6 +455,8 @@ def main():
         },
         "model_tflops": flops_pair * value / 1e12,
         "model_frac_of_bf16_peak": flops_pair * value / 1e12 / (PEAK_BF16_TFLOPS * n_gpus),
+        # one more (untimed) step before and after the timed region: same input, same bits expected (a timing-dependent fault would show here)
+        "output_stable": bool(checksum_before == checksum_after and checksum_after == checksum_after),
     }
     planes = 2 if args.mode == "parity" else 1
     kernels = {  # (names as rocprofv3 prints them)
