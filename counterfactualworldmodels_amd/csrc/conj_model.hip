@@ -73,6 +73,7 @@ struct ConjLane {
     int* err;
     float *qk, *v, *qk_src, *v_src, *scores_t, *cross_partial;
     bf16 *ybuf, *ysbuf;
+    bool have_prev = false;  // a cross block of this forward has used the projection buffers (run_cross); carried from stage to stage
 };
 
 void shift_stream(StreamW& S, int b0, int vcap, int mlp_ratio, bool small) {
@@ -451,7 +452,12 @@ int g_conj_ctx_stream = 1;  // "conj_ctx_stream" switch: 0 keeps the context str
 // the RGB stream in the 8 cross blocks.  It runs on a stream of its own (sc), so that the chain hides under the RGB stream's kernels
 // instead of extending the lane by ~4 %; inside a cross block the two streams exchange their projections once (run_cross).
 // (Not while kernel timers are on: those want every launch alone on the chip.)
-static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0, int B, hipStream_t s, int lane) {
+// Stages [stage_lo, stage_hi) of the lane's launch sequence: 0 = masks + tokenisation + embedding of both streams; 1 .. Le = encoder step i (the cross block in front of
+// block i, then block i of both streams); Le + 1 = the two to_decoder steps; Le + 2 .. Le + 1 + Ld = decoder step i; Le + Ld + 2 = outputs.  cwm_conj_forward issues stage by
+// stage over the lanes, as cwm_forward does: a forward is ~1000 launches per lane, and a host that issues lane 0 to its end first starts lane 1 that much later -- 1.5 ms of
+// 61 normally, but 22 ms under rocprofv3 (whose launches cost ~20 us each: the lanes of the round-4 trace overlapped for half of their time only).  Measured without the
+// profiler: no difference (61.2 ms per step either way; this model's step is the sum of its kernels -- 62.6 ms of kernel time in the one-lane trace).
+static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0, int B, hipStream_t s, int lane, int stage_lo, int stage_hi) {
     cwm_conj_model* m = L.m;
     const cwm_conj_config& c = m->cfg;
     const cwm_config& mc = c.main;
@@ -476,7 +482,9 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
         CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_main[lane], hipEventDisableTiming));
         for (int k = 0; k < 4; ++k) CWM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_cross[lane][k], hipEventDisableTiming));
     }
-    bool have_prev = false;  // a cross block of this forward has used the projection buffers (run_cross)
+    bool& have_prev = L.have_prev;
+    auto in_range = [&](int st) { return st >= stage_lo && st < stage_hi; };
+    const int st_todec = mc.enc_depth + 1, st_out = mc.enc_depth + mc.dec_depth + 2;
     hipStream_t sc = side ? m->ctx_stream[lane] : s;
     // main -> ctx: the context stream may continue once everything queued on s so far is done; ctx -> main likewise
     auto ctx_follows_main = [&]() -> int {
@@ -492,6 +500,8 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
         return 0;
     };
 
+    if (in_range(0)) {
+    have_prev = false;
     // a13: padded masks -> permutations [visible slots ascending | masked slots ascending] over n_tok + max_pad slots
     CWM_HIP_CHECK(hipMemsetAsync(L.err, 0, sizeof(int), s));
     if ((rc = launch_pad_mask(mask_in, B, A.n_tok, A.max_pad, vm, A.ext_mask, s))) return rc;
@@ -514,9 +524,11 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
     if ((rc = launch_imu_gather(ig, planes, s))) return rc;
     if ((rc = embed_stream(m, S, B, vc, planes, s))) return rc;
     if ((rc = ctx_follows_main())) return rc;
+    }
 
     // encoder: cross block BEFORE the self-attention blocks listed in enc_cross (forward_encoder_blocks :543-576)
     for (int i = 0; i < mc.enc_depth; ++i) {
+        if (!in_range(1 + i)) continue;
         for (int k = 0; k < c.n_enc_cross; ++k)
             if (c.enc_cross[k] == i &&
                 (rc = run_cross(L, m->enc_cross[k], A.x_enc, vm, A.enc_dim, S.x_enc, vc, S.enc_dim, B, planes, s, sc, m->ev_cross[lane], have_prev)))
@@ -524,10 +536,11 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
         if ((rc = E.run_block(A.enc[i], A.x_enc, B, vm, A.enc_dim, A.enc_heads, planes, A.sb, s))) return rc;
         if ((rc = E.run_block_small(S.enc[i], S.x_enc, B, vc, S.enc_dim, S.enc_heads, planes, S.sb, sc))) return rc;
     }
-    if ((rc = to_decoder(m, A, B, vm, planes, s)) || (rc = to_decoder(m, S, B, vc, planes, sc))) return rc;
+    if (in_range(st_todec) && ((rc = to_decoder(m, A, B, vm, planes, s)) || (rc = to_decoder(m, S, B, vc, planes, sc)))) return rc;
 
     // decoder: cross block AFTER the blocks listed in dec_cross (forward_decoder_blocks :688-720)
     for (int i = 0; i < mc.dec_depth; ++i) {
+        if (!in_range(st_todec + 1 + i)) continue;
         if ((rc = E.run_block(A.dec[i], A.x_dec, B, Nx, A.dec_dim, A.dec_heads, planes, A.sb, s))) return rc;
         if ((rc = E.run_block_small(S.dec[i], S.x_dec, B, Mx, S.dec_dim, S.dec_heads, planes, S.sb, sc))) return rc;
         for (int k = 0; k < c.n_dec_cross; ++k)
@@ -535,6 +548,7 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
                 (rc = run_cross(L, m->dec_cross[k], A.x_dec, Nx, A.dec_dim, S.x_dec, Mx, S.dec_dim, B, planes, s, sc, m->ev_cross[lane], have_prev)))
                 return rc;
     }
+    if (!in_range(st_out)) return CWM_OK;
     // context output (forward(..., output_context=True), conjoined_decode :990-1002): head_ctx(norm_ctx(x_c[:, -n_out_c:])) * ~null_mask_ctx
     if (a->y_ctx_tokens_dev) {
         const int n_out_c = Mx - vc;
@@ -592,16 +606,19 @@ extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* 
         CWM_HIP_CHECK(hipEventRecord(m->ev_fork, s));
         CWM_HIP_CHECK(hipStreamWaitEvent(m->lane_stream, m->ev_fork, 0));
     }
-    ConjLane L0 = conj_lane(m, 0, 0);
+    ConjLane lanes[2] = {conj_lane(m, 0, 0), conj_lane(m, 1, two ? B0 : 0)};
     m->eng.overlapped = two;
-    int rc = conj_forward_lane(L0, a, 0, B0, s, 0);
-    if (two) {
-        ConjLane L1 = conj_lane(m, 1, B0);
-        const int rc1 = rc ? rc : conj_forward_lane(L1, a, B0, B - B0, m->lane_stream, 1);
-        m->eng.overlapped = 0;
+    int rc = 0;
+    // launch order: stage by stage over the lanes (conj_forward_lane), so that both queues fill at the same pace
+    const int n_stages = m->cfg.main.enc_depth + m->cfg.main.dec_depth + 3;
+    for (int st = 0; st < n_stages && !rc; ++st) {
+        rc = conj_forward_lane(lanes[0], a, 0, B0, s, 0, st, st + 1);
+        if (two && !rc) rc = conj_forward_lane(lanes[1], a, B0, B - B0, m->lane_stream, 1, st, st + 1);
+    }
+    m->eng.overlapped = 0;
+    if (two) {  // join even after a failed launch: the caller's stream must not run ahead of work already queued on the lane
         CWM_HIP_CHECK(hipEventRecord(m->ev_join, m->lane_stream));
         CWM_HIP_CHECK(hipStreamWaitEvent(s, m->ev_join, 0));
-        rc = rc1;
     }
     if (rc) return rc;
 
