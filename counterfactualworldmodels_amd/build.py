@@ -22,6 +22,39 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or add /opt/rocm/bin to PATH)")
 
 
+def hipcc_version() -> str:
+    """`HIP version ...; AMD clang version ...` of the compiler a build would use (compiled into the library: cwm_compiler_version())."""
+    out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout
+    keep = [l.strip() for l in out.splitlines() if l.startswith("HIP version") or "clang version" in l]
+    return "; ".join(keep) or "unknown"
+
+
+LINT_RECORD = os.path.join(CSRC, "LINT_PASSED.json")
+
+
+def lint_record() -> dict:
+    """What tools/asm_lds_lint.py --record last wrote: the compiler version the ISA lint of the hand-counted waits passed on (and the hashes of the
+    sources it read).  The kernels' counted `s_waitcnt`s are only as good as the ISA the compiler emits around them."""
+    import json
+
+    try:
+        with open(LINT_RECORD) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
+
+
+def check_lint_record(verbose: bool = True) -> bool:
+    """True when this compiler is the one the ISA lint last passed on; warns otherwise (a toolchain bump can move instructions across the hand-counted
+    waits without any test noticing: re-run `python tools/asm_lds_lint.py --record`)."""
+    rec = lint_record()
+    ok = rec.get("hipcc") == hipcc_version()
+    if not ok and verbose:
+        print("WARNING: hipcc is `%s` but the ISA lint of the hand-counted waits last passed on `%s`: run `python tools/asm_lds_lint.py --record` before trusting "
+              "this build" % (hipcc_version(), rec.get("hipcc", "<never recorded>")), file=sys.stderr)
+    return ok
+
+
 def source_hash() -> str:
     """sha1 over every source and header of the library (what `cwm_source_hash()` of a current build returns)."""
     import hashlib
@@ -104,7 +137,7 @@ def _build_locked(out_path, extra, obj_dir, force, verbose):
         objs.append(obj)
         if s == "engine.hip":  # carries the hash of ALL sources (cwm_source_hash): recompiled whenever anything changed
             if force or stale_hash or not os.path.exists(obj):
-                jobs.append((base + ['-DCWM_SRC_HASH="%s"' % shash, "-c", src, "-o", obj], obj))
+                jobs.append((base + ['-DCWM_SRC_HASH="%s"' % shash, '-DCWM_HIPCC_VERSION="%s"' % hipcc_version().replace('"', "'"), "-c", src, "-o", obj], obj))
             continue
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(src)):
             jobs.append((base + ["-c", src, "-o", obj], obj))
@@ -126,6 +159,7 @@ def _build_locked(out_path, extra, obj_dir, force, verbose):
     os.replace(tmp, out_path)
     with open(stamp, "w") as fh:
         fh.write(shash)
+    check_lint_record()
     return out_path
 
 

@@ -17,6 +17,12 @@
 // K / V tiles go global -> LDS by LDS-DMA, two slots each: iteration t first issues K(t+2) (slot of K(t), whose S was
 // computed in iteration t - 1) and V(t+1) (slot of V(t-1)), and ends with vmcnt(0) + one workgroup barrier, a whole
 // tile of work later.
+//
+// Round 5: a work item may be a CHAIN of consecutive full query tiles of one (batch, head) (AttnParams.chain_len).  The key-tile sequence of
+// the chain is one virtual sequence: the last key tile of query tile c computes S(0) of query tile c + 1 in its phase A (with the next
+// tile's Q fragments, loaded under the second-to-last tile's P V), the LDS ring wraps around to key tiles 0 / 1, and the output rows of
+// tile c are stored under the first key tile of c + 1 -- no dispatch gap, no cold prologue, no un-overlapped first S between the query
+// tiles of a chain.  Per query row the arithmetic and its order are those of a single-tile item: outputs are bit-identical.
 #include "attention_tail.h"
 #include <algorithm>
 #include <cstdio>
@@ -116,20 +122,33 @@ __device__ __forceinline__ void pv_step(PipeWave<PLANES>& w, const f32x16 (&sc)[
 }
 
 // One key tile of one wave: phase A (S of the next tile into sn, softmax of this tile in sc), phase B (P V of this tile).
-//   kbase: LDS image of K(t+1); va0 / va1: LDS addresses of this lane's V(t) transposed-read blocks (d halves)
+//   kbase: LDS image of the K tile of the NEXT S; va0 / va1: LDS addresses of this lane's V(t) transposed-read blocks (d halves)
 //   dma(i): issues LDS-DMA piece i (< NDMA) of the tiles staged in this iteration -- one per slot at the head of phase
 //   A: issued back to back they hold the wave for ~60 cycles each (measured: ~500 cycles per tile)
-//   half: the sequence's LAST key tile holds at most 32 keys (every model shape: N = 792, 1568, 3168 are 32 mod 64 or less), i.e. its
-//   second key block is all padding.  HAS_NEXT: that tile is the NEXT one -- its S MFMAs of key block 1 are skipped (the values are set to
-//   -inf by the last tile anyway); !HAS_NEXT: it is THIS one -- k-steps 2 / 3 of P V (P exactly 0) are skipped.  Bit-identical: an
-//   accumulator that only ever adds products to +0 is never -0, so adding the +-0 products changes no bit.
-template <int PLANES, bool HAS_NEXT, int NDMA, typename Dma>
-__device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], f32x16 (&sn)[2], const char* kbase, unsigned va0, unsigned va1, int kt, int N, bool half,
-                                          Dma&& dma
+//   KIND (compile time; the control flow inside a tile must not depend on anything else -- see the note on branches below):
+//     TILE_STEADY     next S = the next key tile of the same query tile
+//     TILE_PENULT     the same, and the next key tile is the LAST of this workgroup's key range: if that is the sequence's last tile and it holds
+//                     at most 32 keys (`half_next`; every model shape: N = 792, 1568, 3168 are 32 mod 64 or less) the S MFMAs of its second,
+//                     all-padding key block are skipped (TILE_LAST sets those values to -inf anyway)
+//     TILE_LAST_NEXT  last key tile of a query tile that is followed by another one (chain): sequence-end mask; the next S is S(0) of the next
+//                     query tile; k-steps 2 / 3 of P V (P exactly 0) skipped when `half_this`; TILE_PENULT's mid() has re-loaded the Q fragments
+//     TILE_LAST_END   last key tile of the work item: no next S
+//   Skipping is bit-identical: an accumulator that only ever adds products to +0 is never -0, so adding the +-0 products changes no bit.
+//   BRANCHES: hipcc takes the output registers of the inline-asm V^T reads for written when the statement issues, so a control-flow merge
+//   between such a read and its hand-counted wait may copy stale registers (round 4 shipped that race for a few hours).  The reads are issued
+//   in the last two slots of phase A and inside phase B; every runtime branch of a tile therefore sits BEFORE slot NS - 2 (the DMA pieces, the
+//   rescale, the half_next skip -- which leaves slot NS - 1's MFMA unconditional for that reason) or after a wait that leaves no read in
+//   flight (`half_this`).  tools/asm_lds_lint.py fails on any branch or label with such reads pending (tests/test_host_logic.py).
+enum : int { TILE_STEADY = 0, TILE_PENULT = 1, TILE_LAST_NEXT = 2, TILE_LAST_END = 3 };
+template <int PLANES, int KIND, int NDMA, typename Dma, typename Mid>
+__device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], f32x16 (&sn)[2], const char* kbase, unsigned va0, unsigned va1, int kt, int N, bool half_next,
+                                          bool half_this, Dma&& dma, Mid&& mid
 #ifdef CWM_ATTN_PROF
     , bool prof, unsigned long long (&pacc)[8], unsigned long long& tlast
 #endif
     ) {
+    constexpr bool HAS_NEXT = KIND != TILE_LAST_END;
+    constexpr bool LASTK = KIND == TILE_LAST_NEXT || KIND == TILE_LAST_END;
     constexpr int TILE_BYTES = 64 * 64 * 2;
     constexpr int NM = PLANES == 2 ? 3 : 1;
     constexpr int NS = 8 * NM;       // slots of phase A
@@ -137,13 +156,15 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
     constexpr int NE = NS - NMAX - 1;  // one the maximum's cross-lane step, the rest the exponentials
     constexpr int NRD = 4 * PLANES;  // transposed reads per k-step
 
-    if constexpr (!HAS_NEXT) {
+    if constexpr (LASTK) {
         if (N & 63) {  // keys past the sequence end (last tile only)
+            int hh4 = 4 * w.hh;
+            asm volatile("" : "+v"(hh4));
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * w.hh;
+                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + hh4;
                     if (key >= N) sc[kb][r] = -INFINITY;
                 }
         }
@@ -180,7 +201,8 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
         for (int m = 0; m < NM; ++m) {
             const int slot = g * NM + m;
             if (slot < NDMA) dma(slot);
-            if (HAS_NEXT && !(kb == 1 && half)) {
+            // (half_next is a literal false everywhere but in TILE_PENULT; slot NS - 1 issues behind the first V^T reads: no branch there)
+            if (HAS_NEXT && !(kb == 1 && half_next && slot < NS - 1)) {
                 if constexpr (PLANES == 2) {
                     if (m == 0) sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g][PLANES - 1], w.qf[0][sx], sn[kb], 0, 0, 0);
                     if (m == 1) sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g][0], w.qf[PLANES - 1][sx], sn[kb], 0, 0, 0);
@@ -204,7 +226,7 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
                 // the MFMA shadow)
                 // (the last tile has no MFMA slots to protect and the branch made hipcc keep a second copy of the 32 accumulator registers
                 // alive across it -- 5 dwords of scratch: there the multiplication is unconditional, alpha = 1.0f exactly when nothing grew)
-                if (!HAS_NEXT || grew) {
+                if (KIND == TILE_LAST_END || grew) {
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -232,6 +254,7 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
     }
 
     PROF_T(1);
+    if constexpr (KIND == TILE_PENULT) mid();  // (unconditional: vr0 / vr1 are in flight)
     // ---- phase B --------------------------------------------------------------------------------------
 #pragma unroll
     for (int v = 32 * (NE - 1) / NE; v < 32; ++v) rowsum += sc[v >> 4][v & 15];
@@ -239,15 +262,15 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
     __builtin_amdgcn_sched_barrier(0);
     lds_wait_v_step<NRD, PLANES>(vr0);
     pv_step<PLANES, 0>(w, sc, vr0, ph0, pl0, ph1, pl1);
-    if constexpr (!HAS_NEXT) {
-        // Last tile (once per workgroup).  The branch on `half` must NOT sit between an asm LDS read and its wait: hipcc takes the asm's output registers
+    if constexpr (LASTK) {
+        // Last tile (once per query tile).  The branch on `half_this` must NOT sit between an asm LDS read and its wait: hipcc takes the asm's output registers
         // for written when the statement issues, and at a control-flow merge it is free to move them -- a first form of this code (branch right here, with
         // k-step 1's fragments still in flight) made it copy 16 fragment registers ~85 instructions after the reads and BEFORE the wait.  Right as long as
         // the LDS answers faster than that; beside another kernel's LDS traffic (two batch lanes) one wave in ~10^5 multiplied stale registers (ViT-L/4
         // batch 8: 5 % of the forwards wrong in one sample).  tools/asm_lds_lint.py checks the ISA for this (tests/test_host_logic.py).
         lds_wait_v_step<0, PLANES>(vr1);
         pv_step<PLANES, 1>(w, sc, vr1, ph1, pl1, ph0, pl0);
-        if (!half) {
+        if (!half_this) {
             lds_read_v_step<2, PLANES>(vr0, va0, va1);
             lds_read_v_step<3, PLANES>(vr1, va0, va1);
             lds_wait_v_step<NRD, PLANES>(vr0);
@@ -284,7 +307,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qcol = lane & 31, hh = lane >> 5;
-    const int N = p.n_tok;
+    int N = p.n_tok;
     const int NQ = p.n_q > 0 ? p.n_q : N;
     const int nkt_all = (N + 63) / 64;
     // work item of this workgroup (1-D grid in dispatch order).  Key-split tail round: the items of a last round that would fill at most half of
@@ -298,8 +321,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         kt0 = nkt_all * part / p.ks_parts;
         nkt = nkt_all * (part + 1) / p.ks_parts;  // this workgroup's key tiles: [kt0, nkt)
     }
-    int qt, bh;
-    attn_tile_of_item(item, p.ks_nqb, p.batch * p.heads, NQ, 32 * NW, p.remap != 0, qt, bh);
+    int qt, bh, nchain = 1;
+    if (p.chain_len >= 2) attn_chain_item(item, p.ks_nqb, p.batch * p.heads, NQ, 32 * NW, p.chain_len, p.chain_heads, qt, bh, nchain);
+    else attn_tile_of_item(item, p.ks_nqb, p.batch * p.heads, NQ, 32 * NW, p.remap != 0, qt, bh);
     if constexpr (NW == 4) {
         if (attention_is_split_tail(p, qt, p.ks_nqb, NQ)) {  // ragged last tile of <= 32 rows: the four waves split the keys (attention_tail.h)
             attention_tail_block<PLANES>(p, smem, bh, qt * 128, NQ);
@@ -307,8 +331,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         }
     }
     const int b = bh / p.heads, h = bh - b * p.heads;
-    const int q0 = qt * (32 * NW) + wave * 32;
-    const bool active = q0 < NQ;  // idle waves (query rows past the end) only stage tiles and keep the barrier count
+    int q0 = qt * (32 * NW) + wave * 32;  // first query row of this wave in the current query tile
+    bool active = q0 < NQ;  // idle waves (query rows past the end; never inside a chain) only stage tiles and keep the barrier count
 
     const bf16* Qb = p.q + (size_t)bh * N * 64;
     const bf16* Kb = p.k + (size_t)bh * N * 64;
@@ -316,14 +340,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
 
     PipeWave<PLANES> w;
     w.hh = hh;
-    {
-        const int qrow = p.q_off + min(q0 + qcol, NQ - 1);
+    auto load_q = [&](int q0w) {
+        int qcol = lane & 31, hh = lane >> 5;
+        asm volatile("" : "+v"(qcol), "+v"(hh));
+        const int qrow = p.q_off + min(q0w + qcol, NQ - 1);
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 w.qf[pl][s] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)pl * p.qk_plane + (size_t)qrow * 64 + s * 16 + hh * 8);
-    }
+    };
+    load_q(q0);
 
     // ---- LDS-DMA bookkeeping: piece = 8 key rows x 128 B; lane l lands at chunk l % 8 of row l / 8 ----
     int st_lds[NP], st_koff[NP], st_voff[NP];  // LDS offset of the piece; byte offset of the lane's 16-byte chunk inside a K / V tile
@@ -344,21 +371,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         if constexpr (decltype(clamp_c)::value) return (unsigned)(min(kt * 64 + (toff >> 7), N - 1) * 128 + (toff & 127));
         else return (unsigned)(kt * 8192 + toff);
     };
-    auto stage_k1 = [&](int kt, int jj, auto clamp_c) {
-        __builtin_amdgcn_global_load_lds((gbl_void*)(st_kp[jj] + tile_off(kt, st_koff[jj], clamp_c)), (lds_void*)(smem + (kt & 1) * SLOT_BYTES + st_lds[jj]), 16, 0,
+    // key tile kt -> ring slot `slot` (0 / 1)
+    auto stage_k1 = [&](int kt, int slot, int jj, auto clamp_c) {
+        __builtin_amdgcn_global_load_lds((gbl_void*)(st_kp[jj] + tile_off(kt, st_koff[jj], clamp_c)), (lds_void*)(smem + slot * SLOT_BYTES + st_lds[jj]), 16, 0, 0);
+    };
+    auto stage_v1 = [&](int kt, int slot, int jj, auto clamp_c) {
+        __builtin_amdgcn_global_load_lds((gbl_void*)(st_vp[jj] + tile_off(kt, st_voff[jj], clamp_c)), (lds_void*)(smem + V_BASE + slot * SLOT_BYTES + st_lds[jj]), 16, 0,
                                          0);
     };
-    auto stage_v1 = [&](int kt, int jj, auto clamp_c) {
-        __builtin_amdgcn_global_load_lds((gbl_void*)(st_vp[jj] + tile_off(kt, st_voff[jj], clamp_c)), (lds_void*)(smem + V_BASE + (kt & 1) * SLOT_BYTES + st_lds[jj]),
-                                         16, 0, 0);
-    };
-    auto stage_k = [&](int kt) {
+    auto stage_k = [&](int kt, int slot) {
 #pragma unroll
-        for (int jj = 0; jj < NP; ++jj) stage_k1(kt, jj, std::true_type{});
+        for (int jj = 0; jj < NP; ++jj) stage_k1(kt, slot, jj, std::true_type{});
     };
-    auto stage_v = [&](int kt) {
+    auto stage_v = [&](int kt, int slot) {
 #pragma unroll
-        for (int jj = 0; jj < NP; ++jj) stage_v1(kt, jj, std::true_type{});
+        for (int jj = 0; jj < NP; ++jj) stage_v1(kt, slot, jj, std::true_type{});
     };
 
 #pragma unroll
@@ -373,12 +400,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
             v_addr[db] = (unsigned)(size_t)(lds_void*)(smem + V_BASE + lds_off_v(4 * (g >> 1) + q, db * 4 + (g & 1) * 2 + (pc >> 1)) + (pc & 1) * 8);
     }
 
+    auto reset_acc = [&]() {
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) w.oacc[db][r] = 0.f;
-    w.m_run = -1e30f;
-    w.l_run = 0.f;
+            for (int r = 0; r < 16; ++r) w.oacc[db][r] = 0.f;
+        w.m_run = -1e30f;
+        w.l_run = 0.f;
+    };
+    reset_acc();
 
 #define CWM_TILE_END()                                     \
     do {                                                   \
@@ -387,27 +417,36 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         __builtin_amdgcn_s_barrier();                      \
         __builtin_amdgcn_sched_barrier(0);                 \
     } while (0)
-// tile KT of the wave: S accumulators SC (this tile) -> SN (next tile)
-#define CWM_TILE(HAS_NEXT, SC, SN, KT, CLAMP)                                                                                              \
+// key tile KT of the current query tile: S accumulators SC (this tile) -> SN (next tile).  Ring slots: tile kt of the current query tile sits in
+// slot (kt + pb) & 1 (pb: parity carried over the query tiles of a chain -- the virtual key-tile sequence runs on); this iteration re-fills the
+// K slot of THIS tile (its S is done) with the tile two ahead and the other V slot with the tile one ahead -- past the end of a chained
+// query tile those are key tiles 0 / 1 of the same head again.
+#define CWM_TILE(KIND, SC, SN, KT, CLAMP)                                                                                              \
     do {                                                                                                                               \
-        const bool more_k = (KT) + 2 < nkt;                                                                                            \
+        const int kt_ = (KT);                                                                                                          \
+        const int ks_ = (kt_ + pb) & 1;                                                                                                \
+        const bool do_k = (KIND) == TILE_STEADY || (((KIND) == TILE_PENULT || (KIND) == TILE_LAST_NEXT) && cont);                      \
+        const bool do_v = (KIND) != TILE_LAST_END;                                                                                     \
+        int k2_ = (KIND) == TILE_PENULT ? 0 : (KIND) == TILE_LAST_NEXT ? 1 : kt_ + 2;                                                  \
+        int v1_ = (KIND) == TILE_LAST_NEXT ? 0 : kt_ + 1;                                                                              \
+        if ((KIND) != TILE_STEADY) asm volatile("" : "+s"(k2_), "+s"(v1_)); /* (no hoisting of the wrapped tiles' offsets out of the chain loop) */ \
         auto dma = [&](int i) {                                                                                                        \
             if (i < NP) {                                                                                                              \
-                if (more_k) stage_k1((KT) + 2, i, CLAMP);                                                                                   \
-            } else if (HAS_NEXT) {                                                                                                     \
-                stage_v1((KT) + 1, i - NP, CLAMP);                                                                                        \
+                if (do_k) stage_k1(k2_, ks_, i, CLAMP);                                                                                \
+            } else if (do_v) {                                                                                                         \
+                stage_v1(v1_, ks_ ^ 1, i - NP, CLAMP);                                                                                 \
             }                                                                                                                          \
         };                                                                                                                             \
+        auto mid = [&]() { load_q(cont ? q0 + 32 * NW : q0); };                                                                        \
         PROF_T(0);                                                                                                                     \
         if (active) {                                                                                                                  \
-            pipe_tile<PLANES, HAS_NEXT, 2 * NP>(w, SC, SN, smem + (((KT) + 1) & 1) * SLOT_BYTES, v_addr[0] + ((KT)&1) * SLOT_BYTES,             \
-                                        v_addr[1] + ((KT)&1) * SLOT_BYTES, (KT), N,                                                    \
-                                        decltype(CLAMP)::value && half_last && (KT) + (HAS_NEXT ? 2 : 1) == nkt, dma PROF_ARGS);        \
+            pipe_tile<PLANES, KIND, 2 * NP>(w, SC, SN, smem + (ks_ ^ 1) * SLOT_BYTES, v_addr[0] + ks_ * SLOT_BYTES, v_addr[1] + ks_ * SLOT_BYTES, kt_, N,  \
+                                            (KIND) == TILE_PENULT && half_last, half_last, dma, mid PROF_ARGS);                        \
         } else {                                                                                                                       \
-            if (more_k) stage_k((KT) + 2);                                                                                             \
-            if (HAS_NEXT) stage_v((KT) + 1);                                                                                           \
+            if (do_k) stage_k(k2_, ks_);                                                                                               \
+            if (do_v) stage_v(v1_, ks_ ^ 1);                                                                                           \
         }                                                                                                                              \
-        if (HAS_NEXT) CWM_TILE_END();                                                                                                  \
+        if ((KIND) != TILE_LAST_END) CWM_TILE_END();                                                                                   \
         PROF_T(3);                                                                                                                     \
     } while (0)
 
@@ -420,37 +459,110 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
 #else
 #define PROF_ARGS
 #endif
-    // the sequence's last key tile is in this workgroup's range and at most half full (pipe_tile: `half`)
+    // the sequence's last key tile is in this workgroup's range and at most half full (pipe_tile: half_next / half_this)
     const bool half_last = nkt == nkt_all && ((N - 1) & 63) < 32;
+
+    // ---- normalise and store O[q][h*64 + d] of the current query tile (or, key-split tail round: leave (O^T unnormalised, running max,
+    // sum) of this key range for attention_combine_kernel) ----
+    auto store_out = [&]() {
+        const float l_tot = w.l_run + __shfl_xor(w.l_run, 32, 64);
+        int qcol = lane & 31, hh = lane >> 5;
+        asm volatile("" : "+v"(qcol), "+v"(hh));  // (keeps the address arithmetic below out of the chain loop's live ranges)
+        const int q = q0 + qcol;
+        if (part >= 0) {
+            if (q < NQ) {
+                float* rec = p.ks_scratch + (((size_t)(item - p.ks_main) * p.ks_parts + part) * 128 + (wave * 32 + qcol)) * 68;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4*>(rec + db * 32 + 8 * g + 4 * hh) =
+                            f32x4{w.oacc[db][4 * g], w.oacc[db][4 * g + 1], w.oacc[db][4 * g + 2], w.oacc[db][4 * g + 3]};
+                if (hh == 0) {
+                    rec[64] = w.m_run;
+                    rec[65] = l_tot;
+                }
+            }
+            return;
+        }
+        const float inv = 1.0f / l_tot;
+        if (q < NQ) {
+            const int64_t orow = (int64_t)b * NQ + q;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 hi4, lo4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = w.oacc[db][4 * g + e] * inv;
+                        const bf16 hi = (bf16)v;
+                        hi4[e] = hi;
+                        if constexpr (PLANES == 2) lo4[e] = (bf16)(v - (float)hi);
+                    }
+                    const int d0 = db * 32 + 8 * g + 4 * hh;
+                    bf16* dst = p.o + a_pos<PLANES>(orow, p.ldo, h * 64 + d0);  // GEMM A-operand layout (common.h)
+                    *reinterpret_cast<bf16x4*>(dst) = hi4;
+                    if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + kLoOffset) = lo4;
+                }
+        }
+    };
+
+    // ---- prologue of the work item: K(kt0), V(kt0), K(kt0 + 1) staged, S(kt0) without interleaving ----
+    int pb = 0;
     f32x16 sa[2], sb[2];
-    stage_k(kt0);
-    stage_v(kt0);
-    if (kt0 + 1 < nkt) stage_k(kt0 + 1);
+    stage_k(kt0, kt0 & 1);
+    stage_v(kt0, kt0 & 1);
+    if (kt0 + 1 < nkt) stage_k(kt0 + 1, (kt0 + 1) & 1);
     CWM_TILE_END();
     if (active) qk_plain<PLANES>(w, smem + (kt0 & 1) * SLOT_BYTES, sa);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();  // K(kt0) is re-staged by the first tile
     __builtin_amdgcn_sched_barrier(0);
 
-    int kt = kt0;
-    for (; kt + 4 < nkt; kt += 2) {  // tiles staged here (up to K(kt + 3)) are never the last one: no row clamp
-        CWM_TILE(true, sa, sb, kt, std::false_type{});
-        CWM_TILE(true, sb, sa, kt + 1, std::false_type{});
-    }
-    for (; kt + 2 < nkt; kt += 2) {
-        CWM_TILE(true, sa, sb, kt, std::true_type{});
-        CWM_TILE(true, sb, sa, kt + 1, std::true_type{});
-    }
-    // ONE instance of the last tile: with two (S in sa after an odd count, in sb after an even one) hipcc merged the two paths through
-    // copies of the S and O accumulators and spilled around them (256 VGPRs + 5 dwords of scratch; now 222, none); an even count moves
-    // its S values over instead (32 v_mov, once per workgroup).  Same-box A/B: profiles/r4_ab_attention_no_spill.log (equal within noise).
-    if (kt + 2 == nkt) {
-        CWM_TILE(true, sa, sb, kt, std::true_type{});
+    // ---- the query tiles of the item; S(first key tile) of the current one is in sa ----
+    // Tile instances: two steady ones (no row clamp: the tiles they stage are never the last one), one clamped single step for the 1 - 2 tiles
+    // between the pair loop and the end (S moved back into sa: 32 v_mov), the second-to-last tile and the two forms of the last one.  (ONE
+    // instance per role: with two -- S in sa after an odd count, in sb after an even one -- hipcc merged the paths through copies of the S and
+    // O accumulators and spilled around them, round 4.)
+    int kt_last = kt0;
+    for (int c = 0;; ++c) {
+        const bool cont = c + 1 < nchain;
+        int kt = kt0;
+        asm volatile("" : "+s"(N), "+s"(nkt));
+        if (kt + 1 < nkt) {
+            for (; kt + 4 < nkt; kt += 2) {
+                CWM_TILE(TILE_STEADY, sa, sb, kt, std::false_type{});
+                CWM_TILE(TILE_STEADY, sb, sa, kt + 1, std::false_type{});
+            }
+            for (; kt + 2 < nkt; ++kt) {
+                CWM_TILE(TILE_STEADY, sa, sb, kt, std::true_type{});
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) sa[kb] = sb[kb];
-        ++kt;
+                for (int kb = 0; kb < 2; ++kb) sa[kb] = sb[kb];
+            }
+            CWM_TILE(TILE_PENULT, sa, sb, kt, std::true_type{});
+            ++kt;
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sb[kb] = sa[kb];
+        }
+        if (!cont) {
+            kt_last = kt;
+            break;
+        }
+        CWM_TILE(TILE_LAST_NEXT, sb, sa, kt, std::true_type{});
+        store_out();
+        // next query tile of the chain: its Q fragments are in place (TILE_PENULT), S(0) is in sa, key tiles 0 / 1 are staged or in flight
+        reset_acc();
+        q0 += 32 * NW;
+        active = q0 < NQ;
+        pb ^= nkt & 1;
     }
-    CWM_TILE(false, sa, sb, kt, std::true_type{});
+    {
+        const bool cont = false;
+        CWM_TILE(TILE_LAST_END, sb, sa, kt_last, std::true_type{});
+        store_out();
+    }
 #undef CWM_TILE
 #undef CWM_TILE_END
 #ifdef CWM_ATTN_PROF
@@ -469,49 +581,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
     if (prof && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0)
         for (int i = 0; i < 8; ++i) g_pipe_prof[i] = pacc[i];
 #endif
-
-    const float l_tot = w.l_run + __shfl_xor(w.l_run, 32, 64);
-    if (part >= 0) {
-        // ---- key-split tail round: leave (O^T unnormalised, running max, sum) of this key range for attention_combine_kernel ----
-        const int q = q0 + qcol;
-        if (q < NQ) {
-            float* rec = p.ks_scratch + (((size_t)(item - p.ks_main) * p.ks_parts + part) * 128 + (wave * 32 + qcol)) * 68;
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4*>(rec + db * 32 + 8 * g + 4 * hh) =
-                        f32x4{w.oacc[db][4 * g], w.oacc[db][4 * g + 1], w.oacc[db][4 * g + 2], w.oacc[db][4 * g + 3]};
-            if (hh == 0) {
-                rec[64] = w.m_run;
-                rec[65] = l_tot;
-            }
-        }
-        return;
-    }
-    // ---- normalise and store O[q][h*64 + d] ----------------------------------------------------------
-    const float inv = 1.0f / l_tot;
-    const int q = q0 + qcol;
-    if (q < NQ) {
-        const int64_t orow = (int64_t)b * NQ + q;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 hi4, lo4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = w.oacc[db][4 * g + e] * inv;
-                    const bf16 hi = (bf16)v;
-                    hi4[e] = hi;
-                    if constexpr (PLANES == 2) lo4[e] = (bf16)(v - (float)hi);
-                }
-                const int d0 = db * 32 + 8 * g + 4 * hh;
-                bf16* dst = p.o + a_pos<PLANES>(orow, p.ldo, h * 64 + d0);  // GEMM A-operand layout (common.h)
-                *reinterpret_cast<bf16x4*>(dst) = hi4;
-                if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + kLoOffset) = lo4;
-            }
-    }
 }
 
 #ifdef CWM_ATTN_PROF
@@ -563,6 +632,8 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const AttnParams
 }
 
 int g_attn_ksplit = 1;
+int g_attn_chain = 0;         // 0: automatic; 1: single query tiles; C >= 2: chains of C query tiles
+int g_attn_chain_heads = -1;  // -1: automatic; else the number of chained heads per XCD
 
 // scratch of the key-split tail round: at most one round of partial workgroups (512 x 128 queries x 68 floats = 17.8 MB), one buffer per
 // (device, stream) -- the batch lanes launch concurrently --, created on first need
@@ -615,10 +686,29 @@ static int launch_pipe(const AttnParams& p_in, hipStream_t stream) {
             }
         }
     }
+    // ---- chained work items (attention_device.h attn_chain_item): only with the XCD-aware mapping, without a key-split tail round, and for
+    // sequences long enough that the wrap-around of the LDS ring never meets a tile still in use (>= 4 key tiles) ----
+    p.chain_len = 0;
+    p.chain_heads = 0;
+    unsigned grid = (unsigned)(n_items + extra);
+    if (NW == 4 && p.ks_parts == 0 && p.remap && nbh % 8 == 0 && (p.n_tok + 63) / 64 >= 4 && g_attn_chain != 1) {
+        const int full = nq / 128, per = nbh / 8;
+        int C = g_attn_chain >= 2 ? g_attn_chain : 0, hc = g_attn_chain_heads;
+        if (C >= 2 && full >= C && hc != 0) {
+            if (hc == -2) {  // only as many chained heads as fill whole rounds of the XCD's workgroup slots (2 per CU)
+                const int nc = full / C, slots_x = 2 * gemm_cu_count() / 8;
+                hc = (per * nc / slots_x) * slots_x / nc;
+            }
+            if (hc < 0 || hc > per) hc = per;
+            p.chain_len = C;
+            p.chain_heads = hc;
+            grid = 8u * (unsigned)attn_chain_items_per_xcd(nqb, nbh, nq, 128, C, hc);
+        }
+    }
     const size_t smem = (size_t)4 * (64 * 64 * 2) * PLANES;  // 2 K slots + 2 V slots
     if (smem > 48 * 1024)
         if (int rc = cwm_set_max_lds((const void*)attention_pipe_kernel<PLANES, NW>, (int)smem)) return rc;
-    hipLaunchKernelGGL((attention_pipe_kernel<PLANES, NW>), dim3((unsigned)(n_items + extra)), dim3(64 * NW), smem, stream, p);
+    hipLaunchKernelGGL((attention_pipe_kernel<PLANES, NW>), dim3(grid), dim3(64 * NW), smem, stream, p);
     if (p.ks_parts > 0)
         hipLaunchKernelGGL((attention_combine_kernel<PLANES>), dim3((unsigned)((n_items - p.ks_main) * 32)), dim3(256), 0, stream, p);
     CWM_HIP_CHECK(hipGetLastError());

@@ -37,6 +37,10 @@ extern "C" const char* cwm_version(void) { return "cwm_hip 0.5.0 gfx950"; }
 #define CWM_SRC_HASH "unknown"
 #endif
 extern "C" const char* cwm_source_hash(void) { return CWM_SRC_HASH; }
+#ifndef CWM_HIPCC_VERSION
+#define CWM_HIPCC_VERSION "unknown"
+#endif
+extern "C" const char* cwm_compiler_version(void) { return CWM_HIPCC_VERSION; }
 
 namespace cwm {
 

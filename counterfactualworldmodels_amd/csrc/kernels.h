@@ -84,6 +84,9 @@ struct AttnParams {
     int ks_main, ks_parts, ks_nqb;
     float* ks_scratch;  // [items - ks_main][ks_parts][128 queries][68]: O[64], max, sum, -, -
     int tail_split;  // set by launch_attention: a ragged last query tile of at most 32 rows splits the KEYS over its four waves (attention_tail.h; "attn_tail" switch)
+    // chained schedule (attention_pipe.hip, "attn_chain" switch), set by launch_attention_pipe: the first chain_heads heads of every XCD's share run as
+    // work items of chain_len consecutive full query tiles (attention_device.h attn_chain_item).  chain_len < 2: off
+    int chain_len, chain_heads;
 };
 
 int launch_attention(const AttnParams& p, int planes, hipStream_t stream);
@@ -92,7 +95,9 @@ int launch_attention_pipe(const AttnParams& p, int planes, hipStream_t stream); 
 extern int g_attn_remap;   // 1 (default): attn_tile_of_block's XCD-aware mapping; 0: plain (blockIdx.x, blockIdx.y)
 extern int g_attn_ksplit;  // 1 (default): a last round of workgroups that fills at most a quarter of the chip splits its items' KEYS over the idle slots (attention_pipe.hip)
 extern int g_attn_tail;    // 1 (default): key-split schedule for a ragged last query tile of <= 32 rows; 0: the regular schedule for every tile
-extern int g_attn_kernel;  // 0 auto, 1: 4-wave kernel, 2: 8-wave staggered kernel
+extern int g_attn_kernel;  // 0 auto, 1: 4-wave kernel, 3: software-pipelined kernel
+extern int g_attn_chain;        // 0 (default): automatic chain length of the pipelined kernel's work items; 1: single query tiles; C >= 2: chains of C
+extern int g_attn_chain_heads;  // -1 (default): automatic; else the number of chained heads per XCD
 
 struct LayerNormParams {
     const float* x;  // rows of length D, row stride ldx

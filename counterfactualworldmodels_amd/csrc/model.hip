@@ -599,6 +599,14 @@ extern "C" int cwm_debug_set(const char* key, int value) {
         g_attn_ksplit = value;
         return CWM_OK;
     }
+    if (!strcmp(key, "attn_chain")) {  // 0 auto, 1 single query tiles, C >= 2: work items of C consecutive query tiles (attention_pipe.hip)
+        g_attn_chain = value;
+        return CWM_OK;
+    }
+    if (!strcmp(key, "attn_chain_heads")) {
+        g_attn_chain_heads = value;
+        return CWM_OK;
+    }
     if (!strcmp(key, "attn_tail")) {
         g_attn_tail = value;
         return CWM_OK;
