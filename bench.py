@@ -1,6 +1,8 @@
 """bench.py -- predicted frames/s of the VMAE predictor path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --workload prompts256 --gpus N          # BASELINE configs[3] alone: 256 prompts on one frame pair, sharded over N ranks
+                                                            # (strong scaling; per_rank_ms = every rank's {build, broadcast, own_prompts, predict, gather})
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -42,6 +44,17 @@ WORKLOADS = {
     "large4": dict(cfg="large_4x4patch_2frames_1tube", batch=8, k_vis=32, clump=2,
                    name="ViT-large VMAE 4x4, batch=8 (BASELINE configs[2])"),
 }
+
+
+def build_info():
+    """Which library this line was measured with: version, source hash, the hipcc that compiled it, and whether that compiler is the one the
+    ISA lint of the hand-counted waits last passed on (csrc/LINT_PASSED.json; tools/asm_lds_lint.py --record)."""
+    from counterfactualworldmodels_amd import build
+
+    lib = _lib.get_lib()
+    comp = lib.cwm_compiler_version().decode()
+    return {"library": lib.cwm_version().decode(), "source_hash": lib.cwm_source_hash().decode(), "compiler": comp,
+            "lint_passed_on_this_compiler": build.lint_record().get("hipcc") == comp}
 
 
 def timed_steps(G, x, mask, n_vis, steps, distributed):
@@ -127,8 +140,9 @@ def cpu_baseline(cfg, k_vis, clump, seed, budget_s=20.0):
                 break
         dt = time.perf_counter() - t0
     return {
-        "value": B * n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": "%d forward passes of batch %d (%s, k_vis=%d) through oracle/vmae_oracle.py, torch CPU fp32 eager" % (n, B, cfg.name, k_vis),
+        "value": B * n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "host_threads_available": os.cpu_count(), "kind": "port",
+        "sample": "%d forward passes of batch %d (%s, k_vis=%d) through oracle/vmae_oracle.py, torch CPU fp32 eager on %d threads (the best of an 8 ... 256 "
+                  "scan on this host type; the GPU line runs batch 32)" % (n, B, cfg.name, k_vis, torch.get_num_threads()),
     }
 
 
@@ -178,8 +192,22 @@ def prompts_measure(args, rank, local_rank, world, distributed, model=None, step
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # one more (untimed) step with HIP-event spans around its phases, from every rank: a bad curve on the multi-GPU node can then be read from
+    # ONE run -- which rank, which phase (rank 0 alone builds all prompts and rectangularises; the gather runs on a side stream)
+    ph = cdist.PhaseTimes(dev)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    cdist.sharded_counterfactual_predictions(x0, table, *hooks, dev, chunk=PROMPTS["chunk"], gather=True, comm=comm, shapes=shapes, times=ph)
+    torch.cuda.synchronize()
+    mine = {k: round(v, 3) for k, v in ph.result().items()}
+    mine["wall"] = round(1e3 * (time.perf_counter() - t1), 3)
+    per_rank = [mine]
+    if distributed:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     n_gpus = world if distributed else 1
     return {
+        "per_rank_ms": per_rank,
         "metric": "predicted frames/sec (2x224x224, ViT-B/8)", "value": PROMPTS["total"] * steps / dt, "unit": "frames/s",
         "n_gpus": n_gpus, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -200,6 +228,7 @@ def run_prompts(args, rank, local_rank, world, distributed):
         cdist.reset_comm()
         dist.destroy_process_group()
     if rank == 0:
+        out["build"] = build_info()
         print(json.dumps(out))
 
 
@@ -242,7 +271,7 @@ def run_imu(args, rank, local_rank, world, distributed):
     step()
     model.set_lanes(args.lanes)
     if os.environ.get("CWM_CONJ_CTX_STREAM") == "0":  # profiling runs: the context stream's launches on the lane's own stream, so that no two
-        _lib.check(_lib.get_lib().cwm_debug_set(b"conj_ctx_stream", 0))  # kernels overlap and per-kernel durations mean what they say
+        model.set_option("conj_ctx_stream", 0)          # kernels overlap and per-kernel durations mean what they say
     for _ in range(max(args.warmup, 1)):
         step()
     dt = region()
@@ -292,6 +321,7 @@ def run_imu(args, rank, local_rank, world, distributed):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        out["build"] = build_info()
         print(json.dumps(out))
 
 
@@ -457,6 +487,7 @@ def main():
         "model_frac_of_bf16_peak": flops_pair * value / 1e12 / (PEAK_BF16_TFLOPS * n_gpus),
         # one more (untimed) step before and after the timed region: same input, same bits expected (a timing-dependent fault would show here)
         "output_stable": bool(checksum_before == checksum_after and checksum_after == checksum_after),
+        "build": build_info(),
     }
     planes = 2 if args.mode == "parity" else 1
     kernels = {  # (names as rocprofv3 prints them)
@@ -510,7 +541,7 @@ def main():
     if args.workload == "base8" and not args.no_prompts:
         try:
             pm = prompts_measure(args, rank, local_rank, world, distributed, model=model, steps=max(3, args.steps // 4), warmup=2)
-            out["prompts256"] = {k: pm[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "steps")}
+            out["prompts256"] = {k: pm[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "steps", "per_rank_ms")}
             out["prompts256"]["config"] = pm["config"]
             out["rccl_ranks"], out["collectives"] = pm["config"]["comm_world"], pm["config"]["collectives"]
         except Exception as e:  # noqa: BLE001

@@ -57,6 +57,7 @@ class CwmConfig(C.Structure):
 
 class CwmForwardArgs(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),  # = C.sizeof(CwmForwardArgs): new_forward_args() sets it
         ("x_dev", C.c_void_p),
         ("x_stride_b", C.c_int64),
         ("x_stride_c", C.c_int64),
@@ -97,6 +98,7 @@ class CwmConjConfig(C.Structure):
 
 class CwmConjForwardArgs(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("x_dev", C.c_void_p),
         ("x_stride_b", C.c_int64),
         ("x_stride_c", C.c_int64),
@@ -116,6 +118,18 @@ class CwmConjForwardArgs(C.Structure):
     ]
 
 
+def new_forward_args() -> CwmForwardArgs:
+    a = CwmForwardArgs()
+    a.struct_size = C.sizeof(CwmForwardArgs)
+    return a
+
+
+def new_conj_forward_args() -> CwmConjForwardArgs:
+    a = CwmConjForwardArgs()
+    a.struct_size = C.sizeof(CwmConjForwardArgs)
+    return a
+
+
 class CwmKernelStats(C.Structure):
     _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("total_flops", C.c_double)]
 
@@ -128,6 +142,8 @@ SIGNATURES = {
     "cwm_model_missing_weights": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "cwm_forward": (C.c_int, [C.c_void_p, C.POINTER(CwmForwardArgs)]),
     "cwm_model_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
+    "cwm_model_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "cwm_conj_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "cwm_conj_create": (C.c_int, [C.POINTER(CwmConjConfig), C.POINTER(C.c_void_p)]),
     "cwm_conj_destroy": (None, [C.c_void_p]),
     "cwm_conj_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
@@ -154,7 +170,6 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p] * 6,
     ),
-    "cwm_gemm_tile_override": (C.c_int, [C.c_int] * 6),
     "cwm_flow_features": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "cwm_flow_cov": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 4),
     "cwm_flow_transform": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
@@ -171,16 +186,22 @@ SIGNATURES = {
     "cwm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cwm_allgatherv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p]),
     "cwm_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cwm_last_error": (C.c_char_p, []),
+    "cwm_version": (C.c_char_p, []),
+    "cwm_source_hash": (C.c_char_p, []),
+    "cwm_compiler_version": (C.c_char_p, []),
+}
+# ... and every symbol of include/cwm_hip_dev.h: only libcwm_hip_dev.so (get_dev_lib) has these
+DEV_SIGNATURES = {
+    "cwm_gemm_tile_override": (C.c_int, [C.c_int] * 6),
     "cwm_bench_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cwm_bench_gemm_gapped": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_double)]),
     "cwm_bench_attention": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cwm_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
-    "cwm_last_error": (C.c_char_p, []),
-    "cwm_version": (C.c_char_p, []),
-    "cwm_source_hash": (C.c_char_p, []),
 }
 
 _lib: Optional[C.CDLL] = None
+_dev_lib: Optional[C.CDLL] = None
 _lock = threading.Lock()
 
 
@@ -233,9 +254,34 @@ def get_lib() -> C.CDLL:
         return lib
 
 
-def _bind(path: str) -> C.CDLL:
+def dev_library_path() -> str:
+    p = library_path()
+    return os.environ.get("CWM_HIP_DEV_LIB", _build.DEV_LIB_PATH if p == _build.LIB_PATH else p[:-3] + "_dev.so")
+
+
+def get_dev_lib() -> C.CDLL:
+    """The development library (libcwm_hip_dev.so: the production objects + csrc/dev.hip; include/cwm_hip_dev.h) -- for tools/ and for the tests that
+    cross-check kernel variants.  A SEPARATE shared object with its own state: handles created through it are its own; `cwm_debug_set` acts on the
+    calling thread's options inside it and never on the production library."""
+    global _dev_lib
+    if _dev_lib is not None:
+        return _dev_lib
+    get_lib()  # builds / rebuilds both libraries if the sources changed
+    with _lock:
+        if _dev_lib is None:
+            path = dev_library_path()
+            if not os.path.exists(path):
+                raise RuntimeError("libcwm_hip_dev.so is missing at %s: run `python -m counterfactualworldmodels_amd.build`" % path)
+            lib = _bind(path, dict(SIGNATURES, **DEV_SIGNATURES))
+            if path == _build.DEV_LIB_PATH and os.path.isdir(_build.CSRC) and lib.cwm_source_hash().decode() != _build.source_hash():
+                raise RuntimeError("libcwm_hip_dev.so at %s was built from other sources than the tree holds: run `python -m counterfactualworldmodels_amd.build`" % path)
+            _dev_lib = lib
+    return _dev_lib
+
+
+def _bind(path: str, signatures=None) -> C.CDLL:
     lib = C.CDLL(path)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in (signatures or SIGNATURES).items():
         try:
             fn = getattr(lib, name)  # a missing symbol fails loudly
         except AttributeError:
@@ -248,9 +294,13 @@ def _bind(path: str) -> C.CDLL:
     return lib
 
 
-def check(rc: int) -> None:
+def check(rc: int, lib: Optional[C.CDLL] = None) -> None:
+    """Raise for a negative return code; `lib` = the library the call went through (default: the production one; a call through the development
+    library that fails leaves its message there -- the thread-local error text is per shared object)."""
     if rc != 0:
-        msg = get_lib().cwm_last_error()
+        msg = (lib or get_lib()).cwm_last_error()
+        if not msg and lib is None and _dev_lib is not None:
+            msg = _dev_lib.cwm_last_error()
         raise CwmHipError(rc, (msg.decode() if msg else "") + " [cwm_hip rc=%d]" % rc)
 
 

@@ -10,9 +10,12 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcwm_hip.so")
+DEV_LIB_PATH = os.path.join(LIB_DIR, "libcwm_hip_dev.so")  # the same objects + csrc/dev.hip (switches, micro-benchmarks: include/cwm_hip_dev.h)
+DEV_SOURCES = ["dev.hip"]
 SOURCES = ["gemm.hip", "attention.hip", "attention_pipe.hip", "elementwise.hip", "conj_kernels.hip", "conj_attention.hip", "flowstats.hip", "engine.hip", "model.hip",
            "conj_model.hip", "comm.hip"]
-HEADERS = ["common.h", "kernels.h", "gemm_device.h", "attention_device.h", "attention_tail.h", "engine.h", os.path.join("..", "..", "include", "cwm_hip.h")]
+HEADERS = ["exports.map", "common.h", "kernels.h", "gemm_device.h", "attention_device.h", "attention_tail.h", "engine.h", os.path.join("..", "..", "include", "cwm_hip.h"),
+           os.path.join("..", "..", "include", "cwm_hip_dev.h")]
 
 
 def _hipcc() -> str:
@@ -33,8 +36,7 @@ LINT_RECORD = os.path.join(CSRC, "LINT_PASSED.json")
 
 
 def lint_record() -> dict:
-    """What tools/asm_lds_lint.py --record last wrote: the compiler version the ISA lint of the hand-counted waits passed on (and the hashes of the
-    sources it read).  The kernels' counted `s_waitcnt`s are only as good as the ISA the compiler emits around them."""
+    """What tools/asm_lds_lint.py --record last wrote: the compiler version the ISA lint of the hand-counted waits passed on .  (The lint itself runs on the current sources in the CPU test suite; the record pins the COMPILER.)  The kernels' counted `s_waitcnt`s are only as good as the ISA the compiler emits around them."""
     import json
 
     try:
@@ -60,7 +62,7 @@ def source_hash() -> str:
     import hashlib
 
     h = hashlib.sha1()
-    for f in sorted(SOURCES + HEADERS):
+    for f in sorted(SOURCES + DEV_SOURCES + HEADERS):
         h.update(f.encode())
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
@@ -76,10 +78,10 @@ def _stamp_hash() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(DEV_LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    t = min(os.path.getmtime(LIB_PATH), os.path.getmtime(DEV_LIB_PATH))
+    deps = [os.path.join(CSRC, s) for s in SOURCES + DEV_SOURCES + HEADERS]
     return any(os.path.getmtime(d) > t for d in deps) or _stamp_hash() != source_hash()
 
 
@@ -122,7 +124,8 @@ def build_library(force: bool = False, verbose: bool = False, out_path: str = No
 
 
 def _build_locked(out_path, extra, obj_dir, force, verbose):
-    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + extra
+    # -fvisibility=hidden: the library exports the C ABI of include/cwm_hip.h (CWM_API) and nothing else
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"] + extra
     hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     jobs, objs = [], []
     stamp = os.path.join(obj_dir, "source_hash.txt")
@@ -132,9 +135,11 @@ def _build_locked(out_path, extra, obj_dir, force, verbose):
             stale_hash = fh.read().strip() != shash
     except OSError:
         stale_hash = True
-    for s in SOURCES:
+    dev_objs = [os.path.join(obj_dir, s + ".o") for s in DEV_SOURCES]
+    for s in SOURCES + DEV_SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(obj_dir, s + ".o")
-        objs.append(obj)
+        if s in SOURCES:
+            objs.append(obj)
         if s == "engine.hip":  # carries the hash of ALL sources (cwm_source_hash): recompiled whenever anything changed
             if force or stale_hash or not os.path.exists(obj):
                 jobs.append((base + ['-DCWM_SRC_HASH="%s"' % shash, '-DCWM_HIPCC_VERSION="%s"' % hipcc_version().replace('"', "'"), "-c", src, "-o", obj], obj))
@@ -153,10 +158,18 @@ def _build_locked(out_path, extra, obj_dir, force, verbose):
                 if verbose and log.strip():
                     print(log, file=sys.stderr)
     tmp = "%s.tmp%d" % (out_path, os.getpid())
-    res = subprocess.run(base + ["-shared"] + objs + ["-ldl", "-o", tmp], capture_output=True, text=True)
+    link = ["-shared", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
+    res = subprocess.run(base + link + objs + ["-ldl", "-o", tmp], capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, out_path)
+    # the development library: the production objects + dev.hip, beside the production one (side builds: <name>_dev.so)
+    dev_out = DEV_LIB_PATH if out_path == LIB_PATH else out_path[:-3] + "_dev.so"
+    tmp = "%s.tmp%d" % (dev_out, os.getpid())
+    res = subprocess.run(base + link + objs + dev_objs + ["-ldl", "-o", tmp], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc link failed (development library):\n" + res.stdout + res.stderr)
+    os.replace(tmp, dev_out)
     with open(stamp, "w") as fh:
         fh.write(shash)
     check_lint_record()

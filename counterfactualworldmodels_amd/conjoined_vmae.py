@@ -136,8 +136,31 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
         return ((x, mask, None),)
 
     # ---- C-ABI plumbing ------------------------------------------------------------------------------
+    # ---- C-ABI plumbing --------------------------------------------------------------------------
+    def _library(self):
+        """The shared object this module's handle lives in: libcwm_hip.so unless `use_library` chose the development one."""
+        lib = getattr(self, "_cwm", None)
+        return lib if lib is not None else _lib.get_lib()
+
+    def _check(self, rc):
+        _lib.check(rc, self._library())
+
+    def use_library(self, lib):
+        """Create this model's handle in another build of the library (tools / tests: `_lib.get_dev_lib()`, whose per-shape tile overrides and
+        thread-local switches a handle of the production library never sees).  Call before the first forward; an existing handle is released."""
+        self._release()
+        object.__setattr__(self, "_cwm", lib)
+
+    def set_option(self, key: str, value: int):
+        """One execution option of THIS model (include/cwm_hip.h cwm_conj_set_option: "attn_kernel", "gemm_tile", "prune_last_block" ...): per handle, never
+        process-wide.  Options set before the first forward are applied when the handle is created."""
+        opts = self.__dict__.setdefault("_options", {})
+        opts[key] = int(value)
+        if getattr(self, "_handle", None) is not None:
+            self._check(self._library().cwm_conj_set_option(self._handle, key.encode(), int(value)))
+
     def _ensure_handle(self, device: torch.device) -> int:
-        lib = _lib.get_lib()
+        lib = self._library()
         if self._handle is not None and self._handle_device == device:
             return self._handle
         self._release()
@@ -157,14 +180,16 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
         cc.cross_heads, cc.cross_mlp_ratio = c.cross_heads, c.cross_mlp_ratio
         h = C.c_void_p()
         with torch.cuda.device(device):
-            _lib.check(lib.cwm_conj_create(C.byref(cc), C.byref(h)))
+            self._check(lib.cwm_conj_create(C.byref(cc), C.byref(h)))
         self._handle, self._handle_device, self._loaded = h.value, device, {}
+        for k, v in self.__dict__.get("_options", {}).items():
+            self._check(lib.cwm_conj_set_option(self._handle, k.encode(), v))
         return self._handle
 
     def _release(self):
         if getattr(self, "_handle", None) is not None:
             try:
-                _lib.get_lib().cwm_conj_destroy(self._handle)
+                self._library().cwm_conj_destroy(self._handle)
             except Exception:
                 pass
             # plain attributes: nn.Module.__setattr__ can already be half torn down when __del__ runs at interpreter exit
@@ -184,7 +209,7 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
         if not force and self._handle is not None and self._handle_device == device and self._params_unchanged():
             return 0
         h = self._ensure_handle(device)
-        lib = _lib.get_lib()
+        lib = self._library()
         if force:
             self._loaded = {}
         n = 0
@@ -197,7 +222,7 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
                 if t.dtype != torch.float32 or not t.is_contiguous():
                     t = t.float().contiguous()
                 shape = (C.c_int64 * t.dim())(*t.shape)
-                _lib.check(lib.cwm_conj_load_weight(h, name.encode(), t.data_ptr(), 1 if t.is_cuda else 0, shape, t.dim()))
+                self._check(lib.cwm_conj_load_weight(h, name.encode(), t.data_ptr(), 1 if t.is_cuda else 0, shape, t.dim()))
                 self._loaded[name] = tag
                 n += 1
         self._remember_params()
@@ -258,10 +283,11 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
         # the context stream's predictions: head(norm(x_c[:, -n:])) * ~null_mask over its masked + pad slots (conjoined_vmae.py:990-1002)
         y_ctx = torch.empty((B, c.ctx_tokens + c.ctx_max_pad - vcmax, c.ctx_out_dim), device=dev, dtype=torch.float32) if want_ctx else None
         args_ = _lib.CwmConjForwardArgs(
+            C.sizeof(_lib.CwmConjForwardArgs),
             x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), int(normalize), mask.data_ptr(), B, vmax, ctx.data_ptr(), mc.data_ptr(),
             vcmax, y.data_ptr(), _lib.mode_id(self.mode), int(check), _lib.current_stream_handle(dev), _lib.ptr(y_ctx))
         with torch.cuda.device(dev):
-            _lib.check(_lib.get_lib().cwm_conj_forward(self._handle, C.byref(args_)))
+            self._check(self._library().cwm_conj_forward(self._handle, C.byref(args_)))
         self._record_padding_state(mask, vis, vmax, mc, vis_c, vcmax)
         if want_main and want_ctx:
             return y, y_ctx
@@ -286,14 +312,14 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
         """See `vmae.PretrainVisionTransformer.set_lanes`."""
         if self._handle is None:
             raise RuntimeError("run a forward pass (or sync_weights) before set_lanes")
-        _lib.check(_lib.get_lib().cwm_conj_set_lanes(self._handle, int(lanes)))
+        self._check(self._library().cwm_conj_set_lanes(self._handle, int(lanes)))
 
     def timing_enable(self, kclass: int, enable: bool = True):
-        _lib.check(_lib.get_lib().cwm_conj_timing_enable(self._handle, kclass, int(enable)))
+        self._check(self._library().cwm_conj_timing_enable(self._handle, kclass, int(enable)))
 
     def timing_collect(self, kclass: int):
         st = _lib.CwmKernelStats()
-        _lib.check(_lib.get_lib().cwm_conj_timing_collect(self._handle, kclass, C.byref(st)))
+        self._check(self._library().cwm_conj_timing_collect(self._handle, kclass, C.byref(st)))
         return {"launches": st.launches, "total_ms": st.total_ms, "total_flops": st.total_flops}
 
 

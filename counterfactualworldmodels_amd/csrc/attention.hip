@@ -277,15 +277,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-int g_attn_kernel = 0;  // 0 auto, 1: 4-wave kernel (this file), 3: software-pipelined kernel (attention_pipe.hip)
-
-int g_attn_remap = 1;
-int g_attn_tail = 1;
-
 int launch_attention(const AttnParams& p_in, int planes, hipStream_t stream) {
     AttnParams p = p_in;
-    p.remap = g_attn_remap;
-    p.tail_split = g_attn_tail;
+    const Tuning& tn = p.tune ? *p.tune : default_tuning();
+    p.remap = tn.attn_remap;
+    p.tail_split = tn.attn_tail;
     CWM_REQUIRE(planes == 1 || planes == 2, "attention: planes must be 1 or 2");
     CWM_REQUIRE(p.n_tok > 0 && p.batch > 0 && p.heads > 0, "attention: empty problem");
     CWM_REQUIRE(p.ldo % 4 == 0, "attention: ldo must be a multiple of 4");
@@ -300,8 +296,8 @@ int launch_attention(const AttnParams& p_in, int planes, hipStream_t stream) {
     //   fast mode: one MFMA per product leaves the loop VALU-bound: kernel 1 is 1-5 % ahead on the B/8 sequences (792, 1568 tokens),
     //     kernel 3 2-4 % ahead on the L/4 ones (3168, 6272) -> by sequence length;
     //   (a staggered 8-wave kernel, "2", tied kernel 1 in parity mode and lost 25-35 % in fast mode: removed in round 4).
-    // Both produce bit-identical outputs (tests/test_kernels_gpu.py); cwm_debug_set "attn_kernel" forces one.
-    const int kern = g_attn_kernel ? g_attn_kernel : ((planes == 2 || p.n_tok >= 2048) ? 3 : 1);
+    // Both produce bit-identical outputs (tests/test_kernels_gpu.py); Tuning.attn_kernel forces one.
+    const int kern = tn.attn_kernel ? tn.attn_kernel : ((planes == 2 || p.n_tok >= 2048) ? 3 : 1);
     if (kern == 3) return launch_attention_pipe(p, planes, stream);
     CWM_REQUIRE(kern == 1, "attention: unknown kernel %d (1: 4-wave, 3: software-pipelined)", kern);
     const dim3 grid(nqb, p.batch * p.heads);

@@ -28,41 +28,6 @@ __device__ __forceinline__ void attn_tile_of_item(int L, int nqb, int nbh, int n
         qt = nqb - 1;
     }
 }
-// Work items of the chained schedule (attention_pipe.hip; AttnParams.chain_len = C >= 2): the first chain_heads heads of every XCD's share
-// are cut into chains of C consecutive FULL query tiles -- one workgroup walks the chain with the K / V tiles of the head L2-hot and the
-// software pipeline running through the query-tile boundary --, everything else stays a single tile.  Dispatch order inside an XCD, longest
-// items first: chains, then the single tiles (what the chains leave of their heads, then the unchained heads), then the light ragged tiles.
-//   full = nq / rows whole tiles per head, nc = full / C chains, heavy = nqb - light, left = heavy - nc C single tiles of a chained head
-__device__ __host__ __forceinline__ int attn_chain_items_per_xcd(int nqb, int nbh, int nq, int rows, int C, int hc) {
-    const int per = nbh >> 3;
-    const int light = (nqb > 1 && (nq - (nqb - 1) * rows) * 2 <= rows) ? 1 : 0, heavy = nqb - light;
-    const int nc = (nq / rows) / C, left = heavy - nc * C;
-    return hc * (nc + left) + (per - hc) * heavy + per * light;
-}
-__device__ __forceinline__ void attn_chain_item(int L, int nqb, int nbh, int nq, int rows, int C, int hc, int& qt, int& bh, int& nchain) {
-    const int xcd = L & 7, per = nbh >> 3;
-    int idx = L >> 3;
-    const int light = (nqb > 1 && (nq - (nqb - 1) * rows) * 2 <= rows) ? 1 : 0, heavy = nqb - light;
-    const int nc = (nq / rows) / C, left = heavy - nc * C;
-    nchain = 1;
-    int head;
-    if (idx < hc * nc) {  // chains
-        head = idx / nc;
-        qt = (idx - head * nc) * C;
-        nchain = C;
-    } else if ((idx -= hc * nc) < hc * left) {  // what the chains leave of their heads
-        head = idx / left;
-        qt = nc * C + (idx - head * left);
-    } else if ((idx -= hc * left) < (per - hc) * heavy) {  // unchained heads
-        head = idx / heavy;
-        qt = idx - head * heavy;
-        head += hc;
-    } else {  // light ragged tiles
-        head = idx - (per - hc) * heavy;
-        qt = nqb - 1;
-    }
-    bh = xcd * per + head;
-}
 // (the same for a 2-D grid of (nqb, nbh) workgroups: linear id = dispatch order)
 __device__ __forceinline__ void attn_tile_of_block(int nq, int rows, bool remap, int& qt, int& bh) {
     attn_tile_of_item(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, nq, rows, remap, qt, bh);

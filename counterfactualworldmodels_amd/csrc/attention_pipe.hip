@@ -18,11 +18,11 @@
 // computed in iteration t - 1) and V(t+1) (slot of V(t-1)), and ends with vmcnt(0) + one workgroup barrier, a whole
 // tile of work later.
 //
-// Round 5: a work item may be a CHAIN of consecutive full query tiles of one (batch, head) (AttnParams.chain_len).  The key-tile sequence of
-// the chain is one virtual sequence: the last key tile of query tile c computes S(0) of query tile c + 1 in its phase A (with the next
-// tile's Q fragments, loaded under the second-to-last tile's P V), the LDS ring wraps around to key tiles 0 / 1, and the output rows of
-// tile c are stored under the first key tile of c + 1 -- no dispatch gap, no cold prologue, no un-overlapped first S between the query
-// tiles of a chain.  Per query row the arithmetic and its order are those of a single-tile item: outputs are bit-identical.
+// Round 5: the tile function takes its role (steady / second-to-last / last key tile) as a template argument and every runtime branch of a
+// tile sits where no inline-asm LDS read is in flight (see BRANCHES below).  Measured and NOT kept (profiles/r5_attention_chain*.log, DESIGN.md
+// section 4.10): work items that chain 2 - 6 query tiles of one head through the query-tile boundary (next tile's S(0) under the last key tile's
+// softmax, LDS ring wrapping around, outputs stored under the next tile) -- bit-identical, the isolated batch-32 encoder launch 213 -> 201.5 us,
+// the half-batch launches of a two-lane call +-0, the step +0.2 ... +1.2 % (two lanes) / -0.3 % (one lane).
 #include "attention_tail.h"
 #include <algorithm>
 #include <cstdio>
@@ -130,25 +130,23 @@ __device__ __forceinline__ void pv_step(PipeWave<PLANES>& w, const f32x16 (&sc)[
 //     TILE_PENULT     the same, and the next key tile is the LAST of this workgroup's key range: if that is the sequence's last tile and it holds
 //                     at most 32 keys (`half_next`; every model shape: N = 792, 1568, 3168 are 32 mod 64 or less) the S MFMAs of its second,
 //                     all-padding key block are skipped (TILE_LAST sets those values to -inf anyway)
-//     TILE_LAST_NEXT  last key tile of a query tile that is followed by another one (chain): sequence-end mask; the next S is S(0) of the next
-//                     query tile; k-steps 2 / 3 of P V (P exactly 0) skipped when `half_this`; TILE_PENULT's mid() has re-loaded the Q fragments
-//     TILE_LAST_END   last key tile of the work item: no next S
+//     TILE_LAST       last key tile: sequence-end mask, no next S; k-steps 2 / 3 of P V (P exactly 0) skipped when `half_this`
 //   Skipping is bit-identical: an accumulator that only ever adds products to +0 is never -0, so adding the +-0 products changes no bit.
 //   BRANCHES: hipcc takes the output registers of the inline-asm V^T reads for written when the statement issues, so a control-flow merge
 //   between such a read and its hand-counted wait may copy stale registers (round 4 shipped that race for a few hours).  The reads are issued
 //   in the last two slots of phase A and inside phase B; every runtime branch of a tile therefore sits BEFORE slot NS - 2 (the DMA pieces, the
 //   rescale, the half_next skip -- which leaves slot NS - 1's MFMA unconditional for that reason) or after a wait that leaves no read in
 //   flight (`half_this`).  tools/asm_lds_lint.py fails on any branch or label with such reads pending (tests/test_host_logic.py).
-enum : int { TILE_STEADY = 0, TILE_PENULT = 1, TILE_LAST_NEXT = 2, TILE_LAST_END = 3 };
-template <int PLANES, int KIND, int NDMA, typename Dma, typename Mid>
+enum : int { TILE_STEADY = 0, TILE_PENULT = 1, TILE_LAST = 2 };
+template <int PLANES, int KIND, int NDMA, typename Dma>
 __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], f32x16 (&sn)[2], const char* kbase, unsigned va0, unsigned va1, int kt, int N, bool half_next,
-                                          bool half_this, Dma&& dma, Mid&& mid
+                                          bool half_this, Dma&& dma
 #ifdef CWM_ATTN_PROF
     , bool prof, unsigned long long (&pacc)[8], unsigned long long& tlast
 #endif
     ) {
-    constexpr bool HAS_NEXT = KIND != TILE_LAST_END;
-    constexpr bool LASTK = KIND == TILE_LAST_NEXT || KIND == TILE_LAST_END;
+    constexpr bool HAS_NEXT = KIND != TILE_LAST;
+    constexpr bool LASTK = KIND == TILE_LAST;
     constexpr int TILE_BYTES = 64 * 64 * 2;
     constexpr int NM = PLANES == 2 ? 3 : 1;
     constexpr int NS = 8 * NM;       // slots of phase A
@@ -158,8 +156,7 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
 
     if constexpr (LASTK) {
         if (N & 63) {  // keys past the sequence end (last tile only)
-            int hh4 = 4 * w.hh;
-            asm volatile("" : "+v"(hh4));
+            const int hh4 = 4 * w.hh;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -226,7 +223,7 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
                 // the MFMA shadow)
                 // (the last tile has no MFMA slots to protect and the branch made hipcc keep a second copy of the 32 accumulator registers
                 // alive across it -- 5 dwords of scratch: there the multiplication is unconditional, alpha = 1.0f exactly when nothing grew)
-                if (KIND == TILE_LAST_END || grew) {
+                if (KIND == TILE_LAST || grew) {
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -254,7 +251,6 @@ __device__ __forceinline__ void pipe_tile(PipeWave<PLANES>& w, f32x16 (&sc)[2], 
     }
 
     PROF_T(1);
-    if constexpr (KIND == TILE_PENULT) mid();  // (unconditional: vr0 / vr1 are in flight)
     // ---- phase B --------------------------------------------------------------------------------------
 #pragma unroll
     for (int v = 32 * (NE - 1) / NE; v < 32; ++v) rowsum += sc[v >> 4][v & 15];
@@ -321,9 +317,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         kt0 = nkt_all * part / p.ks_parts;
         nkt = nkt_all * (part + 1) / p.ks_parts;  // this workgroup's key tiles: [kt0, nkt)
     }
-    int qt, bh, nchain = 1;
-    if (p.chain_len >= 2) attn_chain_item(item, p.ks_nqb, p.batch * p.heads, NQ, 32 * NW, p.chain_len, p.chain_heads, qt, bh, nchain);
-    else attn_tile_of_item(item, p.ks_nqb, p.batch * p.heads, NQ, 32 * NW, p.remap != 0, qt, bh);
+    int qt, bh;
+    attn_tile_of_item(item, p.ks_nqb, p.batch * p.heads, NQ, 32 * NW, p.remap != 0, qt, bh);
     if constexpr (NW == 4) {
         if (attention_is_split_tail(p, qt, p.ks_nqb, NQ)) {  // ragged last tile of <= 32 rows: the four waves split the keys (attention_tail.h)
             attention_tail_block<PLANES>(p, smem, bh, qt * 128, NQ);
@@ -331,8 +326,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         }
     }
     const int b = bh / p.heads, h = bh - b * p.heads;
-    int q0 = qt * (32 * NW) + wave * 32;  // first query row of this wave in the current query tile
-    bool active = q0 < NQ;  // idle waves (query rows past the end; never inside a chain) only stage tiles and keep the barrier count
+    const int q0 = qt * (32 * NW) + wave * 32;
+    const bool active = q0 < NQ;  // idle waves (query rows past the end) only stage tiles and keep the barrier count
 
     const bf16* Qb = p.q + (size_t)bh * N * 64;
     const bf16* Kb = p.k + (size_t)bh * N * 64;
@@ -340,17 +335,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
 
     PipeWave<PLANES> w;
     w.hh = hh;
-    auto load_q = [&](int q0w) {
-        int qcol = lane & 31, hh = lane >> 5;
-        asm volatile("" : "+v"(qcol), "+v"(hh));
-        const int qrow = p.q_off + min(q0w + qcol, NQ - 1);
+    {
+        const int qrow = p.q_off + min(q0 + qcol, NQ - 1);
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 w.qf[pl][s] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)pl * p.qk_plane + (size_t)qrow * 64 + s * 16 + hh * 8);
-    };
-    load_q(q0);
+    }
 
     // ---- LDS-DMA bookkeeping: piece = 8 key rows x 128 B; lane l lands at chunk l % 8 of row l / 8 ----
     int st_lds[NP], st_koff[NP], st_voff[NP];  // LDS offset of the piece; byte offset of the lane's 16-byte chunk inside a K / V tile
@@ -400,15 +392,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
             v_addr[db] = (unsigned)(size_t)(lds_void*)(smem + V_BASE + lds_off_v(4 * (g >> 1) + q, db * 4 + (g & 1) * 2 + (pc >> 1)) + (pc & 1) * 8);
     }
 
-    auto reset_acc = [&]() {
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) w.oacc[db][r] = 0.f;
-        w.m_run = -1e30f;
-        w.l_run = 0.f;
-    };
-    reset_acc();
+        for (int r = 0; r < 16; ++r) w.oacc[db][r] = 0.f;
+    w.m_run = -1e30f;
+    w.l_run = 0.f;
 
 #define CWM_TILE_END()                                     \
     do {                                                   \
@@ -417,36 +406,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         __builtin_amdgcn_s_barrier();                      \
         __builtin_amdgcn_sched_barrier(0);                 \
     } while (0)
-// key tile KT of the current query tile: S accumulators SC (this tile) -> SN (next tile).  Ring slots: tile kt of the current query tile sits in
-// slot (kt + pb) & 1 (pb: parity carried over the query tiles of a chain -- the virtual key-tile sequence runs on); this iteration re-fills the
-// K slot of THIS tile (its S is done) with the tile two ahead and the other V slot with the tile one ahead -- past the end of a chained
-// query tile those are key tiles 0 / 1 of the same head again.
+// key tile KT: S accumulators SC (this tile) -> SN (next tile).  Ring slots: tile kt sits in slot kt & 1; this iteration re-fills the K slot of
+// THIS tile (its S is done) with the tile two ahead and the other V slot with the tile one ahead.
 #define CWM_TILE(KIND, SC, SN, KT, CLAMP)                                                                                              \
     do {                                                                                                                               \
         const int kt_ = (KT);                                                                                                          \
-        const int ks_ = (kt_ + pb) & 1;                                                                                                \
-        const bool do_k = (KIND) == TILE_STEADY || (((KIND) == TILE_PENULT || (KIND) == TILE_LAST_NEXT) && cont);                      \
-        const bool do_v = (KIND) != TILE_LAST_END;                                                                                     \
-        int k2_ = (KIND) == TILE_PENULT ? 0 : (KIND) == TILE_LAST_NEXT ? 1 : kt_ + 2;                                                  \
-        int v1_ = (KIND) == TILE_LAST_NEXT ? 0 : kt_ + 1;                                                                              \
-        if ((KIND) != TILE_STEADY) asm volatile("" : "+s"(k2_), "+s"(v1_)); /* (no hoisting of the wrapped tiles' offsets out of the chain loop) */ \
+        const int ks_ = kt_ & 1;                                                                                                       \
         auto dma = [&](int i) {                                                                                                        \
             if (i < NP) {                                                                                                              \
-                if (do_k) stage_k1(k2_, ks_, i, CLAMP);                                                                                \
-            } else if (do_v) {                                                                                                         \
-                stage_v1(v1_, ks_ ^ 1, i - NP, CLAMP);                                                                                 \
+                if ((KIND) == TILE_STEADY) stage_k1(kt_ + 2, ks_, i, CLAMP);                                                           \
+            } else if ((KIND) != TILE_LAST) {                                                                                          \
+                stage_v1(kt_ + 1, ks_ ^ 1, i - NP, CLAMP);                                                                             \
             }                                                                                                                          \
         };                                                                                                                             \
-        auto mid = [&]() { load_q(cont ? q0 + 32 * NW : q0); };                                                                        \
         PROF_T(0);                                                                                                                     \
         if (active) {                                                                                                                  \
             pipe_tile<PLANES, KIND, 2 * NP>(w, SC, SN, smem + (ks_ ^ 1) * SLOT_BYTES, v_addr[0] + ks_ * SLOT_BYTES, v_addr[1] + ks_ * SLOT_BYTES, kt_, N,  \
-                                            (KIND) == TILE_PENULT && half_last, half_last, dma, mid PROF_ARGS);                        \
+                                            (KIND) == TILE_PENULT && half_last, half_last, dma PROF_ARGS);                             \
         } else {                                                                                                                       \
-            if (do_k) stage_k(k2_, ks_);                                                                                               \
-            if (do_v) stage_v(v1_, ks_ ^ 1);                                                                                           \
+            if ((KIND) == TILE_STEADY) stage_k(kt_ + 2, ks_);                                                                          \
+            if ((KIND) != TILE_LAST) stage_v(kt_ + 1, ks_ ^ 1);                                                                        \
         }                                                                                                                              \
-        if ((KIND) != TILE_LAST_END) CWM_TILE_END();                                                                                   \
+        if ((KIND) != TILE_LAST) CWM_TILE_END();                                                                                       \
         PROF_T(3);                                                                                                                     \
     } while (0)
 
@@ -462,12 +443,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
     // the sequence's last key tile is in this workgroup's range and at most half full (pipe_tile: half_next / half_this)
     const bool half_last = nkt == nkt_all && ((N - 1) & 63) < 32;
 
-    // ---- normalise and store O[q][h*64 + d] of the current query tile (or, key-split tail round: leave (O^T unnormalised, running max,
-    // sum) of this key range for attention_combine_kernel) ----
+    // ---- normalise and store O[q][h*64 + d] (or, key-split tail round: leave (O^T unnormalised, running max, sum) of this key range for
+    // attention_combine_kernel) ----
     auto store_out = [&]() {
         const float l_tot = w.l_run + __shfl_xor(w.l_run, 32, 64);
-        int qcol = lane & 31, hh = lane >> 5;
-        asm volatile("" : "+v"(qcol), "+v"(hh));  // (keeps the address arithmetic below out of the chain loop's live ranges)
         const int q = q0 + qcol;
         if (part >= 0) {
             if (q < NQ) {
@@ -508,8 +487,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
         }
     };
 
-    // ---- prologue of the work item: K(kt0), V(kt0), K(kt0 + 1) staged, S(kt0) without interleaving ----
-    int pb = 0;
+    // ---- prologue: K(kt0), V(kt0), K(kt0 + 1) staged, S(kt0) without interleaving ----
     f32x16 sa[2], sb[2];
     stage_k(kt0, kt0 & 1);
     stage_v(kt0, kt0 & 1);
@@ -520,49 +498,36 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
     __builtin_amdgcn_s_barrier();  // K(kt0) is re-staged by the first tile
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- the query tiles of the item; S(first key tile) of the current one is in sa ----
-    // Tile instances: two steady ones (no row clamp: the tiles they stage are never the last one), one clamped single step for the 1 - 2 tiles
-    // between the pair loop and the end (S moved back into sa: 32 v_mov), the second-to-last tile and the two forms of the last one.  (ONE
-    // instance per role: with two -- S in sa after an odd count, in sb after an even one -- hipcc merged the paths through copies of the S and
-    // O accumulators and spilled around them, round 4.)
-    int kt_last = kt0;
-    for (int c = 0;; ++c) {
-        const bool cont = c + 1 < nchain;
-        int kt = kt0;
-        asm volatile("" : "+s"(N), "+s"(nkt));
-        if (kt + 1 < nkt) {
-            for (; kt + 4 < nkt; kt += 2) {
-                CWM_TILE(TILE_STEADY, sa, sb, kt, std::false_type{});
-                CWM_TILE(TILE_STEADY, sb, sa, kt + 1, std::false_type{});
-            }
-            for (; kt + 2 < nkt; ++kt) {
-                CWM_TILE(TILE_STEADY, sa, sb, kt, std::true_type{});
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) sa[kb] = sb[kb];
-            }
-            CWM_TILE(TILE_PENULT, sa, sb, kt, std::true_type{});
+    // ---- key tiles; S of the current one is in sa ----
+    // Tile instances: two steady ones (no row clamp: the tiles they stage are never the last one), one clamped steady tile for the 1 - 2 tiles
+    // between the pair loop and the end, the second-to-last tile and the last one.  ONE instance per role, each with fixed S registers
+    // (steady pairs sa -> sb -> sa, clamped sa -> sb, second-to-last sb -> sa, last sa): with two instances of a role -- S in sa after an odd
+    // count, in sb after an even one -- hipcc merged the paths through copies of the S and O accumulators and spilled around them (round 4).
+    // The parity is fixed up by moving S (32 v_mov) -- never for an odd tile count, which every model shape has (13, 25, 49 ... key tiles).
+    int kt = kt0;
+    const int n_mine = nkt - kt0;
+    if (n_mine >= 3) {
+        for (; kt + 4 < nkt; kt += 2) {
+            CWM_TILE(TILE_STEADY, sa, sb, kt, std::false_type{});
+            CWM_TILE(TILE_STEADY, sb, sa, kt + 1, std::false_type{});
+        }
+        for (;;) {  // 3 or 4 tiles left: one or two clamped steady tiles
+            CWM_TILE(TILE_STEADY, sa, sb, kt, std::true_type{});
             ++kt;
-        } else {
+            if (kt + 2 == nkt) break;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) sb[kb] = sa[kb];
+            for (int kb = 0; kb < 2; ++kb) sa[kb] = sb[kb];
         }
-        if (!cont) {
-            kt_last = kt;
-            break;
-        }
-        CWM_TILE(TILE_LAST_NEXT, sb, sa, kt, std::true_type{});
-        store_out();
-        // next query tile of the chain: its Q fragments are in place (TILE_PENULT), S(0) is in sa, key tiles 0 / 1 are staged or in flight
-        reset_acc();
-        q0 += 32 * NW;
-        active = q0 < NQ;
-        pb ^= nkt & 1;
+    } else if (n_mine == 2) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) sb[kb] = sa[kb];
     }
-    {
-        const bool cont = false;
-        CWM_TILE(TILE_LAST_END, sb, sa, kt_last, std::true_type{});
-        store_out();
+    if (n_mine >= 2) {
+        CWM_TILE(TILE_PENULT, sb, sa, kt, std::true_type{});
+        ++kt;
     }
+    CWM_TILE(TILE_LAST, sa, sb, kt, std::true_type{});
+    store_out();
 #undef CWM_TILE
 #undef CWM_TILE_END
 #ifdef CWM_ATTN_PROF
@@ -631,10 +596,6 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const AttnParams
     if constexpr (PLANES == 2) dst[kLoOffset] = (bf16)(v - (float)hi);
 }
 
-int g_attn_ksplit = 1;
-int g_attn_chain = 0;         // 0: automatic; 1: single query tiles; C >= 2: chains of C query tiles
-int g_attn_chain_heads = -1;  // -1: automatic; else the number of chained heads per XCD
-
 // scratch of the key-split tail round: at most one round of partial workgroups (512 x 128 queries x 68 floats = 17.8 MB), one buffer per
 // (device, stream) -- the batch lanes launch concurrently --, created on first need
 static int ksplit_scratch(hipStream_t stream, float** out) {
@@ -665,7 +626,7 @@ static int launch_pipe(const AttnParams& p_in, hipStream_t stream) {
     p.ks_parts = 0;
     p.ks_scratch = nullptr;
     int extra = 0;
-    if (NW == 4 && g_attn_ksplit) {
+    if (NW == 4 && (p.tune ? p.tune->attn_ksplit : 1)) {
         // a last round that fills at most a quarter of the slots (two workgroups per CU) costs most of a workgroup period for a fraction of a
         // round's work: split its items' keys.  Measured (profiles/r4_microbench_attn_ksplit.log): ViT-L/4 decoder (3136 items = 6 rounds + 64,
         // 8 ranges) 1646 -> 1597 us parity, 766 -> 753 us fast; a last round of 128 items in 4 ranges (ViT-L/4 encoder) gains nothing -- the
@@ -686,25 +647,7 @@ static int launch_pipe(const AttnParams& p_in, hipStream_t stream) {
             }
         }
     }
-    // ---- chained work items (attention_device.h attn_chain_item): only with the XCD-aware mapping, without a key-split tail round, and for
-    // sequences long enough that the wrap-around of the LDS ring never meets a tile still in use (>= 4 key tiles) ----
-    p.chain_len = 0;
-    p.chain_heads = 0;
-    unsigned grid = (unsigned)(n_items + extra);
-    if (NW == 4 && p.ks_parts == 0 && p.remap && nbh % 8 == 0 && (p.n_tok + 63) / 64 >= 4 && g_attn_chain != 1) {
-        const int full = nq / 128, per = nbh / 8;
-        int C = g_attn_chain >= 2 ? g_attn_chain : 0, hc = g_attn_chain_heads;
-        if (C >= 2 && full >= C && hc != 0) {
-            if (hc == -2) {  // only as many chained heads as fill whole rounds of the XCD's workgroup slots (2 per CU)
-                const int nc = full / C, slots_x = 2 * gemm_cu_count() / 8;
-                hc = (per * nc / slots_x) * slots_x / nc;
-            }
-            if (hc < 0 || hc > per) hc = per;
-            p.chain_len = C;
-            p.chain_heads = hc;
-            grid = 8u * (unsigned)attn_chain_items_per_xcd(nqb, nbh, nq, 128, C, hc);
-        }
-    }
+    const unsigned grid = (unsigned)(n_items + extra);
     const size_t smem = (size_t)4 * (64 * 64 * 2) * PLANES;  // 2 K slots + 2 V slots
     if (smem > 48 * 1024)
         if (int rc = cwm_set_max_lds((const void*)attention_pipe_kernel<PLANES, NW>, (int)smem)) return rc;

@@ -29,7 +29,6 @@
 
 namespace cwm {
 
-int g_conj_attn = 1;
 constexpr int kCrossSplit2 = 16;  // wave-sized shares per (batch, head): grid.x = kCrossSplit2 / 4 workgroups of 4 waves
 
 namespace {

@@ -3,6 +3,8 @@
 // (cwm/models/VideoMAE/conjoined_vmae.py:889-1011, 852-887, 1230-1243): two token streams (RGB "main",
 // IMU "context"), null-token padding (:49-165), cross-attention blocks BEFORE encoder blocks 0,3,6,9 and
 // AFTER every decoder block (:543-576, :688-720; cwm/models/transformer.py:253-378, 442-583).
+#include <stddef.h>
+
 #include "engine.h"
 
 using namespace cwm;
@@ -290,7 +292,7 @@ int run_cross(ConjLane& L, const CrossW& C, float* x, int N, int ci, float* src,
     const int rows = B * N, rows_s = B * M;
     int rc;
     // main-stream projections: operand layout (bf16 hi [, lo] planes, the same 4 bytes per element as fp32) for the MFMA kernel
-    const bool mfma = g_conj_attn && cross_attention_mfma_ok(hd, M) && cross_attention_mfma_fits(B, N, heads, hd) && (2 * D) % 32 == 0;
+    const bool mfma = E.tune.conj_attn && cross_attention_mfma_ok(hd, M) && cross_attention_mfma_fits(B, N, heads, hd) && (2 * D) % 32 == 0;
     const bool two = sc != s && mfma;
     if (sc != s && !two) {  // VALU fallback: one chain on s, bracketed by the context stream
         CWM_HIP_CHECK(hipEventRecord(ev[1], sc));
@@ -442,10 +444,6 @@ extern "C" int cwm_conj_load_weight(cwm_conj_model* m, const char* key, const fl
 
 extern "C" int cwm_conj_missing_weights(cwm_conj_model* m, char* buf, int buflen) { return m->eng.missing_weights(buf, buflen); }
 
-namespace cwm {
-int g_conj_ctx_stream = 1;  // "conj_ctx_stream" switch: 0 keeps the context stream's blocks on the lane's own stream
-}  // namespace cwm
-
 // One lane: batch elements [b0, b0 + B) of the call on stream s.
 //
 // The context (IMU) stream is a chain of ~300 tiny launches (25 / 50 tokens per sample: 5-15 us each, latency-bound) that only meets
@@ -474,7 +472,7 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
     const uint8_t* ctx_mask_in = a->ctx_mask_dev + (size_t)b0 * S.n_tok;
     float* y_tokens = a->y_tokens_dev + (size_t)b0 * n_out * A.out_dim;
     int rc;
-    bool side = g_conj_ctx_stream != 0;
+    bool side = E.tune.conj_ctx_stream != 0;  // (0 keeps the context stream's blocks on the lane's own stream)
     for (int k = 0; k < CWM_KCLASS_COUNT; ++k) side = side && !E.timers[k].enabled;
     if (side && !m->ctx_stream[lane]) {
         CWM_HIP_CHECK(hipStreamCreateWithFlags(&m->ctx_stream[lane], hipStreamNonBlocking));
@@ -579,8 +577,15 @@ static int conj_forward_lane(ConjLane& L, const cwm_conj_forward_args* a, int b0
     return launch_zero_pad_out_rows(y_tokens, A.perm, B, Nx, vm, n_out, A.n_tok, A.out_dim, s);
 }
 
-extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* a) {
-    CWM_REQUIRE(m && a, "cwm_conj_forward: null argument");
+extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* a_in) {
+    CWM_REQUIRE(m && a_in, "cwm_conj_forward: null argument");
+    // the caller's struct may end before the fields later versions appended: copy what it has, the rest stays zero (= not requested)
+    CWM_REQUIRE(a_in->struct_size >= offsetof(cwm_conj_forward_args, stream) + sizeof(void*) && a_in->struct_size <= 4096,
+                "cwm_conj_forward: args->struct_size = %u is not a cwm_conj_forward_args (set it to sizeof(cwm_conj_forward_args))", a_in->struct_size);
+    cwm_conj_forward_args a_copy;
+    memset(&a_copy, 0, sizeof(a_copy));
+    memcpy(&a_copy, a_in, std::min<size_t>(a_in->struct_size, sizeof(a_copy)));
+    const cwm_conj_forward_args* a = &a_copy;
     CWM_REQUIRE(a->x_dev && a->mask_dev && a->ctx_dev && a->ctx_mask_dev && a->y_tokens_dev, "cwm_conj_forward: x, mask, context, context mask and y are required");
     CWM_REQUIRE(a->mode == CWM_MODE_FAST || a->mode == CWM_MODE_PARITY, "cwm_conj_forward: bad mode %d", a->mode);
     const int B = a->batch, vm = a->n_vis_max, vc = a->n_vis_ctx_max;
@@ -595,7 +600,7 @@ extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* 
     hipStream_t s = (hipStream_t)a->stream;
 
     // two lanes as in cwm_forward (model.hip): the halves share n_vis_max / n_vis_ctx_max, so the padded layout of every row is unchanged
-    const bool two = m->lanes >= 2 && B >= 2 && (int64_t)(B / 2) * vm >= kMinLaneRowsConj;
+    const bool two = m->lanes >= 2 && B >= 2 && (int64_t)(B / 2) * vm >= (m->eng.tune.min_lane_rows > 0 ? m->eng.tune.min_lane_rows : kMinLaneRowsConj);
     const int B0 = two ? (B + 1) / 2 : B;
     if (two) {
         if (!m->lane_stream) {
@@ -631,6 +636,12 @@ extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* 
             return CWM_ERR_MASK;
         }
     }
+    return CWM_OK;
+}
+
+extern "C" int cwm_conj_set_option(cwm_conj_model* m, const char* key, int value) {
+    CWM_REQUIRE(m && key, "cwm_conj_set_option: null argument");
+    CWM_REQUIRE(tuning_set(m->eng.tune, key, value) == 0, "cwm_conj_set_option: unknown option %s", key);
     return CWM_OK;
 }
 

@@ -85,7 +85,6 @@ int launch_layernorm(const LayerNormParams& p, int planes, hipStream_t stream) {
     CWM_REQUIRE(p.D % 8 == 0 && p.D <= 1024, "layernorm: D=%d must be a multiple of 8 and <= 1024", p.D);
     CWM_REQUIRE(p.ldx % 4 == 0 && p.ldo % 8 == 0, "layernorm: row strides must be multiples of 4 (input) / 8 (output)");
     const int blocks = (p.rows + 3) / 4;
-    if (g_gemm_debug & 8) return 0;  // ablation (cwm_debug_set "gemm_debug" bit 3): what the step would cost without any LayerNorm launch
     if (planes == 1)
         hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, stream, p);
     else
@@ -220,6 +219,121 @@ int launch_patch_gather(const PatchGatherParams& p, int planes, hipStream_t stre
         hipLaunchKernelGGL(patch_gather_kernel<1>, dim3(blocks), dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL(patch_gather_kernel<2>, dim3(blocks), dim3(256), 0, stream, p);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The index prologue of a forward in ONE launch (round 5): mask -> permutation (visible tokens ascending, then masked ascending:
+// vmae.py:167, :555-557), its inverse `rank` (what the un-embed scatter reads, prediction.py:252-259), the per-row check of the visible
+// count (the reference's reshape failure at vmae.py:167) and the patch gather above.  Until round 4 these were four dependent launches
+// (memset of the error word, mask_to_perm, patch_gather, and perm_to_rank before the un-embed) of 4 - 12 us each with the platform's ~6 us
+// between dependent kernels: ~25 us of the 1.86-ms batch-1 forward.  grid = (workgroups per sample, B).  Every workgroup of a sample
+// scans the sample's mask row itself (1.5 - 6 KB from L2, a wave-shuffle prefix sum) into an LDS table {i-th visible token -> token index}
+// and gathers its share of the visible rows from it; workgroup 0 of the sample also writes perm / rank / the row check.  Integer-exact.
+// ---------------------------------------------------------------------------------------------
+template <int PLANES>
+__global__ __launch_bounds__(256) void index_gather_kernel(const PatchGatherParams p, const uint8_t* __restrict__ mask, int n_vis, int* __restrict__ perm_out,
+                                                           int* __restrict__ rank_out, int* __restrict__ err_rows) {
+    extern __shared__ int vis_tab[];  // [n_rows]
+    __shared__ int wave_tot[4];
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int L = p.perm_stride ? p.perm_stride : p.Nt;  // mask row length (padded predictors: real tokens + pad slots)
+    const uint8_t* m = mask + (size_t)b * L;
+    const int per = (L + 255) / 256;
+    const int lo = min(t * per, L), hi = min(lo + per, L);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += (m[i] == 0);
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int before = incl - c;
+    for (int w2 = 0; w2 < wave; ++w2) before += wave_tot[w2];
+    const int total_vis = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    const bool lead = blockIdx.x == 0;
+    int* pr = perm_out + (size_t)b * L;
+    int* rk = rank_out ? rank_out + (size_t)b * L : nullptr;
+    int v = before;
+    for (int i = lo; i < hi; ++i) {
+        if (m[i] == 0) {
+            if (v < p.n_rows) vis_tab[v] = i;
+            if (lead) {
+                pr[v] = i;
+                if (rk) rk[i] = v;
+            }
+            ++v;
+        } else if (lead) {
+            const int pos = total_vis + (i - v);
+            pr[pos] = i;
+            if (rk) rk[i] = pos;
+        }
+    }
+    if (lead && t == 0) err_rows[b] = total_vis != n_vis ? 1 : 0;
+    __syncthreads();
+
+    const int per_row = p.C * p.P;
+    const int total = p.n_rows * per_row;
+    const int gw = p.W / p.P;
+    const int n = (p.H / p.P) * gw;
+    for (int gid = blockIdx.x * 256 + t; gid < total; gid += gridDim.x * 256) {
+        const int i = gid / per_row;
+        const int rem = gid - i * per_row;
+        const int ch = rem / p.P, ph = rem - ch * p.P;
+        const int tau = i < total_vis ? vis_tab[i] : p.Nt;  // (a row with too few visible tokens is reported through err_rows: its missing rows read nothing)
+        const bool pad_slot = tau >= p.Nt;                  // null-token pad slot of a padded predictor: no pixels behind it
+        const int tt = pad_slot ? 0 : tau;
+        const int tf = tt / n, hw = tt - tf * n;
+        const int hy = hw / gw, wx = hw - hy * gw;
+        const float* src = p.x + b * p.sb + ch * p.sc + tf * p.st + (int64_t)(hy * p.P + ph) * p.W + wx * p.P;
+        const float mean = (ch == 0) ? 0.485f : (ch == 1) ? 0.456f : 0.406f;
+        const float stdv = (ch == 0) ? 0.229f : (ch == 1) ? 0.224f : 0.225f;
+        const int kbase = ch * p.P * p.P + ph * p.P;
+        const int64_t row = (int64_t)b * p.n_rows + i;
+        for (int pw = 0; pw < p.P; pw += 4) {
+            const float4 q = pad_slot ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(src + pw);
+            float f[4] = {q.x, q.y, q.z, q.w};
+            bf16x4 hv, lv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = f[e];
+                if (p.normalize && !pad_slot) a = (a - mean) / stdv;
+                bf16 hi2, lo2;
+                split_bf16(a, hi2, lo2);
+                hv[e] = hi2;
+                lv[e] = lo2;
+            }
+            bf16* dst = p.out + a_pos<PLANES>(row, p.ld, kbase + pw);
+            *reinterpret_cast<bf16x4*>(dst) = hv;
+            if constexpr (PLANES == 2) *reinterpret_cast<bf16x4*>(dst + kLoOffset) = lv;
+        }
+        if (rem == 0) {  // zero the K padding (K = C*P*P rounded up to ld) once per row
+            const int K = p.C * p.P * p.P;
+            for (int k = K; k < p.ld; ++k) {
+                bf16* z = p.out + a_pos<PLANES>(row, p.ld, k);
+                *z = (bf16)0.f;
+                if constexpr (PLANES == 2) z[kLoOffset] = (bf16)0.f;
+            }
+        }
+    }
+}
+
+int launch_index_gather(const PatchGatherParams& p, const uint8_t* mask, int n_vis, int* perm, int* rank, int* err_rows, int planes, hipStream_t stream) {
+    CWM_REQUIRE(p.P % 4 == 0 && p.W % 4 == 0, "index_gather: patch size and width must be multiples of 4");
+    CWM_REQUIRE(p.C == 3 || !p.normalize, "index_gather: imagenet normalisation needs 3 channels");
+    CWM_REQUIRE(p.ld >= p.C * p.P * p.P && p.ld % 4 == 0, "index_gather: bad ld");
+    CWM_REQUIRE(mask && perm && err_rows && p.n_rows > 0 && p.n_rows <= 12000, "index_gather: bad argument (rows per sample: %d)", p.n_rows);
+    const int per_sample = (p.n_rows * p.C * p.P + 255) / 256;
+    const dim3 grid((unsigned)per_sample, (unsigned)p.B);
+    const size_t smem = (size_t)p.n_rows * sizeof(int);
+    if (planes == 1)
+        hipLaunchKernelGGL(index_gather_kernel<1>, grid, dim3(256), smem, stream, p, mask, n_vis, perm, rank, err_rows);
+    else
+        hipLaunchKernelGGL(index_gather_kernel<2>, grid, dim3(256), smem, stream, p, mask, n_vis, perm, rank, err_rows);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }

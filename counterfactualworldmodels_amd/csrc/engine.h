@@ -66,8 +66,7 @@ struct StreamBuffers {
 // Encoder rows (batch elements x visible tokens) each half of a batch must keep for the forward to run as two batch lanes (cwm_forward,
 // cwm_conj_forward).  Measured (tools/lane_threshold.py, round 4): ViT-B/8 batch 8 / 10 / 14 (3168 / 3960 / 5544 rows per half) -6 / -7.5 / -10 % with
 // two lanes, batch 6 (2376) +3 %; ViT-L/4 batch 2 (3168) -7 %.  (Rounds 1-3 used 6000: batch >= 16.)
-constexpr int kMinLaneRows = 3000;
-extern int g_min_lane_rows;  // = kMinLaneRows; cwm_debug_set "min_lane_rows" moves it (tools/lane_threshold.py)
+constexpr int kMinLaneRows = 3000;  // (Tuning.min_lane_rows overrides it per model: tools/lane_threshold.py)
 // The IMU-conditioned model (its lanes carry a context stream each: four queues): batch 2 / 3 / 4 / 6 are 5.3 / 4.3 / 2.5 / 2.8 % SLOWER on two lanes,
 // batch 8 / 12 / 16 2.3 / 1.4 / 1.0 % faster (3172 visible rows per sample; rounds 1-3 split from batch 4)
 constexpr int kMinLaneRowsConj = 12000;
@@ -75,6 +74,7 @@ constexpr int kMinLaneRowsConj = 12000;
 struct Engine {
     int device = 0;
     int overlapped = 0;  // 1 while a forward call runs two batch lanes (passed to the GEMM kernel choice)
+    Tuning tune = thread_tuning();  // this model's execution options (cwm_model_set_option); every launch of the model carries a pointer to it
     float ln_eps = 1e-6f;
     std::map<std::string, Slot> slots;
     std::vector<void*> allocs;     // weights etc., freed on destroy
@@ -83,7 +83,9 @@ struct Engine {
     struct SplitKWs {
         float* slabs;
         unsigned* counts;
+        uint64_t last_use;  // launch counter at the last split launch on the stream: the eviction order
     };
+    uint64_t splitk_clock = 0;
     static constexpr size_t kMaxSplitKStreams = 8;
     std::map<hipStream_t, SplitKWs> splitk_ws;  // one split-K workspace per stream that has launched a split GEMM (batch lanes run concurrently); created lazily, capped
 
@@ -115,6 +117,7 @@ struct Engine {
     // the HBM-bound edge kernels, booked by class with their algorithmic bytes (cwm_hip.h CWM_KCLASS_*)
     int run_layernorm(const LayerNormParams& p, int planes, hipStream_t s);
     int run_patch_gather(const PatchGatherParams& p, int planes, hipStream_t s);
+    int run_index_gather(const PatchGatherParams& p, const uint8_t* mask, int n_vis, int* perm, int* rank, int* err_rows, int planes, hipStream_t s);
     int run_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt, int n_vis, int D, hipStream_t s);
     int run_unembed(const UnembedParams& p, hipStream_t s);
     // `launch()` between an event pair of class `kclass` (no events unless the class is enabled); work = FLOPs or bytes

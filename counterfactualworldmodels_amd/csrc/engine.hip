@@ -32,7 +32,7 @@ int cwm_set_max_lds(const void* kernel, int bytes) {
     done.insert({dev, kernel});
     return 0;
 }
-extern "C" const char* cwm_version(void) { return "cwm_hip 0.5.0 gfx950"; }
+extern "C" const char* cwm_version(void) { return "cwm_hip 0.6.0 gfx950"; }
 #ifndef CWM_SRC_HASH
 #define CWM_SRC_HASH "unknown"
 #endif
@@ -43,6 +43,29 @@ extern "C" const char* cwm_source_hash(void) { return CWM_SRC_HASH; }
 extern "C" const char* cwm_compiler_version(void) { return CWM_HIPCC_VERSION; }
 
 namespace cwm {
+
+// ---- execution options -------------------------------------------------------------------------
+const Tuning& default_tuning() {
+    static const Tuning t;
+    return t;
+}
+Tuning& thread_tuning() {
+    static thread_local Tuning t;
+    return t;
+}
+int tuning_set(Tuning& t, const char* key, int value) {
+    struct Field { const char* name; int Tuning::*member; };
+    static const Field fields[] = {{"gemm_tile", &Tuning::gemm_tile}, {"gemm_debug", &Tuning::gemm_debug}, {"gemm_staged", &Tuning::gemm_staged},
+                                   {"gemm_direct", &Tuning::gemm_direct}, {"attn_kernel", &Tuning::attn_kernel}, {"attn_remap", &Tuning::attn_remap},
+                                   {"attn_tail", &Tuning::attn_tail}, {"attn_ksplit", &Tuning::attn_ksplit}, {"prune_last_block", &Tuning::prune_last_block}, {"index_fused", &Tuning::index_fused},
+                                   {"min_lane_rows", &Tuning::min_lane_rows}, {"conj_ctx_stream", &Tuning::conj_ctx_stream}, {"conj_attn", &Tuning::conj_attn}};
+    for (const Field& f : fields)
+        if (!strcmp(key, f.name)) {
+            t.*(f.member) = value;
+            return 0;
+        }
+    return -1;
+}
 
 __global__ void pack_weight_kernel(const float* src, int N, int K, bf16* hi, bf16* il, int Npad, int Kpad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,6 +308,7 @@ int Engine::timer_end(EventPair* e, hipStream_t s) {
 int Engine::run_gemm(const GemmParams& p_in, int planes, hipStream_t s) {
     GemmParams p = p_in;
     p.overlapped = overlapped;
+    p.tune = &tune;
     const int cfg = gemm_choose_tile(p, planes);
     {   // a launch (or the 128x128 remainder of a mixed-tiling launch: fc2 of a single-lane batch) that takes the deep-ring kernel's split-K
         // path carries this stream's workspace, created on first need (32 MB + counters; at most kMaxSplitKStreams per engine: a caller
@@ -296,17 +320,22 @@ int Engine::run_gemm(const GemmParams& p_in, int planes, hipStream_t s) {
             auto it = splitk_ws.find(s);
             if (it == splitk_ws.end()) {
                 if (splitk_ws.size() >= kMaxSplitKStreams) {
-                    // (the evicted stream may still have a launch in flight that reads its workspace: let it finish first)
+                    // evict the workspace of the stream that used one longest ago.  (hipFree waits for the device, so a launch of that stream
+                    // that still reads it finishes first; the stream itself may be gone -- a caller that rotates streams has usually destroyed
+                    // it --, so it is not touched.)  The entry leaves the table before anything here can fail.
                     auto victim = splitk_ws.begin();
-                    CWM_HIP_CHECK(hipStreamSynchronize(victim->first));
-                    (void)hipFree(victim->second.slabs);
-                    (void)hipFree(victim->second.counts);
+                    for (auto w = splitk_ws.begin(); w != splitk_ws.end(); ++w)
+                        if (w->second.last_use < victim->second.last_use) victim = w;
+                    const SplitKWs old = victim->second;
                     splitk_ws.erase(victim);
+                    (void)hipFree(old.slabs);
+                    (void)hipFree(old.counts);
                 }
-                SplitKWs w = {nullptr, nullptr};
+                SplitKWs w = {nullptr, nullptr, 0};
                 if (int rc = splitk_workspace_alloc(&w.slabs, &w.counts, s)) return rc;
                 it = splitk_ws.emplace(s, w).first;
             }
+            it->second.last_use = ++splitk_clock;
             p.sk2_slabs = it->second.slabs;
             p.sk2_count = it->second.counts;
         }
@@ -330,7 +359,9 @@ int Engine::run_gemm(const GemmParams& p_in, int planes, hipStream_t s) {
     return 0;
 }
 
-int Engine::run_attention(const AttnParams& p, int planes, hipStream_t s) {
+int Engine::run_attention(const AttnParams& p_in, int planes, hipStream_t s) {
+    AttnParams p = p_in;
+    p.tune = &tune;
     EventPair* e;
     const double fl = 4.0 * (double)p.n_tok * p.n_tok * 64.0 * p.heads * p.batch;
     if (int rc = timer_begin(CWM_KCLASS_ATTENTION, fl, s, &e)) return rc;
@@ -339,11 +370,19 @@ int Engine::run_attention(const AttnParams& p, int planes, hipStream_t s) {
 }
 
 int Engine::run_layernorm(const LayerNormParams& p, int planes, hipStream_t s) {
+    if (tune.gemm_debug & 8) return 0;  // ablation ("gemm_debug" bit 3): what the step would cost without any LayerNorm launch (timing only)
     return timed(CWM_KCLASS_LAYERNORM, (double)p.rows * p.D * (4.0 + 2.0 * planes), s, [&] { return launch_layernorm(p, planes, s); });
 }
 
 int Engine::run_patch_gather(const PatchGatherParams& p, int planes, hipStream_t s) {
     return timed(CWM_KCLASS_PATCH_GATHER, (double)p.B * p.n_rows * p.C * p.P * p.P * (4.0 + 2.0 * planes), s, [&] { return launch_patch_gather(p, planes, s); });
+}
+
+int Engine::run_index_gather(const PatchGatherParams& p, const uint8_t* mask, int n_vis, int* perm, int* rank, int* err_rows, int planes, hipStream_t s) {
+    // booked with the patch gather's class and bytes (+ the mask row in, the permutation and its inverse out)
+    const int L = p.perm_stride ? p.perm_stride : p.Nt;
+    return timed(CWM_KCLASS_PATCH_GATHER, (double)p.B * p.n_rows * p.C * p.P * p.P * (4.0 + 2.0 * planes) + (double)p.B * L * (1.0 + 4.0 + (rank ? 4.0 : 0.0)), s,
+                 [&] { return launch_index_gather(p, mask, n_vis, perm, rank, err_rows, planes, s); });
 }
 
 int Engine::run_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt, int n_vis, int D,
@@ -483,7 +522,7 @@ int Engine::run_block_small(const BlockW& w, float* x, int B, int n_tok, int D, 
     a.qkv = sb.qkv_f32; a.B = B; a.n_tok = n_tok; a.heads = H; a.head_dim = D / H;
     a.o = sb.hbuf; a.o_plane = hplane; a.ldo = D;
     if ((rc = timed(CWM_KCLASS_SMALL_ATTN, 4.0 * (double)B * H * n_tok * n_tok * (D / H), s, [&] {
-             return (g_conj_attn && small_attention_mfma_ok(n_tok, D / H) && D % 32 == 0) ? launch_small_attention_mfma(a, planes, s) : launch_small_attention(a, planes, s);
+             return (tune.conj_attn && small_attention_mfma_ok(n_tok, D / H) && D % 32 == 0) ? launch_small_attention_mfma(a, planes, s) : launch_small_attention(a, planes, s);
          })))
         return rc;
 

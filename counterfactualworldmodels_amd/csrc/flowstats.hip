@@ -12,6 +12,7 @@
 // fp32 matrix pipe above; it runs on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate) with the operands swapped
 // so that a lane owns 4 consecutive columns of one output row (16-byte stores).  Sharding: rows [row0, row0 + nrows) per
 // call, so that ranks which all-gather the small feature matrix each produce a row slab (dist.py).
+#include "../../include/cwm_hip.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
 
 // argsort of every row over its S samples, as floats (`torch.argsort(flow_inp[b], -1).float()`, :521): out[rank of element j] = j.
 // One wave per row; rank = #(smaller) + #(equal with a lower index): the stable order (torch's default sort is not stable, so rows
-// with exactly tied values are the one place where the reference's own output is implementation-defined).
+// with exactly tied values are the one place where the reference's own output is implementation-defined).  NaNs order LAST and equal to each
+// other, as torch.sort places them: the result is a permutation of 0 .. S-1 for every input.
 __global__ __launch_bounds__(256) void flow_argsort_rows_kernel(float* __restrict__ x, int rows, int S) {
     extern __shared__ float srow[];  // [4 waves][S]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -162,7 +164,9 @@ __global__ __launch_bounds__(256) void flow_argsort_rows_kernel(float* __restric
         int rank = 0;
         for (int k = 0; k < S; ++k) {
             const float u = mine[k];
-            rank += (u < v || (u == v && k < j)) ? 1 : 0;
+            const bool less = u < v || (v != v && u == u);
+            const bool same = u == v || (u != u && v != v);
+            rank += (less || (same && k < j)) ? 1 : 0;
         }
         x[(size_t)row * S + rank] = (float)j;
     }
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void flow_colstats_kernel(const float* __restr
     const bool in = s < S;
     const float* xb = x + (size_t)b * P * S + (in ? s : 0);
     float mn = INFINITY, mx = -INFINITY;
-    double sum = 0.0;
+    double sum = 0.0;  // (a NaN in the column makes the sum, and with it min / max / mean / std, NaN: torch.amin / amax / mean / std propagate it)
     if (in)
         for (int p = rg; p < P; p += 4) {
             const float v = xb[(size_t)p * S];
@@ -201,9 +205,11 @@ __global__ __launch_bounds__(256) void flow_colstats_kernel(const float* __restr
     rs[rg][c] = sq;
     __syncthreads();
     if (rg == 0 && in) {
-        const double var = (rs[0][c] + rs[1][c] + rs[2][c] + rs[3][c]) / (double)(P - 1);
-        st[(size_t)b * S + s] = make_float4(fminf(fminf(rmn[0][c], rmn[1][c]), fminf(rmn[2][c], rmn[3][c])),
-                                            fmaxf(fmaxf(rmx[0][c], rmx[1][c]), fmaxf(rmx[2][c], rmx[3][c])), (float)mean, (float)sqrt(var));
+        const double var = (rs[0][c] + rs[1][c] + rs[2][c] + rs[3][c]) / (double)(P - 1);  // P == 1: 0 / 0 = NaN, as torch.std
+        const bool has_nan = mean != mean;
+        const float qn = __builtin_nanf("");
+        st[(size_t)b * S + s] = make_float4(has_nan ? qn : fminf(fminf(rmn[0][c], rmn[1][c]), fminf(rmn[2][c], rmn[3][c])),
+                                            has_nan ? qn : fmaxf(fmaxf(rmx[0][c], rmx[1][c]), fmaxf(rmx[2][c], rmx[3][c])), (float)mean, (float)sqrt(var));
     }
 }
 
@@ -218,8 +224,8 @@ __global__ void flow_apply_kernel(float* __restrict__ x, int64_t total, int P, i
     if (op == 1) o = v * ((v > a) ? 1.0f : 0.0f);
     else if (op == 2) o = (v > a) ? 1.0f : 0.0f;
     else if (op == 3) o = ((v - c.x) > a * (c.y - c.x)) ? 1.0f : 0.0f;
-    else if (op == 4) o = v / fmaxf(c.y, eps);
-    else o = (v - c.z) / fmaxf(c.w, eps);
+    else if (op == 4) o = v / (c.y != c.y ? c.y : fmaxf(c.y, eps));   // tensor.clamp(min=eps) keeps a NaN
+    else o = (v - c.z) / (c.w != c.w ? c.w : fmaxf(c.w, eps));
     x[i] = o;
 }
 
@@ -342,7 +348,6 @@ extern "C" int cwm_flow_transform(float* x_dev, int B, int P, int S, int spearma
     CWM_REQUIRE(thresh_mode >= 0 && thresh_mode <= 3, "cwm_flow_transform: thresh_mode must be 0 (none), 1 (x * (x > t)), 2 (x > t) or 3 (range threshold)");
     CWM_REQUIRE(!(thresh_mode == 3 || normalize || zscore) || stats_work_dev, "cwm_flow_transform: the column statistics need the [B][S][4] work buffer");
     CWM_REQUIRE(!spearman || S <= 4096, "cwm_flow_transform: Spearman ranks support at most 4096 samples (S=%d)", S);
-    CWM_REQUIRE(!zscore || P > 1, "cwm_flow_transform: z-scores need more than one position");
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = (int64_t)B * P * S;
     const unsigned eblocks = (unsigned)((total + 255) / 256);

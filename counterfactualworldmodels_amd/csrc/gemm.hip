@@ -550,13 +550,15 @@ int splitk_workspace_alloc(float** slabs, unsigned** counts, hipStream_t stream)
 // Tile height of the deep-ring kernel for a launch with at most one 128x128 tile per CU: 64 rows when the 128-row grid would leave half of the
 // CUs idle (batch 1: 792 rows = 7 row tiles, the last one 24 rows; qkv 126 tiles on 256 CUs -> 13 x 18 = 234 tiles of half the work each).
 // "gemm_debug" bit 8 keeps 128.
+static inline const Tuning& tn(const GemmParams& p) { return p.tune ? *p.tune : default_tuning(); }
+
 static int deep_tile_rows(const GemmParams& p) {
     const int tiles128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-    return (tiles128 * 2 <= gemm_cu_count() && p.M > 64 && !(g_gemm_debug & 256)) ? 64 : 128;
+    return (tiles128 * 2 <= gemm_cu_count() && p.M > 64 && !(tn(p).gemm_debug & 256)) ? 64 : 128;
 }
 
 int gemm_splitk_parts(const GemmParams& p, int planes) {
-    if (g_gemm_debug & (4 | 32)) return 1;
+    if (tn(p).gemm_debug & (4 | 32)) return 1;
     const int tiles128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
     const int cus = gemm_cu_count();
     if (tiles128 > cus) return 1;
@@ -579,12 +581,7 @@ int gemm_cu_count() {
     return cus;
 }
 
-int g_gemm_tile = 0;  // 0 = automatic choice per shape
 static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t stream);
-int g_gemm_debug = 0;
-int g_gemm_staged = 1;  // 0: force the per-fragment epilogue of round 1
-int g_gemm_direct = 1;  // 1 (default): bf16-output epilogues (qkv, fc1, the cross-attention projections) store straight from the accumulators with the W tile
-                        // staged in permuted row order (gemm_device.h epilogue_direct); 2: the fp32-output epilogues too (measured slower); 0: LDS-staged everywhere
 
 // Mixed tiling (tile configuration 6): the leading rows that fill whole rounds of 256x256 tiles go to the 8-phase kernel, the
 // remaining rows to 128x128 tiles.  Both kernels apply the same product sequence to every accumulator, so the result does not
@@ -611,41 +608,13 @@ int launch_gemm_tile(const GemmParams& p_in, int planes, int cfg, hipStream_t st
 
 int launch_gemm(const GemmParams& p_in, int planes, hipStream_t stream) { return launch_gemm_checked(p_in, planes, 0, stream); }
 
-// Per-shape overrides of the tile choice (cwm_gemm_tile_override: the tuning hook behind tools/autotune_step.py).  All configurations
-// give bit-identical results (tests/test_kernels_gpu.py), so an override can only change the speed.
-namespace {
-struct TileKey {
-    int M, N, K, epi, ovl;
-    bool operator<(const TileKey& o) const { return std::tie(M, N, K, epi, ovl) < std::tie(o.M, o.N, o.K, o.epi, o.ovl); }
-};
-std::mutex g_tile_mu;
-std::map<TileKey, int> g_tile_overrides;
-std::atomic<int> g_tile_override_count{0};
-}  // namespace
-
-int gemm_tile_override(int M, int N, int K, int epi, int overlapped, int cfg) {
-    std::lock_guard<std::mutex> lock(g_tile_mu);
-    if (M <= 0) {
-        g_tile_overrides.clear();
-    } else if (cfg == 0) {
-        g_tile_overrides.erase(TileKey{M, N, K, epi, overlapped ? 1 : 0});
-    } else {
-        CWM_REQUIRE(cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 6, "gemm_tile_override: unknown tile configuration %d", cfg);
-        g_tile_overrides[TileKey{M, N, K, epi, overlapped ? 1 : 0}] = cfg;
-    }
-    g_tile_override_count.store((int)g_tile_overrides.size());
-    return 0;
-}
-
-// Tile configuration for a launch: g_gemm_tile (development switch) if set, else a per-shape override, else the measured rule.
+// Tile configuration for a launch: Tuning.gemm_tile (development switch) if set, else the development library's per-shape hook, else the measured rule.
 int gemm_choose_tile(const GemmParams& p, int planes) {
     (void)planes;
-    int cfg = g_gemm_tile;
-    if (cfg == 0 && g_tile_override_count.load(std::memory_order_relaxed) > 0) {
-        std::lock_guard<std::mutex> lock(g_tile_mu);
-        auto it = g_tile_overrides.find(TileKey{p.M, p.N, p.K, p.epi, p.overlapped ? 1 : 0});
-        if (it != g_tile_overrides.end()) cfg = it->second;
-    }  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase, 6: 4 + 1 by rows
+    const Tuning& t = tn(p);
+    int cfg = t.gemm_tile;
+    if (cfg == 0 && t.tile_hook) cfg = t.tile_hook(p.M, p.N, p.K, p.epi, p.overlapped ? 1 : 0);
+    // 0 auto, 1: 128x128, 4: 256x256 8-phase, 6: 4 + 1 by rows
     if (cfg == 0) {
         // Measured on MI355X (tools/microbench.py gemm / gemm_mid / gemm_l4: B/8 at batch 8, 16, 32 and L/4 batch 8, both modes;
         // profiles/r1n_*, r1o_*, r1p_* logs).  The 256x256 8-phase kernel has the fastest main loop (~1.6 PFLOP/s of executed MFMA
@@ -662,7 +631,7 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
         //    the direct epilogue the 8-phase kernel wins there too (decoder qkv 149 -> 140 us, fc1 214 -> 191 us, profiles/r4_ab_gemm_direct.log)
         cfg = 1;
         const bool bf16_out = p.epi != EPI_F32;
-        if (p.K >= ((bf16_out && !(g_gemm_debug & 512)) ? 256 : 512) && p.M >= 512 && (p.N >= 1024 || (p.N >= 512 && p.N % 256 == 0))) {
+        if (p.K >= ((bf16_out && !(t.gemm_debug & 512)) ? 256 : 512) && p.M >= 512 && (p.N >= 1024 || (p.N >= 512 && p.N % 256 == 0))) {
             const int64_t tiles = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
             const int cus = gemm_cu_count();
             if (tiles < cus) {
@@ -672,7 +641,7 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
                 // 75 and 93 tiles (batch 16, 20) measure equal or worse, 57 and 39 lose)
                 const bool long_or_direct = bf16_out || p.K >= 1024;
                 cfg = (tiles * 2 >= cus || (p.overlapped && long_or_direct && tiles * 5 >= cus * 2)) ? 4 : 1;
-            } else if (p.overlapped && !(g_gemm_debug & 128)) {
+            } else if (p.overlapped && !(t.gemm_debug & 128)) {
                 // two batch lanes: the other lane's kernels take the CUs a partly filled last round leaves idle, so the kernel with the
                 // fastest main loop wins regardless of the fill (B/8 batch 32 as 2 x 16: +2 % over the single-lane rule below)
                 cfg = 4;
@@ -695,7 +664,8 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
 
 static int launch_gemm_checked(const GemmParams& p_in, int planes, int forced_cfg, hipStream_t stream) {
     GemmParams p = p_in;
-    p.debug = g_gemm_debug;
+    const Tuning& t = tn(p);
+    p.debug = t.gemm_debug;
     CWM_REQUIRE(planes == 1 || planes == 2, "gemm: planes must be 1 or 2");
     CWM_REQUIRE(p.K % 64 == 0, "gemm: K=%d must be a multiple of 64", p.K);
     CWM_REQUIRE(p.lda % 8 == 0, "gemm: lda=%d must be a multiple of 8", p.lda);
@@ -712,7 +682,7 @@ static int launch_gemm_checked(const GemmParams& p_in, int planes, int forced_cf
     }
     // ---- LDS-staged epilogue whenever its 16-byte row segments are aligned (always, for the predictor's widths) ----
     p.staged = 0;
-    if (g_gemm_staged) {
+    if (t.gemm_staged) {
         if (p.epi == EPI_F32) p.staged = 1;
         else if (p.epi == EPI_QKV) p.staged = (p.qkv_dim % 32 == 0 && p.head_dim % 32 == 0);
         else p.staged = (p.ldo % 8 == 0);
@@ -722,7 +692,7 @@ static int launch_gemm_checked(const GemmParams& p_in, int planes, int forced_cf
     CWM_REQUIRE((int64_t)(p.m_offset + p.M) * p.lda * planes < (1ll << 32) && (int64_t)(((p.N + 255) / 256) * 256) * p.K * planes < (1ll << 32),
                 "gemm: operand too large for 32-bit element offsets (M=%d lda=%d N=%d K=%d planes=%d): split the batch", p.m_offset + p.M, p.lda,
                 p.N, p.K, planes);
-    p.direct = (g_gemm_direct && p.staged && (p.epi != EPI_F32 || g_gemm_direct >= 2)) ? 1 : 0;
+    p.direct = (t.gemm_direct && p.staged && (p.epi != EPI_F32 || t.gemm_direct >= 2)) ? 1 : 0;
     int cfg = forced_cfg > 0 ? forced_cfg : gemm_choose_tile(p, planes);
     if (cfg == 6) {
         GemmParams a, b;
@@ -737,7 +707,8 @@ static int launch_gemm_checked(const GemmParams& p_in, int planes, int forced_cf
 
 static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t stream) {
     typedef void (*kern_t)(const GemmParams);
-    CWM_REQUIRE(cfg >= 1 && cfg <= 4, "gemm: unknown tile configuration %d", cfg);
+    CWM_REQUIRE(cfg == 1 || cfg == 4, "gemm: unknown tile configuration %d (1: 128x128, 4: 256x256 8-phase)", cfg);
+    const int dbg = tn(p).gemm_debug;
     if (cfg == 4) {
         static const kern_t k8[2] = {gemm8p_kernel<1>, gemm8p_kernel<2>};
         const size_t smem8 = 2 * 4 * 128 * 128;
@@ -748,15 +719,13 @@ static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t strea
         CWM_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    static const kern_t deep128[2] = {gemm_bf16_kernel<1, 128, 128, 2, 2, 4>, gemm_bf16_kernel<2, 128, 128, 2, 2, 4>};
-    static const kern_t deep128w8[2] = {gemm_bf16_kernel<1, 128, 128, 2, 4, 4>, gemm_bf16_kernel<2, 128, 128, 2, 4, 4>};  // 8 waves of 64x32
     // 128x128 tiles, at most one workgroup per CU (fewer tiles than CUs): the 4-stage ring hides the staging latency that the second
     // co-resident workgroup hides in bigger launches ("gemm_debug" bit 2 switches it off for A/B runs)
     const int tiles128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
     const int cus = gemm_cu_count();
-    const bool deep = cfg == 1 && !(g_gemm_debug & 4) && tiles128 <= cus;
+    const bool deep = !(dbg & 4) && tiles128 <= cus;
     p.splitk = 1;
-    if (deep && !(g_gemm_debug & 32)) {
+    if (deep && !(dbg & 32)) {
         // fill the idle CUs of a latency-bound launch by cutting K: only where it pays (measured, ViT-B/8 batch 1: fc2 65 -> 32 us with
         // 6 parts, decoder fc2 36 -> 26 us; two parts of a K = 768 qkv projection LOSE 6 us to the hand-off) -- at least three parts of at
         // least 12 K tiles each; the parts of a tile are reduced in a fixed order (deterministic)
@@ -784,41 +753,30 @@ static int launch_gemm_cfg(GemmParams& p, int planes, int cfg, hipStream_t strea
         }
     }
     if (deep) {
-        static const kern_t deep64[2] = {gemm_bf16_kernel<1, 64, 128, 1, 4, 4>, gemm_bf16_kernel<2, 64, 128, 1, 4, 4>};  // 4 waves of 64x32
+        // 8 waves of 64x32 (two per SIMD cover each other's LDS / barrier latency; the 4-wave form measured slower and was removed in round 5), or
+        // 64x128 tiles as 4 waves of 64x32 where the 128-row grid would leave half of the CUs idle
+        static const kern_t deep128w8[2] = {gemm_bf16_kernel<1, 128, 128, 2, 4, 4>, gemm_bf16_kernel<2, 128, 128, 2, 4, 4>};
+        static const kern_t deep64[2] = {gemm_bf16_kernel<1, 64, 128, 1, 4, 4>, gemm_bf16_kernel<2, 64, 128, 1, 4, 4>};
         const int bm = deep_tile_rows(p);
         const size_t smem = (size_t)4 * (bm + 128) * 128;
-        const bool w8 = !(g_gemm_debug & 16);  // 8 waves of 64x32 (two per SIMD cover each other's LDS / barrier latency); bit 4: 4 waves
-        kern_t k = bm == 64 ? deep64[planes - 1] : w8 ? deep128w8[planes - 1] : deep128[planes - 1];
+        kern_t k = bm == 64 ? deep64[planes - 1] : deep128w8[planes - 1];
         const int tiles = ((p.M + bm - 1) / bm) * ((p.N + 127) / 128);
         if (int rc = cwm_set_max_lds((const void*)k, (int)smem)) return rc;
-        hipLaunchKernelGGL(k, dim3(tiles * p.splitk), dim3(bm == 64 ? 256 : w8 ? 512 : 256), smem, stream, p);
+        hipLaunchKernelGGL(k, dim3(tiles * p.splitk), dim3(bm == 64 ? 256 : 512), smem, stream, p);
         CWM_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    // cfg 1 = 128x128 tiles as 8-wave workgroups (64x32 per wave), two per CU = FOUR waves per SIMD: measured 5-25 % faster than the
-    // 4-wave form (two waves per SIMD) on every model shape -- the extra waves cover the per-K-tile barrier + LDS-DMA latency that the
-    // simple loop exposes ("gemm_debug" bit 6 selects the 4-wave form for A/B runs)
-    static const kern_t kerns[3][2] = {
-        {gemm_bf16_kernel<1, 128, 128, 2, 4>, gemm_bf16_kernel<2, 128, 128, 2, 4>},
-        {gemm_bf16_kernel<1, 256, 128, 4, 2>, gemm_bf16_kernel<2, 256, 128, 4, 2>},
-        {gemm_bf16_kernel<1, 256, 256, 2, 4>, gemm_bf16_kernel<2, 256, 256, 2, 4>},
-    };
-    static const kern_t narrow4[2] = {gemm_bf16_kernel<1, 128, 128, 2, 2>, gemm_bf16_kernel<2, 128, 128, 2, 2>};
-    static const int bms[3] = {128, 256, 256}, bns[3] = {128, 128, 256};
-    int threads[3] = {512, 512, 512};
-    const int ci = cfg - 1;
-    // (8-wave 128x128 workgroups: the epilogue's eight 8-KiB wave buffers fill the 64-KiB operand ring; the row table sits behind them)
-    const size_t smem = (size_t)2 * (bms[ci] + bns[ci]) * 128 + (ci == 0 ? 4096 : 0);
-    const int tiles = ((p.M + bms[ci] - 1) / bms[ci]) * ((p.N + bns[ci] - 1) / bns[ci]);
-    kern_t k = kerns[ci][planes - 1];
-    if (ci == 0 && (g_gemm_debug & 64)) {
-        k = narrow4[planes - 1];
-        threads[0] = 256;
-    }
-    CWM_REQUIRE(smem >= (size_t)(threads[ci] / 64) * 8192 + (size_t)bms[ci] * 16 + (size_t)bns[ci] * 8,
-                "gemm: dynamic LDS too small for the staged epilogue (wave buffers + row table)");
+    // 128x128 tiles as 8-wave workgroups (64x32 per wave), two per CU = FOUR waves per SIMD: measured 5-25 % faster than the 4-wave form (two
+    // waves per SIMD) on every model shape -- the extra waves cover the per-K-tile barrier + LDS-DMA latency that the simple loop exposes.
+    // (Rounds 1-4 also carried 256x128 and 256x256 tiles on this loop and the 4-wave forms: never selected by the rule above, removed in round 5.)
+    static const kern_t kerns[2] = {gemm_bf16_kernel<1, 128, 128, 2, 4>, gemm_bf16_kernel<2, 128, 128, 2, 4>};
+    // (the epilogue's eight 8-KiB wave buffers fill the 64-KiB operand ring; the row table sits behind them)
+    const size_t smem = (size_t)2 * (128 + 128) * 128 + 4096;
+    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+    kern_t k = kerns[planes - 1];
+    CWM_REQUIRE(smem >= (size_t)8 * 8192 + (size_t)128 * 16 + (size_t)128 * 8, "gemm: dynamic LDS too small for the staged epilogue (wave buffers + row table)");
     if (int rc = cwm_set_max_lds((const void*)k, (int)smem)) return rc;
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(threads[ci]), smem, stream, p);
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, p);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -4,6 +4,35 @@
 
 namespace cwm {
 
+// Execution options of one model handle (cwm_model_set_option / cwm_conj_set_option) -- every switch that was a process-wide global of the library
+// until round 4.  The defaults are the measured best; the other values exist for same-box A/B measurements and for the bitwise cross-checks of the
+// test suite.  A launch reads them through its parameter struct (GemmParams.tune, AttnParams.tune; nullptr = the defaults), a forward through its
+// Engine -- never from a global, so two models in one process cannot change each other's kernels.
+struct Tuning {
+    int gemm_tile = 0;     // 0 automatic per shape (gemm_choose_tile), 1: 128x128, 4: 256x256 8-phase, 6: 8-phase rounds + 128x128 remainder rows
+    int gemm_debug = 0;    // bit mask of ablations / A-B switches: 1 skip the epilogue's global stores, 2 skip the epilogue, 4 no 4-stage ring for small launches,
+                           // 8 skip every LayerNorm launch (timing only), 32 no split-K, 128 the one-lane tile choice also inside a two-lane call, 256 small launches keep
+                           // 128-row tiles where the default takes 64x128 ones, 512 bf16-output GEMMs with K < 512 stay on 128x128 tiles
+    int gemm_staged = 1;   // 0: the per-fragment epilogue of round 1 everywhere (it stays the fallback for unaligned widths)
+    int gemm_direct = 1;   // 1: bf16-output epilogues store 16 bytes per lane straight from the accumulators; 2: the fp32-output ones too; 0: LDS-staged everywhere
+    int attn_kernel = 0;   // 0 automatic, 1: 4-wave kernel (attention.hip), 3: software-pipelined kernel (attention_pipe.hip)
+    int attn_remap = 1;    // 0: plain workgroup order instead of one XCD per (batch, head) with the ragged query tiles last
+    int attn_tail = 1;     // 0: the regular schedule also for a ragged last query tile of <= 32 rows (attention_tail.h)
+    int attn_ksplit = 1;   // 0: a nearly empty last round of workgroups runs its items whole instead of cutting them into key ranges
+    int index_fused = 1;       // 0: the index prologue as the four launches of rounds 1-4 (memset, mask_to_perm, patch_gather, perm_to_rank) instead of one
+    int prune_last_block = 1;  // 0: the last decoder block runs over all tokens
+    int min_lane_rows = 0;     // encoder rows per half batch from which a forward splits into two lanes; 0: the model family's default (engine.h)
+    int conj_ctx_stream = 1;   // 0: the IMU-conditioned model's context stream on the lane's own stream
+    int conj_attn = 1;         // 0: the fp32 VALU cross / context attention kernels instead of the MFMA ones
+    // development library only (csrc/dev.hip, cwm_gemm_tile_override): per-shape tile configuration, 0 = no opinion
+    int (*tile_hook)(int M, int N, int K, int epi, int overlapped) = nullptr;
+};
+const Tuning& default_tuning();
+// What the stand-alone entry points (cwm_linear, cwm_attention ...) use and what a new model handle starts from: the defaults, unless the
+// development library's cwm_debug_set changed this THREAD's copy (libcwm_hip.so exports no way to)
+Tuning& thread_tuning();
+int tuning_set(Tuning& t, const char* key, int value);  // 0, or -1 for an unknown key
+
 enum GemmEpilogue : int {
     EPI_F32 = 0,        // C = acc + bias (+ resid[rowmap])            fp32 out
     EPI_BF16_GELU = 1,  // out = split_bf16(gelu_erf(acc + bias))      bf16 plane(s) out
@@ -49,7 +78,8 @@ struct GemmParams {
     int staged;  // set by launch_gemm: epilogue through LDS with full-line global accesses (gemm.hip)
     int direct;  // set by launch_gemm: 16-byte stores straight from the accumulators, W tile staged with permuted rows (gemm_device.h epilogue_direct)
     int overlapped;  // set by the engine: the launch runs beside another lane's kernels, so a partly filled last round of workgroups is not lost
-    int debug;  // development ablations (cwm_debug_set "gemm_debug"): bit 0 skip the epilogue's global stores, bit 1 skip the epilogue
+    int debug;  // set by launch_gemm from tune->gemm_debug (the kernels read bits 0 / 1: skip the epilogue's global stores / the epilogue)
+    const Tuning* tune;  // execution options of the calling model (nullptr: defaults)
 };
 
 constexpr int kSplitKSlots = 512;  // >= CUs: a split launch has at most one part per CU
@@ -58,14 +88,9 @@ int gemm_splitk_parts(const GemmParams& p, int planes);  // K ranges the deep-ri
 int launch_gemm(const GemmParams& p, int planes, hipStream_t stream);
 int gemm_choose_tile(const GemmParams& p, int planes);
 bool gemm_mixed_split(const GemmParams& p, GemmParams* big, GemmParams* rest);  // tile configuration 6
-int launch_gemm_tile(const GemmParams& p, int planes, int cfg, hipStream_t stream);  // 1: 128x128 ... 4: 256x256 8-phase (see g_gemm_tile)
-int gemm_tile_override(int M, int N, int K, int epi, int overlapped, int cfg);  // per-shape tile choice (cfg 0: remove, M <= 0: clear all)
+int launch_gemm_tile(const GemmParams& p, int planes, int cfg, hipStream_t stream);  // 1: 128x128, 4: 256x256 8-phase, 6: mixed (Tuning.gemm_tile)
 int gemm_cu_count();  // compute units of the current device, rounded down to a multiple of the 8 XCDs (256 on MI355X)
 int gemm_prof_dump();  // builds with -DCWM_GEMM_PROF: per-workgroup timers of gemm8p_kernel -> /tmp/gemm_blocks.bin
-extern int g_gemm_debug;
-extern int g_gemm_staged;
-extern int g_gemm_direct;
-extern int g_gemm_tile;    // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256 output tile, 4: 256x256 8-phase, 6: 4 for the whole rounds + 1 for the remaining rows
 
 struct AttnParams {
     const bf16* q;   // [planes][B*H][N][64]   (q pre-scaled by hd^-0.5)
@@ -84,20 +109,12 @@ struct AttnParams {
     int ks_main, ks_parts, ks_nqb;
     float* ks_scratch;  // [items - ks_main][ks_parts][128 queries][68]: O[64], max, sum, -, -
     int tail_split;  // set by launch_attention: a ragged last query tile of at most 32 rows splits the KEYS over its four waves (attention_tail.h; "attn_tail" switch)
-    // chained schedule (attention_pipe.hip, "attn_chain" switch), set by launch_attention_pipe: the first chain_heads heads of every XCD's share run as
-    // work items of chain_len consecutive full query tiles (attention_device.h attn_chain_item).  chain_len < 2: off
-    int chain_len, chain_heads;
+    const Tuning* tune;  // execution options of the calling model (nullptr: defaults)
 };
 
 int launch_attention(const AttnParams& p, int planes, hipStream_t stream);
 int attention_pipe_prof(int i);  // per-phase s_memtime totals of block 0 wave 0 (builds with -DCWM_ATTN_PROF only)
 int launch_attention_pipe(const AttnParams& p, int planes, hipStream_t stream);  // attention_pipe.hip; arguments checked by launch_attention
-extern int g_attn_remap;   // 1 (default): attn_tile_of_block's XCD-aware mapping; 0: plain (blockIdx.x, blockIdx.y)
-extern int g_attn_ksplit;  // 1 (default): a last round of workgroups that fills at most a quarter of the chip splits its items' KEYS over the idle slots (attention_pipe.hip)
-extern int g_attn_tail;    // 1 (default): key-split schedule for a ragged last query tile of <= 32 rows; 0: the regular schedule for every tile
-extern int g_attn_kernel;  // 0 auto, 1: 4-wave kernel, 3: software-pipelined kernel
-extern int g_attn_chain;        // 0 (default): automatic chain length of the pipelined kernel's work items; 1: single query tiles; C >= 2: chains of C
-extern int g_attn_chain_heads;  // -1 (default): automatic; else the number of chained heads per XCD
 
 struct LayerNormParams {
     const float* x;  // rows of length D, row stride ldx
@@ -137,6 +154,9 @@ struct PatchGatherParams {
 };
 
 int launch_patch_gather(const PatchGatherParams& p, int planes, hipStream_t stream);
+// mask[B][L] (L = perm_stride or Nt) -> perm[B][L], rank[B][L] (inverse; may be nullptr), err_rows[b] = (visible count of row b != n_vis), and the
+// gather of the first n_rows visible tokens of every sample, in one launch (elementwise.hip index_gather_kernel); p.perm is not read
+int launch_index_gather(const PatchGatherParams& p, const uint8_t* mask, int n_vis, int* perm, int* rank, int* err_rows, int planes, hipStream_t stream);
 
 // x_full[b][n_vis + j][:] = mask_token + pos[perm[b][n_vis + j]]   (vmae.py:556-557)
 int launch_fill_mask_tokens(float* x_full, const float* mask_token, const float* pos, const int* perm, int B, int Nt, int n_vis, int D, hipStream_t stream);
@@ -218,8 +238,6 @@ int launch_cross_attention_mfma_roles(const CrossAttnParams& p, int planes, hipS
 bool cross_attention_mfma_ok(int head_dim, int M);
 bool cross_attention_mfma_fits(int B, int N, int heads, int head_dim);  // the MFMA kernel's 32-bit offsets hold this lane (else: the VALU kernels)
 size_t cross_attention_mfma_partial_floats(int B, int heads, int M, int head_dim);
-extern int g_conj_ctx_stream;  // 1 (default): the IMU-conditioned model runs its context stream's blocks on a side stream between cross blocks
-extern int g_conj_attn;  // 1 (default): MFMA cross / small attention where the shapes allow; 0: the fp32 VALU kernels ("conj_attn" switch)
 
 int launch_perm_to_rank(const int* perm, int* rank, int B, int Nt, hipStream_t stream);
 

@@ -3,6 +3,8 @@
 // `PretrainVisionTransformerEncoder.forward_features` (:152-173), `...Decoder.forward` (:246-255) and
 // `Block.forward` (cwm/models/VideoMAE/utils.py:146-153) as a fixed sequence of HIP kernel launches
 // on the caller's stream.
+#include <stddef.h>
+
 #include "engine.h"
 
 using namespace cwm;
@@ -56,7 +58,7 @@ int ensure_workspace(cwm_model* m, int B, int n_vis) {
     const int Bc = std::max(B, m->ws_batch), Nv = std::max(n_vis, m->ws_nvis), Nt = m->Nt;
     const size_t rows_e = (size_t)Bc * Nv, rows_d = (size_t)Bc * Nt;
     int rc;
-    if ((rc = E.ws(&m->perm, rows_d)) || (rc = E.ws(&m->rank, rows_d)) || (rc = E.ws(&m->err, 4))) return rc;
+    if ((rc = E.ws(&m->perm, rows_d)) || (rc = E.ws(&m->rank, rows_d)) || (rc = E.ws(&m->err, (size_t)Bc + 4))) return rc;
     if ((rc = E.ws(&m->patches, 2 * rows_e * m->patch_kpad))) return rc;
     if ((rc = E.ws(&m->x_enc, rows_e * c.enc_dim)) || (rc = E.ws(&m->x_dec, rows_d * c.dec_dim))) return rc;
     const size_t act = std::max(rows_e * c.enc_dim, rows_d * c.dec_dim);
@@ -78,7 +80,8 @@ LaneWs lane_ws(const cwm_model* m, int lane, int b0) {
     LaneWs w;
     w.perm = m->perm + rows_d;
     w.rank = m->rank + rows_d;
-    w.err = m->err + lane;
+    w.err = m->err + b0;  // one word per batch row (index_gather_kernel writes every row's, every call: no memset)
+    (void)lane;
     w.patches = m->patches + 2 * rows_e * m->patch_kpad;
     w.x_enc = m->x_enc + rows_e * c.enc_dim;
     w.x_dec = m->x_dec + rows_d * c.dec_dim;
@@ -162,8 +165,6 @@ extern "C" int cwm_model_load_weight(cwm_model* m, const char* key, const float*
 
 extern "C" int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen) { return m->eng.missing_weights(buf, buflen); }
 
-static int g_prune_last_block = 1;
-int cwm::g_min_lane_rows = cwm::kMinLaneRows;
 // (Rounds 2-3 carried a form with every LayerNorm folded into the GEMMs around it -- parity-tested, measured slower: the 4 bytes / element
 // a producer GEMM then adds to its store-bound epilogue cost more than the LayerNorm launch they replace, DESIGN.md section 4.6 -- never the
 // default and removed in round 4.)
@@ -189,17 +190,22 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
     LayerNormParams ln;
 
     if (in_range(0)) {
-    CWM_HIP_CHECK(hipMemsetAsync(w.err, 0, sizeof(int), s));
-    if ((rc = launch_mask_to_perm(mask_in, B, Nt, Nv, w.perm, w.err, s))) return rc;
-
-    // a1-a3: frame load (+normalise) + tubelet patch gather of the visible tokens, patch-embed GEMM
-    // with bias and positional-table add in the epilogue
+    // a1-a3: mask -> permutation (+ its inverse for the un-embed, + the per-row check of the visible count), frame load (+normalise) and
+    // tubelet patch gather of the visible tokens in ONE launch (elementwise.hip index_gather_kernel); then the patch-embed GEMM with bias
+    // and positional-table add in the epilogue
     PatchGatherParams pg;
     memset(&pg, 0, sizeof(pg));
     pg.x = x_in; pg.sb = a->x_stride_b; pg.sc = a->x_stride_c; pg.st = a->x_stride_t; pg.normalize = a->normalize;
     pg.C = c.in_chans; pg.H = c.img_h; pg.W = c.img_w; pg.P = c.patch; pg.perm = w.perm; pg.Nt = Nt; pg.n_rows = Nv; pg.B = B;
     pg.out = w.patches; pg.out_plane = (int64_t)B * Nv * m->patch_kpad; pg.ld = m->patch_kpad;
-    if ((rc = E.run_patch_gather(pg, planes, s))) return rc;
+    if (E.tune.index_fused) {
+        if ((rc = E.run_index_gather(pg, mask_in, Nv, w.perm, a->y_video_dev ? w.rank : nullptr, w.err, planes, s))) return rc;
+    } else {  // the four launches of rounds 1-4 (A/B and the bitwise cross-check of the fused kernel)
+        CWM_HIP_CHECK(hipMemsetAsync(w.err, 0, (size_t)B * sizeof(int), s));
+        if ((rc = launch_mask_to_perm(mask_in, B, Nt, Nv, w.perm, w.err, s))) return rc;
+        if ((rc = E.run_patch_gather(pg, planes, s))) return rc;
+        if (a->y_video_dev && (rc = launch_perm_to_rank(w.perm, w.rank, B, Nt, s))) return rc;
+    }
     }
 
     StreamBuffers sb_enc = w.sb, sb_dec = w.sb;
@@ -228,8 +234,8 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
     }
 
     // a9: decoder blocks over the full token set, norm + head on the last Nm tokens
-    // (the last block only has to produce the Nm rows the head reads: debug key "prune_last_block" = 0 runs it in full)
-    const bool pruned = Nm > 0 && g_prune_last_block;
+    // (the last block only has to produce the Nm rows the head reads: option "prune_last_block" = 0 runs it in full)
+    const bool pruned = Nm > 0 && E.tune.prune_last_block;
     for (int i = 0; i < c.dec_depth; ++i) {
         const int keep = (i == c.dec_depth - 1 && pruned) ? Nm : 0;
         if (in_range(st_e2d + 1 + i) && (rc = E.run_block(m->dec[i], w.x_dec, B, Nt, c.dec_dim, c.dec_heads, planes, sb_dec, s, keep))) return rc;
@@ -247,8 +253,7 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
     // a11: patch un-embed scatter
     if (a->y_video_dev) {
         const float* xr = a->xraw_dev ? a->xraw_dev + (int64_t)b0 * a->x_stride_b : x_in;
-        if ((rc = launch_perm_to_rank(w.perm, w.rank, B, Nt, s))) return rc;
-        UnembedParams u;
+        UnembedParams u;  // (w.rank: written by the index prologue of stage 0)
         memset(&u, 0, sizeof(u));
         u.y = y_tokens; u.x = xr; u.sb = a->x_stride_b; u.sc = a->x_stride_c; u.st = a->x_stride_t;
         u.mask = mask_in; u.rank = w.rank; u.B = B; u.T = c.num_frames; u.C = c.in_chans; u.H = c.img_h; u.W = c.img_w;
@@ -261,6 +266,8 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
 
 extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     CWM_REQUIRE(m && a, "cwm_forward: null argument");
+    CWM_REQUIRE(a->struct_size >= offsetof(cwm_forward_args, stream) + sizeof(void*), "cwm_forward: args->struct_size = %u is smaller than cwm_forward_args (set it to sizeof(cwm_forward_args))",
+                a->struct_size);
     CWM_REQUIRE(a->x_dev && a->mask_dev && a->y_tokens_dev, "cwm_forward: x_dev, mask_dev and y_tokens_dev are required");
     CWM_REQUIRE(a->mode == CWM_MODE_FAST || a->mode == CWM_MODE_PARITY, "cwm_forward: bad mode %d", a->mode);
     const cwm_config& c = m->cfg;
@@ -281,8 +288,9 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
 
     // Batch lanes: between two dependent kernels the queue idles ~6 us (x 136 kernels = 5 % of a batch-32 step) and every kernel ends in a
     // partially filled round of workgroups; further, independent slices of the batch on other queues fill both.
+    const int min_rows = m->eng.tune.min_lane_rows > 0 ? m->eng.tune.min_lane_rows : kMinLaneRows;
     int n_lanes = 1;
-    while (n_lanes < m->lanes && n_lanes < B && (int64_t)(B / (n_lanes + 1)) * Nv >= g_min_lane_rows) ++n_lanes;
+    while (n_lanes < m->lanes && n_lanes < B && (int64_t)(B / (n_lanes + 1)) * Nv >= min_rows) ++n_lanes;
     const bool two = n_lanes >= 2;
     int first[cwm_model::kMaxLanes + 1];
     for (int l = 0; l <= n_lanes; ++l) first[l] = (int)(((int64_t)B * l + n_lanes - 1) / n_lanes);  // lane l owns batch elements [first[l], first[l+1])
@@ -313,10 +321,10 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
     if (rc) return rc;
 
     if (a->check) {
-        int herr[cwm_model::kMaxLanes] = {0, 0, 0, 0};
-        CWM_HIP_CHECK(hipMemcpyAsync(herr, m->err, n_lanes * sizeof(int), hipMemcpyDeviceToHost, s));
+        std::vector<int> herr((size_t)B, 0);
+        CWM_HIP_CHECK(hipMemcpyAsync(herr.data(), m->err, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
         CWM_HIP_CHECK(hipStreamSynchronize(s));
-        if (herr[0] || herr[1] || herr[2] || herr[3]) {
+        if (std::any_of(herr.begin(), herr.end(), [](int e) { return e != 0; })) {
             cwm_set_error("mask rows do not all have n_vis=%d visible tokens (shape '[%d, -1, %d]' is invalid for the gathered input)", Nv, B,
                           c.enc_dim);
             return CWM_ERR_MASK;
@@ -328,6 +336,12 @@ extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
 extern "C" int cwm_model_set_lanes(cwm_model* m, int lanes) {
     CWM_REQUIRE(m && lanes >= 1 && lanes <= cwm_model::kMaxLanes, "cwm_model_set_lanes: lanes must be 1 .. %d", cwm_model::kMaxLanes);
     m->lanes = lanes;
+    return CWM_OK;
+}
+
+extern "C" int cwm_model_set_option(cwm_model* m, const char* key, int value) {
+    CWM_REQUIRE(m && key, "cwm_model_set_option: null argument");
+    CWM_REQUIRE(tuning_set(m->eng.tune, key, value) == 0, "cwm_model_set_option: unknown option %s", key);
     return CWM_OK;
 }
 
@@ -439,6 +453,7 @@ extern "C" int cwm_linear(const float* a_dev, const float* w_dev, const float* b
     } else {
         p.epi = EPI_F32; p.C = c_dev; p.ldc = N; p.resid = resid_dev; p.ldr = N;
     }
+    p.tune = &thread_tuning();
     if (int rc = launch_gemm(p, planes, s)) return rc;
     if (gelu) {
         const unsigned gridG = (unsigned)(((int64_t)M * N + 255) / 256);
@@ -470,6 +485,7 @@ extern "C" int cwm_attention(const float* qkv_dev, float* o_dev, int B, int N, i
     memset(&a, 0, sizeof(a));
     a.q = q; a.k = k; a.v = v; a.qk_plane = qk_plane; a.o = o; a.o_plane = qk_plane; a.ldo = D;
     a.n_tok = N; a.heads = H; a.batch = B;
+    a.tune = &thread_tuning();
     if (int rc = launch_attention(a, planes, s)) return rc;
     if (planes == 2)
         hipLaunchKernelGGL(merge_planes_kernel<2>, dim3((unsigned)((qk_plane + 255) / 256)), dim3(256), 0, s, o, o_dev, B * N, D, D);
@@ -553,236 +569,3 @@ extern "C" int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H,
     return launch_shift_prompts(p, (hipStream_t)stream);
 }
 
-// ---------------------------------------------------------------------------------------------
-// diagnostics
-// ---------------------------------------------------------------------------------------------
-namespace {
-__global__ void fill_random_bf16_kernel(bf16* dst, int64_t n, unsigned seed, float scale) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    unsigned x = (unsigned)i * 2654435761u + seed;
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    dst[i] = (bf16)(((float)(x & 0xFFFF) / 32768.0f - 1.0f) * scale);
-}
-__global__ void fill_random_f32_kernel(float* dst, int64_t n, unsigned seed, float scale) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    unsigned x = (unsigned)i * 2654435761u + seed;
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    dst[i] = ((float)(x & 0xFFFF) / 32768.0f - 1.0f) * scale;
-}
-void fill_bf16(bf16* d, int64_t n, unsigned seed, float scale) {
-    hipLaunchKernelGGL(fill_random_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, n, seed, scale);
-}
-void fill_f32(float* d, int64_t n, unsigned seed, float scale) {
-    hipLaunchKernelGGL(fill_random_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, n, seed, scale);
-}
-}  // namespace
-
-extern "C" int cwm_debug_set(const char* key, int value) {
-    CWM_REQUIRE(key, "cwm_debug_set: null key");
-    if (!strcmp(key, "gemm_tile")) {
-        g_gemm_tile = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "gemm_prof")) return gemm_prof_dump();  // query (profiling builds)
-    if (!strcmp(key, "attn_prof")) return attention_pipe_prof(value);  // query (profiling builds)
-    if (!strcmp(key, "prune_last_block")) {
-        g_prune_last_block = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "min_lane_rows")) {  // encoder rows per half batch from which cwm_forward runs two lanes (default: engine.h kMinLaneRows)
-        g_min_lane_rows = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "attn_ksplit")) {
-        g_attn_ksplit = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "attn_chain")) {  // 0 auto, 1 single query tiles, C >= 2: work items of C consecutive query tiles (attention_pipe.hip)
-        g_attn_chain = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "attn_chain_heads")) {
-        g_attn_chain_heads = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "attn_tail")) {
-        g_attn_tail = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "attn_remap")) {
-        g_attn_remap = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "conj_ctx_stream")) {
-        g_conj_ctx_stream = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "conj_attn")) {  // 1: MFMA cross / small attention of the IMU-conditioned model (conj_attention.hip); 0: the fp32 VALU kernels
-        g_conj_attn = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "attn_kernel")) {
-        g_attn_kernel = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "gemm_staged")) {
-        g_gemm_staged = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "gemm_direct")) {
-        g_gemm_direct = value;
-        return CWM_OK;
-    }
-    if (!strcmp(key, "gemm_debug")) {
-        g_gemm_debug = value;
-        return CWM_OK;
-    }
-    cwm_set_error("cwm_debug_set: unknown key %s", key);
-    return CWM_ERR_INVALID;
-}
-
-extern "C" int cwm_gemm_tile_override(int M, int N, int K, int epi, int overlapped, int cfg) { return gemm_tile_override(M, N, K, epi, overlapped, cfg); }
-
-extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters, double* avg_us) {
-    CWM_REQUIRE(avg_us && M > 0 && N > 0 && K > 0 && iters > 0, "cwm_bench_gemm: bad argument");
-    CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_bench_gemm: bad mode");
-    const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
-    const int Kp = round_up(K, 64), Np = round_up(N, 256);
-    Scratch sc;
-    bf16* A = sc.get<bf16>((size_t)2 * M * Kp);
-    bf16* W = sc.get<bf16>((size_t)2 * Np * Kp);
-    float* bias = sc.get<float>(Np);
-    float* Cm = sc.get<float>((size_t)M * N);
-    bf16* G = sc.get<bf16>((size_t)2 * M * N + 64 * 1024);
-    bf16* G2 = sc.get<bf16>((size_t)2 * M * N + 64 * 1024);
-    bf16* G3 = sc.get<bf16>((size_t)2 * M * N + 64 * 1024 * 64);
-    CWM_REQUIRE(A && W && bias && Cm && G && G2 && G3, "cwm_bench_gemm: out of device memory");
-    fill_bf16(A, (int64_t)2 * M * Kp, 1, 1.0f);
-    fill_bf16(W, (int64_t)2 * Np * Kp, 2, 0.05f);
-    fill_f32(bias, Np, 3, 0.1f);
-    fill_f32(Cm, (int64_t)M * N, 4, 1.0f);
-    GemmParams p;
-    memset(&p, 0, sizeof(p));
-    p.A = A; p.lda = Kp; p.W = W;
-    p.M = M; p.N = N; p.K = Kp; p.bias = bias;
-    if (epi == 1 || epi == 2) {
-        p.epi = epi == 1 ? EPI_BF16_GELU : EPI_BF16; p.out_hi = G; p.ldo = N;
-    } else if (epi == 3) {
-        CWM_REQUIRE(N % 192 == 0, "cwm_bench_gemm: QKV epilogue needs N = 3*64*heads");
-        const int D = N / 3, H = D / 64, n_tok = 792 <= M && M % 792 == 0 ? 792 : M, B = M / n_tok;
-        (void)B;
-        p.epi = EPI_QKV; p.rows_in = n_tok; p.rows_out = n_tok; p.map_stride = n_tok;
-        p.q_out = G; p.k_out = G2; p.v_out = G3; p.qk_plane = (int64_t)M * D;
-        p.qkv_dim = D; p.heads = H; p.head_dim = 64; p.n_tok = n_tok; p.q_scale = 0.125f;
-    } else {
-        p.epi = EPI_F32; p.C = Cm; p.ldc = N; p.resid = Cm; p.ldr = N;
-    }
-    hipEvent_t e0, e1;
-    CWM_HIP_CHECK(hipEventCreate(&e0));
-    CWM_HIP_CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i)
-        if (int rc = launch_gemm(p, planes, 0)) return rc;
-    CWM_HIP_CHECK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i)
-        if (int rc = launch_gemm(p, planes, 0)) return rc;
-    CWM_HIP_CHECK(hipEventRecord(e1, 0));
-    CWM_HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0.f;
-    CWM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    *avg_us = 1e3 * ms / iters;
-    return CWM_OK;
-}
-
-// One wave idling for `us` microseconds (100 MHz s_memrealtime): a low-power gap between two launches of the duty-cycle probe.
-__global__ void idle_kernel(int us) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(64);
-}
-
-// Duty-cycle probe (tools/power_probe.py): `iters` launches of one GEMM with an idle gap of gap_us after each; returns the mean
-// duration of the GEMM launches alone (one HIP event pair per launch, the first quarter discarded as warm-up).
-extern "C" int cwm_bench_gemm_gapped(int M, int N, int K, int mode, int epi, int iters, int gap_us, double* avg_us) {
-    CWM_REQUIRE(avg_us && M > 0 && N > 0 && K > 0 && iters >= 4 && gap_us >= 0, "cwm_bench_gemm_gapped: bad argument");
-    const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
-    const int Kp = round_up(K, 64), Np = round_up(N, 256);
-    Scratch sc;
-    bf16* A = sc.get<bf16>((size_t)2 * M * Kp);
-    bf16* W = sc.get<bf16>((size_t)2 * Np * Kp);
-    float* bias = sc.get<float>(Np);
-    float* Cm = sc.get<float>((size_t)M * N);
-    bf16* G = sc.get<bf16>((size_t)2 * M * N + 64 * 1024);
-    CWM_REQUIRE(A && W && bias && Cm && G, "cwm_bench_gemm_gapped: out of device memory");
-    fill_bf16(A, (int64_t)2 * M * Kp, 1, 1.0f);
-    fill_bf16(W, (int64_t)2 * Np * Kp, 2, 0.05f);
-    fill_f32(bias, Np, 3, 0.1f);
-    fill_f32(Cm, (int64_t)M * N, 4, 1.0f);
-    GemmParams p;
-    memset(&p, 0, sizeof(p));
-    p.A = A; p.lda = Kp; p.W = W;
-    p.M = M; p.N = N; p.K = Kp; p.bias = bias;
-    if (epi == 1) {
-        p.epi = EPI_BF16_GELU; p.out_hi = G; p.ldo = N;
-    } else {
-        p.epi = EPI_F32; p.C = Cm; p.ldc = N; p.resid = Cm; p.ldr = N;
-    }
-    std::vector<hipEvent_t> ev(2 * iters);
-    for (auto& e : ev) CWM_HIP_CHECK(hipEventCreate(&e));
-    for (int i = 0; i < iters; ++i) {
-        CWM_HIP_CHECK(hipEventRecord(ev[2 * i], 0));
-        if (int rc = launch_gemm(p, planes, 0)) return rc;
-        CWM_HIP_CHECK(hipEventRecord(ev[2 * i + 1], 0));
-        if (gap_us > 0) hipLaunchKernelGGL(idle_kernel, dim3(1), dim3(64), 0, 0, gap_us);
-    }
-    CWM_HIP_CHECK(hipDeviceSynchronize());
-    double tot = 0;
-    int n = 0;
-    for (int i = iters / 4; i < iters; ++i, ++n) {
-        float ms = 0.f;
-        CWM_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
-        tot += ms;
-    }
-    for (auto& e : ev) (void)hipEventDestroy(e);
-    *avg_us = 1e3 * tot / n;
-    return CWM_OK;
-}
-
-extern "C" int cwm_bench_attention(int B, int H, int N, int mode, int iters, double* avg_us) {
-    CWM_REQUIRE(avg_us && B > 0 && H > 0 && N > 0 && iters > 0, "cwm_bench_attention: bad argument");
-    CWM_REQUIRE(mode == CWM_MODE_FAST || mode == CWM_MODE_PARITY, "cwm_bench_attention: bad mode");
-    const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
-    const int D = H * 64;
-    const int64_t qk_plane = (int64_t)B * N * D;
-    Scratch sc;
-    bf16* q = sc.get<bf16>(2 * qk_plane);
-    bf16* k = sc.get<bf16>(2 * qk_plane);
-    bf16* v = sc.get<bf16>(2 * qk_plane);
-    bf16* o = sc.get<bf16>(2 * qk_plane);
-    CWM_REQUIRE(q && k && v && o, "cwm_bench_attention: out of device memory");
-    fill_bf16(q, 2 * qk_plane, 5, 0.5f);
-    fill_bf16(k, 2 * qk_plane, 6, 1.0f);
-    fill_bf16(v, 2 * qk_plane, 7, 1.0f);
-    AttnParams a;
-    memset(&a, 0, sizeof(a));
-    a.q = q; a.k = k; a.v = v; a.qk_plane = qk_plane; a.o = o; a.o_plane = qk_plane; a.ldo = D;
-    a.n_tok = N; a.heads = H; a.batch = B;
-    hipEvent_t e0, e1;
-    CWM_HIP_CHECK(hipEventCreate(&e0));
-    CWM_HIP_CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i)
-        if (int rc = launch_attention(a, planes, 0)) return rc;
-    CWM_HIP_CHECK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i)
-        if (int rc = launch_attention(a, planes, 0)) return rc;
-    CWM_HIP_CHECK(hipEventRecord(e1, 0));
-    CWM_HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0.f;
-    CWM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    *avg_us = 1e3 * ms / iters;
-    return CWM_OK;
-}

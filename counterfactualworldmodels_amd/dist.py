@@ -143,23 +143,40 @@ class RcclComm(LocalComm):
         with torch.cuda.device(self.device):
             self._lib_mod.check(self._lib_mod.get_lib().cwm_broadcast(self._handle, buf.data_ptr(), buf.numel() * buf.element_size(), src, self._stream()))
 
+    @staticmethod
+    def gather_args(base: int, row: int, offsets: Sequence[int], counts: Sequence[int], rank: int):
+        """The pointer arithmetic of `all_gather_rows` as a pure function (so that the 8-rank layout can be checked without 8 GPUs).
+        Equal blocks back to back: ("allgather", send, recv, bytes_per_rank) with NCCL's in-place contract send == recv + rank * bytes;
+        otherwise ("allgatherv", send or None, base, byte offsets, byte counts)."""
+        world = len(counts)
+        assert len(offsets) == world and 0 <= rank < world and row >= 0
+        if _equal_contiguous(offsets, counts):
+            nbytes = counts[0] * row
+            send, recv = base + offsets[rank] * row, base + offsets[0] * row
+            assert send == recv + rank * nbytes  # ncclAllGather in place: every rank's block already sits at its slot of the receive buffer
+            return "allgather", send, recv, nbytes
+        sizes, offs = [n * row for n in counts], [o * row for o in offsets]
+        for r in range(world):  # blocks may be empty or differ, but never overlap
+            for q in range(r + 1, world):
+                assert offs[r] + sizes[r] <= offs[q] or offs[q] + sizes[q] <= offs[r] or sizes[r] == 0 or sizes[q] == 0, (offs, sizes)
+        return "allgatherv", (base + offs[rank] if counts[rank] else None), base, offs, sizes
+
     def all_gather_rows(self, out, offsets, counts):
         """Equal blocks back to back -> `ncclAllGather` in place (`cwm_allgather`, the tuned ring collective); anything else ->
         `cwm_allgatherv` (one group of per-root broadcasts, blocks may differ or be empty).  Both on the current stream."""
         assert out.is_cuda and out.is_contiguous()
         lib, row = self._lib_mod.get_lib(), (out[0].numel() * out.element_size() if out.shape[0] else 0)
-        base = out.data_ptr()
+        args = self.gather_args(out.data_ptr(), row, offsets, counts, self.rank)
+        assert max(o + n for o, n in zip(offsets, counts)) <= out.shape[0], "a block lies outside the result"
         with torch.cuda.device(self.device):
-            if _equal_contiguous(offsets, counts):
+            if args[0] == "allgather":
                 self.last_collective = "ncclAllGather"
-                self._lib_mod.check(lib.cwm_allgather(self._handle, base + offsets[self.rank] * row, base + offsets[0] * row, counts[0] * row,
-                                                      self._stream()))
+                self._lib_mod.check(lib.cwm_allgather(self._handle, args[1], args[2], args[3], self._stream()))
             else:
                 self.last_collective = "grouped ncclBroadcast"
-                sizes = (C.c_size_t * self.world)(*[n * row for n in counts])
-                offs = (C.c_size_t * self.world)(*[o * row for o in offsets])
-                send = base + offsets[self.rank] * row if counts[self.rank] else None
-                self._lib_mod.check(lib.cwm_allgatherv(self._handle, send, base, offs, sizes, self._stream()))
+                sizes = (C.c_size_t * self.world)(*args[4])
+                offs = (C.c_size_t * self.world)(*args[3])
+                self._lib_mod.check(lib.cwm_allgatherv(self._handle, args[1], args[2], offs, sizes, self._stream()))
         return out
 
     def all_reduce_sum(self, t):
@@ -247,6 +264,48 @@ def unpack_inputs(buf: torch.Tensor):
 
 
 # ---- the config-4 loop --------------------------------------------------------------------------------------------------
+class PhaseTimes:
+    """HIP-event spans around the phases of ONE sharded call -- {build (rank 0: all prompts + rectangularise + pack), broadcast, own_prompts,
+    predict, gather} -- on the stream each phase is issued on (the gathers run on the side stream).  `bench.py` puts every rank's result in its
+    line, so that a bad scaling curve can be read from one run: which rank, which phase.  Costs nothing when not passed."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.spans: List[Tuple[str, object, object]] = []
+
+    class _Span:
+        def __init__(self, owner, phase, stream):
+            self.owner, self.phase, self.stream = owner, phase, stream
+
+        def __enter__(self):
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record(self.stream or torch.cuda.current_stream(self.owner.device))
+
+        def __exit__(self, *exc):
+            b = torch.cuda.Event(enable_timing=True)
+            b.record(self.stream or torch.cuda.current_stream(self.owner.device))
+            self.owner.spans.append((self.phase, self.a, b))
+            return False
+
+    def span(self, phase: str, stream=None):
+        return PhaseTimes._Span(self, phase, stream)
+
+    def result(self) -> dict:
+        """{phase: summed milliseconds} (synchronises the device)."""
+        torch.cuda.synchronize(self.device)
+        out: dict = {}
+        for phase, a, b in self.spans:
+            out[phase] = out.get(phase, 0.0) + a.elapsed_time(b)
+        return out
+
+
+class _NoTimes:
+    def span(self, phase, stream=None):
+        import contextlib
+
+        return contextlib.nullcontext()
+
+
 class RemoteRankError(RuntimeError):
     """Rank 0 failed while preparing the prompts; raised on the other ranks instead of leaving them inside a collective."""
 
@@ -271,6 +330,7 @@ def sharded_counterfactual_predictions(
     gather: bool = True,
     comm: Optional[LocalComm] = None,
     shapes: Optional[Tuple[Sequence[int], Sequence[int], int]] = None,
+    times: Optional[PhaseTimes] = None,
 ) -> torch.Tensor:
     """S prompts over ONE frame pair, sharded over the ranks of `comm`.
 
@@ -287,16 +347,18 @@ def sharded_counterfactual_predictions(
     word in the packed header (they raise `RemoteRankError`)."""
     comm = comm or get_comm(device)
     rank, world = comm.rank, comm.world
+    T = times if times is not None else _NoTimes()
     failure = None
     if rank == 0:
         try:
-            xb, table = x.to(device), prompts.to(device)
-            x_all, masks = build_fn(xb, table)
-            masks, n_masked = rect_fn(masks)
-            if world > 1:
-                buf = pack_inputs(xb, table, masks, n_masked, device)
-                if shapes is not None and buf.numel() != _layout(shapes[0], shapes[1], shapes[2])[3]:
-                    raise ValueError("packed prompt buffer has %d bytes, the shape hint says %d" % (buf.numel(), _layout(shapes[0], shapes[1], shapes[2])[3]))
+            with T.span("build"):
+                xb, table = x.to(device), prompts.to(device)
+                x_all, masks = build_fn(xb, table)
+                masks, n_masked = rect_fn(masks)
+                if world > 1:
+                    buf = pack_inputs(xb, table, masks, n_masked, device)
+                    if shapes is not None and buf.numel() != _layout(shapes[0], shapes[1], shapes[2])[3]:
+                        raise ValueError("packed prompt buffer has %d bytes, the shape hint says %d" % (buf.numel(), _layout(shapes[0], shapes[1], shapes[2])[3]))
         except Exception as e:  # noqa: BLE001 -- the peers are (about to be) inside the broadcast: tell them, then raise here
             if world == 1:
                 raise
@@ -316,7 +378,8 @@ def sharded_counterfactual_predictions(
                 buf = torch.zeros(total, dtype=torch.uint8, device=device)  # magic 0 = status word "failed"
         if rank != 0:
             buf = torch.empty(total, dtype=torch.uint8, device=device)
-        comm.broadcast_bytes(buf, 0)
+        with T.span("broadcast"):
+            comm.broadcast_bytes(buf, 0)
         if failure is not None:
             raise failure
         if rank != 0:
@@ -327,10 +390,12 @@ def sharded_counterfactual_predictions(
     bounds = [shard_range(S, r, world) for r in range(world)]
     lo, hi = bounds[rank]
     if hi > lo:
-        x_own = x_all[lo:hi] if rank == 0 else build_fn(xb, table[lo:hi])[0]
+        with T.span("own_prompts"):
+            x_own = x_all[lo:hi] if rank == 0 else build_fn(xb, table[lo:hi])[0]
     if not gather or world == 1:
         if hi > lo:
-            return predict_fn(x_own, masks[lo:hi], n_masked, chunk)
+            with T.span("predict"):
+                return predict_fn(x_own, masks[lo:hi], n_masked, chunk)
         # an empty slice keeps the right trailing shape: predict one row, keep none
         return predict_fn(build_fn(xb, table[:1])[0], masks[:1], n_masked, chunk)[:0]
     # ---- chunk c of every rank is gathered while chunk c + 1 is predicted
@@ -342,7 +407,8 @@ def sharded_counterfactual_predictions(
     for c in range(n_chunks):
         a, b = min(lo + c * chunk, hi), min(lo + (c + 1) * chunk, hi)
         if b > a:
-            y = predict_fn(x_own[a - lo : b - lo], masks[a:b], n_masked, chunk)
+            with T.span("predict"):
+                y = predict_fn(x_own[a - lo : b - lo], masks[a:b], n_masked, chunk)
         elif out is None:  # this rank owns nothing at all: one row gives the trailing shape
             y = predict_fn(build_fn(xb, table[:1])[0], masks[:1], n_masked, chunk)[:0]
         if out is None:
@@ -353,10 +419,11 @@ def sharded_counterfactual_predictions(
         cnts = [min(l + (c + 1) * chunk, h) - o for (l, h), o in zip(bounds, offs)]
         if on_gpu and n_chunks > 1:
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), T.span("gather", side):
                 comm.all_gather_rows(out, offs, cnts)
         else:
-            comm.all_gather_rows(out, offs, cnts)
+            with T.span("gather"):
+                comm.all_gather_rows(out, offs, cnts)
     if on_gpu and n_chunks > 1:
         main.wait_stream(side)
     return out

@@ -95,20 +95,32 @@ def compute_flow_corrs(flow_samples, flow_samples_swap=None, downsample=1, take_
                        rows: Optional[Tuple[int, int]] = None):
     """[B,C,H,W,S] -> [B,1,H/ds,W/ds,H/ds,W/ds] covariance or correlation of the pooled flow magnitude over the samples
     (segmentation.py:479-547).  `rows=(row0, nrows)` returns only that slab [B,nrows,P] of the flattened [P,P] matrix."""
-    if distance_func is not None:
-        raise NotImplementedError("compute_flow_corrs: the features are the reference's default distance_func, utils.ChannelMSE(dim=1), "
-                                  "computed on the device; another callable cannot be run there")
+    _require_cuda(flow_samples, "compute_flow_corrs")
     B, Cc, H, W, S = flow_samples.shape
     if S == 0:  # segmentation.py:495-499
         flow_samples = torch.zeros(list(flow_samples.shape)[:-1] + [1], device=flow_samples.device, dtype=torch.float32)
         S = 1
     K = S if take_top_k is None else take_top_k
-    x = flow_features(flow_samples[..., :K], downsample)
+    ds = int(downsample or 1)
     if flow_samples_swap is not None:
         assert list(flow_samples_swap.shape) == [B, Cc, H, W, S]
-        x = torch.cat([x, flow_features(flow_samples_swap[..., :K], downsample)], -1)
+    if distance_func is None:
+        # the reference's default features, utils.ChannelMSE(dim=1) against zeros (segmentation.py:485, :513), fused with the pooling
+        x = flow_features(flow_samples[..., :K], downsample)
+        if flow_samples_swap is not None:
+            x = torch.cat([x, flow_features(flow_samples_swap[..., :K], downsample)], -1)
+    else:
+        # a caller's `distance_func(flow_inp, zeros)` (segmentation.py:503-513): it is the caller's PyTorch code, so it runs as PyTorch -- on the
+        # flows' device, on the pooled samples exactly as the reference hands them over -- and its [B, P, S] result goes through the same
+        # device prologues and covariance kernels as the default features
+        def _ds(fs):
+            return torch.nn.functional.avg_pool3d(fs[..., :K].permute(0, 1, 4, 2, 3), (1, ds, ds), stride=(1, ds, ds)).permute(0, 1, 3, 4, 2)
+
+        flow_inp = _ds(flow_samples.float())
+        if flow_samples_swap is not None:
+            flow_inp = torch.cat([flow_inp, _ds(flow_samples_swap.float())], -1)
+        x = distance_func(flow_inp, torch.zeros_like(flow_inp)).reshape(B, -1, flow_inp.size(-1)).float().contiguous()
     P = x.shape[1]
-    ds = int(downsample or 1)
     x = transform_features(x, do_spearman=do_spearman, thresh=thresh, binarize=binarize, normalize=normalize, zscore=zscore,
                            range_thresh=range_thresh, eps=eps)
     if rows is not None:

@@ -195,8 +195,30 @@ class PretrainVisionTransformer(WeightSync, nn.Module):
         return len(self.encoder.blocks)
 
     # ---- C-ABI plumbing --------------------------------------------------------------------------
+    def _library(self):
+        """The shared object this module's handle lives in: libcwm_hip.so unless `use_library` chose the development one."""
+        lib = getattr(self, "_cwm", None)
+        return lib if lib is not None else _lib.get_lib()
+
+    def _check(self, rc):
+        _lib.check(rc, self._library())
+
+    def use_library(self, lib):
+        """Create this model's handle in another build of the library (tools / tests: `_lib.get_dev_lib()`, whose per-shape tile overrides and
+        thread-local switches a handle of the production library never sees).  Call before the first forward; an existing handle is released."""
+        self._release()
+        object.__setattr__(self, "_cwm", lib)
+
+    def set_option(self, key: str, value: int):
+        """One execution option of THIS model (include/cwm_hip.h cwm_model_set_option: "attn_kernel", "gemm_tile", "prune_last_block" ...): per handle, never
+        process-wide.  Options set before the first forward are applied when the handle is created."""
+        opts = self.__dict__.setdefault("_options", {})
+        opts[key] = int(value)
+        if getattr(self, "_handle", None) is not None:
+            self._check(self._library().cwm_model_set_option(self._handle, key.encode(), int(value)))
+
     def _ensure_handle(self, device: torch.device) -> int:
-        lib = _lib.get_lib()
+        lib = self._library()
         if self._handle is not None and self._handle_device == device:
             return self._handle
         self._release()
@@ -207,16 +229,18 @@ class PretrainVisionTransformer(WeightSync, nn.Module):
         )
         h = C.c_void_p()
         with torch.cuda.device(device):
-            _lib.check(lib.cwm_model_create(C.byref(ccfg), C.byref(h)))
+            self._check(lib.cwm_model_create(C.byref(ccfg), C.byref(h)))
         self._handle = h.value
         self._handle_device = device
         self._loaded = {}
+        for k, v in self.__dict__.get("_options", {}).items():
+            self._check(lib.cwm_model_set_option(self._handle, k.encode(), v))
         return self._handle
 
     def _release(self):
         if getattr(self, "_handle", None) is not None:
             try:
-                _lib.get_lib().cwm_model_destroy(self._handle)
+                self._library().cwm_model_destroy(self._handle)
             except Exception:
                 pass
             # plain attributes: nn.Module.__setattr__ can already be half torn down when __del__ runs at interpreter exit
@@ -241,7 +265,7 @@ class PretrainVisionTransformer(WeightSync, nn.Module):
         if not force and self._handle is not None and self._handle_device == device and self._params_unchanged():
             return 0
         h = self._ensure_handle(device)
-        lib = _lib.get_lib()
+        lib = self._library()
         if force:
             self._loaded = {}
         n = 0
@@ -257,7 +281,7 @@ class PretrainVisionTransformer(WeightSync, nn.Module):
                 if t.is_cuda and t.device != device:
                     t = t.to(device)
                 shape = (C.c_int64 * t.dim())(*t.shape)
-                _lib.check(lib.cwm_model_load_weight(h, name.encode(), t.data_ptr(), on_dev, shape, t.dim()))
+                self._check(lib.cwm_model_load_weight(h, name.encode(), t.data_ptr(), on_dev, shape, t.dim()))
                 self._loaded[name] = tag
                 n += 1
         self._remember_params()
@@ -272,7 +296,7 @@ class PretrainVisionTransformer(WeightSync, nn.Module):
         _lib.require_gpu()
         if not x.is_cuda:
             raise RuntimeError("PretrainVisionTransformer.forward needs a CUDA/HIP tensor (no CPU fallback); got %s" % x.device)
-        lib = _lib.get_lib()
+        lib = self._library()
         dev = x.device
         if not weights_synced or self._handle is None or self._handle_device != dev:
             self.sync_weights(dev)
@@ -289,11 +313,11 @@ class PretrainVisionTransformer(WeightSync, nn.Module):
         y = self._out_buffer(out_tokens, (B, Nm if Nm > 0 else Nt, c.out_dim), dev)
         video = self._out_buffer(out_video, (B, c.num_frames, c.in_chans, c.img_size[0], c.img_size[1]), dev) if want_video else None
         args = _lib.CwmForwardArgs(
-            x.data_ptr(), strides[0], strides[1], strides[2], int(normalize), mask.data_ptr(), B, n_vis, y.data_ptr(),
+            C.sizeof(_lib.CwmForwardArgs), x.data_ptr(), strides[0], strides[1], strides[2], int(normalize), mask.data_ptr(), B, n_vis, y.data_ptr(),
             _lib.ptr(video), _lib.ptr(xraw), _lib.mode_id(self.mode), int(check), _lib.current_stream_handle(dev),
         )
         with torch.cuda.device(dev):
-            _lib.check(lib.cwm_forward(self._handle, C.byref(args)))
+            self._check(lib.cwm_forward(self._handle, C.byref(args)))
         return y, video
 
     @staticmethod
@@ -349,17 +373,17 @@ class PretrainVisionTransformer(WeightSync, nn.Module):
         streams (forked / joined inside the library), which fills the idle time between dependent kernels."""
         if self._handle is None:
             raise RuntimeError("run a forward pass (or sync_weights) before set_lanes")
-        _lib.check(_lib.get_lib().cwm_model_set_lanes(self._handle, int(lanes)))
+        self._check(self._library().cwm_model_set_lanes(self._handle, int(lanes)))
 
     # ---- kernel timing (bench.py roofline) ------------------------------------------------------------
     def timing_enable(self, kclass: int, enable: bool = True):
         if self._handle is None:
             raise RuntimeError("run a forward pass (or sync_weights) before enabling timing")
-        _lib.check(_lib.get_lib().cwm_timing_enable(self._handle, kclass, int(enable)))
+        self._check(self._library().cwm_timing_enable(self._handle, kclass, int(enable)))
 
     def timing_collect(self, kclass: int):
         st = _lib.CwmKernelStats()
-        _lib.check(_lib.get_lib().cwm_timing_collect(self._handle, kclass, C.byref(st)))
+        self._check(self._library().cwm_timing_collect(self._handle, kclass, C.byref(st)))
         return {"launches": st.launches, "total_ms": st.total_ms, "total_flops": st.total_flops}
 
 

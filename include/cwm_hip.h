@@ -27,6 +27,10 @@
 extern "C" {
 #endif
 
+/* The shared objects are built with -fvisibility=hidden: the entry points declared here (and, in libcwm_hip_dev.so, those of cwm_hip_dev.h)
+ * are all they export. */
+#define CWM_API __attribute__((visibility("default")))
+
 #define CWM_OK 0
 #define CWM_ERR_INVALID (-1) /* bad argument / precondition (mirrors the reference's shape errors) */
 #define CWM_ERR_HIP (-2)     /* a HIP runtime call failed */
@@ -53,18 +57,20 @@ typedef struct cwm_model cwm_model;
 struct cwm_kernel_stats;
 
 /* replaces: model construction via the factories, vmae.py:597-619 */
-int cwm_model_create(const cwm_config* cfg, cwm_model** out);
-void cwm_model_destroy(cwm_model* m);
+CWM_API int cwm_model_create(const cwm_config* cfg, cwm_model** out);
+CWM_API void cwm_model_destroy(cwm_model* m);
 
 /* replaces: `model.load_state_dict(...)` (prediction.py:81-107).  `key` is the reference state-dict
  * name, `data` fp32 in PyTorch layout, on the host (on_device=0) or on the
  * model's device (on_device=1).  The tensor is copied and packed; the caller's buffer is not kept.
  * Re-loading a key overwrites it.  Unknown key or wrong shape -> CWM_ERR_INVALID. */
-int cwm_model_load_weight(cwm_model* m, const char* key, const float* data, int on_device, const int64_t* shape, int ndim);
+CWM_API int cwm_model_load_weight(cwm_model* m, const char* key, const float* data, int on_device, const int64_t* shape, int ndim);
 /* Number of state-dict tensors not loaded yet (0 = ready); fills `buf` with the first missing key. */
-int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen);
+CWM_API int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen);
 
 typedef struct cwm_forward_args {
+    uint32_t struct_size;    /* sizeof(cwm_forward_args) of the header the CALLER was compiled against: fields added at the end by later versions
+                              * are read only when the size covers them; a size below the first version's is CWM_ERR_INVALID */
     /* frames: element (b, c, t, y, x) at x_dev[b*x_stride_b + c*x_stride_c + t*x_stride_t + y*W + x]
      * (so both [B,C,T,H,W] and the wrapper's [B,T,C,H,W] layouts are accepted without a copy) */
     const float* x_dev;
@@ -89,13 +95,34 @@ typedef struct cwm_forward_args {
 /* replaces: `self.predictor(self._preprocess(x), mask)` prediction.py:419-422
  *           = PretrainVisionTransformer.forward vmae.py:539-560,
  * and optionally `pred_patches_to_video` prediction.py:245-259. */
-int cwm_forward(cwm_model* m, const cwm_forward_args* args);
+CWM_API int cwm_forward(cwm_model* m, const cwm_forward_args* args);
 
 /* Batch lanes (no counterpart in the reference: an execution option of this library).  lanes = 2 (default): a call with
  * batch >= 2 whose halves keep >= 3000 encoder rows (ViT-B/8: batch >= 8; ViT-L/4: batch >= 2) runs as two half batches, the first on args->stream and the second on a stream owned by the model, forked and joined
  * with events inside cwm_forward, so the caller sees ordinary stream semantics; results are those of the single-lane call up to the
  * kernel choice per GEMM shape (fp32 re-association, < 1e-5).  lanes = 1: everything on args->stream. */
-int cwm_model_set_lanes(cwm_model* m, int lanes); /* 1 .. 4; more than two lanes measured slower on MI355X */
+CWM_API int cwm_model_set_lanes(cwm_model* m, int lanes); /* 1 .. 4; more than two lanes measured slower on MI355X */
+
+/* Execution options of ONE model handle (no counterpart in the reference).  The defaults are the measured best and what production callers run;
+ * the other values exist for same-box A/B measurements and for the bitwise cross-checks of the test suite.  Options are per handle: two models in
+ * one process never see each other's settings (until round 4 these were process-wide switches).  Unknown key -> CWM_ERR_INVALID.  Results do not
+ * depend on an option beyond fp32 re-association (< 1e-5), except the timing-only ablation bits of "gemm_debug".
+ *   "gemm_tile"    0 automatic per shape, 1: 128x128 tiles, 4: 256x256 8-phase kernel, 6: 8-phase rounds + 128x128 remainder rows
+ *   "gemm_direct"  1: bf16-output epilogues store 16 bytes per lane straight from the accumulators; 2: the fp32-output ones too; 0: LDS-staged
+ *   "gemm_staged"  0: the per-fragment epilogue of round 1
+ *   "gemm_debug"   bit mask: 1 skip the epilogue's global stores (timing only), 2 skip the epilogue (timing only), 4 no 4-stage ring for small launches,
+ *                  8 skip every LayerNorm launch (timing only), 32 no split-K, 128 the one-lane tile choice also inside a two-lane call, 256 small launches
+ *                  keep 128-row tiles, 512 bf16-output GEMMs with K < 512 stay on 128x128 tiles
+ *   "attn_kernel"  0 automatic, 1: 4-wave kernel, 3: software-pipelined kernel
+ *   "attn_remap"   0: plain workgroup order instead of one XCD per (batch, head) with the ragged query tiles last
+ *   "attn_tail"    0: the regular schedule also for a ragged last query tile of <= 32 rows
+ *   "attn_ksplit"  0: a nearly empty last round of workgroups runs its items whole instead of cutting them into key ranges
+ *   "index_fused"       0: the index prologue (mask -> permutation, its inverse, the row check, the patch gather) as the four launches of rounds 1-4
+ *   "prune_last_block"  0: the last decoder block runs over all tokens
+ *   "min_lane_rows"     encoder rows per half batch from which a forward splits into two lanes (0: the default, 3000 / 12000 for the IMU model)
+ *   "conj_attn"         0: the fp32 VALU cross / context attention kernels of the IMU-conditioned model instead of the MFMA ones
+ *   "conj_ctx_stream"   0: the IMU-conditioned model's context stream on the lane's own stream instead of a side stream */
+CWM_API int cwm_model_set_option(cwm_model* m, const char* key, int value);
 
 /* ---- IMU-conditioned conjoined padded predictor (BASELINE configs[4]) ------------------------------
  * replaces: ConjoinedPaddedVisionTransformer.forward for the `imu400_base_4x4patch_2frames_1tube` family
@@ -114,12 +141,14 @@ typedef struct cwm_conj_config {
 } cwm_conj_config;
 
 typedef struct cwm_conj_model cwm_conj_model;
-int cwm_conj_create(const cwm_conj_config* cfg, cwm_conj_model** out);
-void cwm_conj_destroy(cwm_conj_model* m);
-int cwm_conj_load_weight(cwm_conj_model* m, const char* key, const float* data, int on_device, const int64_t* shape, int ndim);
-int cwm_conj_missing_weights(cwm_conj_model* m, char* buf, int buflen);
+CWM_API int cwm_conj_create(const cwm_conj_config* cfg, cwm_conj_model** out);
+CWM_API void cwm_conj_destroy(cwm_conj_model* m);
+CWM_API int cwm_conj_load_weight(cwm_conj_model* m, const char* key, const float* data, int on_device, const int64_t* shape, int ndim);
+CWM_API int cwm_conj_missing_weights(cwm_conj_model* m, char* buf, int buflen);
 
 typedef struct cwm_conj_forward_args {
+    uint32_t struct_size;        /* sizeof(cwm_conj_forward_args) as the caller knows it (see cwm_forward_args): y_ctx_tokens_dev, added in 0.5, is read only
+                                  * when the size covers it */
     const float* x_dev;          /* frames, strides as in cwm_forward_args */
     int64_t x_stride_b, x_stride_c, x_stride_t;
     int32_t normalize;
@@ -140,10 +169,11 @@ typedef struct cwm_conj_forward_args {
 } cwm_conj_forward_args;
 
 /* replaces: `self.predictor(self._preprocess(x), mask, x_context=..., mask_context=...)` (prediction.py:419-422) */
-int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* args);
-int cwm_conj_set_lanes(cwm_conj_model* m, int lanes); /* as cwm_model_set_lanes (here the halves must keep >= 12000 encoder rows: batch >= 8); the halves keep the call's n_vis_max / n_vis_ctx_max */
-int cwm_conj_timing_enable(cwm_conj_model* m, int kclass, int enable);
-int cwm_conj_timing_collect(cwm_conj_model* m, int kclass, struct cwm_kernel_stats* out);
+CWM_API int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* args);
+CWM_API int cwm_conj_set_lanes(cwm_conj_model* m, int lanes); /* as cwm_model_set_lanes (here the halves must keep >= 12000 encoder rows: batch >= 8); the halves keep the call's n_vis_max / n_vis_ctx_max */
+CWM_API int cwm_conj_set_option(cwm_conj_model* m, const char* key, int value); /* as cwm_model_set_option */
+CWM_API int cwm_conj_timing_enable(cwm_conj_model* m, int kclass, int enable);
+CWM_API int cwm_conj_timing_collect(cwm_conj_model* m, int kclass, struct cwm_kernel_stats* out);
 
 /* ---- timing hooks (bench.py roofline): HIP events around every launch of one kernel class ------ */
 #define CWM_KCLASS_GEMM 0        /* every GEMM launch */
@@ -165,28 +195,28 @@ typedef struct cwm_kernel_stats {
     double total_ms;    /* sum of launch durations (HIP events on the launch stream) */
     double total_flops; /* algorithmic FLOPs (2*M*N*K; attention 4*N*N*hd per head) of those launches; BYTES for classes 4-7 */
 } cwm_kernel_stats;
-int cwm_timing_enable(cwm_model* m, int kclass, int enable);
+CWM_API int cwm_timing_enable(cwm_model* m, int kclass, int enable);
 /* Synchronises the recorded events, accumulates, and resets the event pool. */
-int cwm_timing_collect(cwm_model* m, int kclass, cwm_kernel_stats* out);
+CWM_API int cwm_timing_collect(cwm_model* m, int kclass, cwm_kernel_stats* out);
 
 /* ---- stand-alone kernel entry points (kernel-level parity tests; same kernels the model uses) -- */
 /* fp32 -> bf16 hi (and lo if lo_dev != NULL) */
-int cwm_split_bf16(const float* x_dev, int64_t n, void* hi_dev, void* lo_dev, void* stream);
+CWM_API int cwm_split_bf16(const float* x_dev, int64_t n, void* hi_dev, void* lo_dev, void* stream);
 /* C[M,N] (fp32, ldc=N) = A[M,K] * W[N,K]^T + bias (+ resid), all fp32 device inputs; the library
  * splits/pads the operands exactly as the model path does.  replaces: F.linear (VideoMAE/utils.py:48-53) */
-int cwm_linear(const float* a_dev, const float* w_dev, const float* bias_dev, const float* resid_dev, float* c_dev,
+CWM_API int cwm_linear(const float* a_dev, const float* w_dev, const float* bias_dev, const float* resid_dev, float* c_dev,
                int M, int N, int K, int gelu, int mode, void* stream);
 /* O[B,N,H*64] = softmax(q k^T) v per head from a packed qkv activation [B,N,3*H*64] (fp32 device),
  * q scaled by 64^-0.5 after bias as in VideoMAE/utils.py:94-113. */
-int cwm_attention(const float* qkv_dev, float* o_dev, int B, int N, int H, int mode, void* stream);
+CWM_API int cwm_attention(const float* qkv_dev, float* o_dev, int B, int N, int H, int mode, void* stream);
 /* y = LayerNorm(x) (fp32 in/out, eps, affine).  replaces nn.LayerNorm at VideoMAE/utils.py:148-149 */
-int cwm_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev, int rows, int D,
+CWM_API int cwm_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev, int rows, int D,
                   float eps, void* stream);
 /* perm[B,Nt] = [visible ascending | masked ascending]; returns CWM_ERR_MASK if a row's visible
  * count != n_vis (synchronises).  replaces the boolean gathers vmae.py:167,555-556 */
-int cwm_mask_to_perm(const uint8_t* mask_dev, int B, int Nt, int n_vis, int32_t* perm_dev, void* stream);
+CWM_API int cwm_mask_to_perm(const uint8_t* mask_dev, int B, int Nt, int n_vis, int32_t* perm_dev, void* stream);
 /* replaces pred_patches_to_video (prediction.py:245-259); x is [B,T,C,H,W] contiguous raw frames */
-int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const uint8_t* mask_dev, int B, int T, int C, int H, int W,
+CWM_API int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const uint8_t* mask_dev, int B, int T, int C, int H, int W,
                 int P, int n_vis, float* out_dev, void* stream);
 
 /* Motion-counterfactual prompt construction for B*S prompts at once.
@@ -197,7 +227,7 @@ int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const uint8_t* ma
  *           leaves visible take their frame-0 pixels), BEFORE the final mask_rectangularizer call (host).  x [B,T,C,H,W]; active/masks [B*S,Nt] bool ('(b s)' order,
  *           0 = active patch / 0 = passive visible patch); shifts [B*S,2] (dy,dx) in patch units;
  *           outputs x_out [B*S,T,C,H,W], mask_out [B*S,Nt].  Asynchronous on `stream`. */
-int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int P, int frame, int S, int fix_passive,
+CWM_API int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int P, int frame, int S, int fix_passive,
                       const uint8_t* active_dev, const uint8_t* masks_dev, const int32_t* shifts_dev, float* x_out_dev,
                       uint8_t* mask_out_dev, void* stream);
 
@@ -217,20 +247,20 @@ int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int
  *                     replaces: compute_flow_samples_magnitude + the `.mean(-1)` numerator (segmentation.py:250-255, :264-268)
  * cwm_flow_map_finish map = map*scale (scale = 1/S_total), then (map - min)/max(max - min, eps) per b if normalize.
  *                     replaces: segmentation.py:273-275.  Split from the sum so that sample shards can be all-reduced in between. */
-int cwm_flow_features(const float* flows_dev, const int64_t* strides, int B, int C, int H, int W, int S, int downsample,
+CWM_API int cwm_flow_features(const float* flows_dev, const int64_t* strides, int B, int C, int H, int W, int S, int downsample,
                       float* x_dev, void* stream);
 /* cwm_flow_transform  the optional prologues of compute_flow_corrs on the pooled features, in place, in the reference's order
  *                     (segmentation.py:519-538; x[b] is its [P, S] matrix): spearman: every row -> argsort over its samples (as floats);
  *                     thresh_mode 1: x * (x > thresh), 2: (x > thresh), 3: ((x - min_P) > thresh * (max_P - min_P)) ("range_thresh");
  *                     normalize: x / max(max_P, eps); zscore: (x - mean_P) / max(std_P, eps), statistics over the P positions per sample.
  *                     stats_work_dev: [B][S][4] floats (needed by mode 3, normalize, zscore) */
-int cwm_flow_transform(float* x_dev, int B, int P, int S, int spearman, int thresh_mode, float thresh, int normalize, int zscore, float eps,
+CWM_API int cwm_flow_transform(float* x_dev, int B, int P, int S, int spearman, int thresh_mode, float thresh, int normalize, int zscore, float eps,
                        float* stats_work_dev, void* stream);
-int cwm_flow_cov(const float* x_dev, int B, int P, int S, int row0, int nrows, int use_covariance, float* xc_work_dev,
+CWM_API int cwm_flow_cov(const float* x_dev, int B, int P, int S, int row0, int nrows, int use_covariance, float* xc_work_dev,
                  float* inv_std_work_dev, float* out_dev, void* stream);
-int cwm_flow_motion_sum(const float* flows_dev, const int64_t* strides, int B, int C, int H, int W, int S,
+CWM_API int cwm_flow_motion_sum(const float* flows_dev, const int64_t* strides, int B, int C, int H, int W, int S,
                         int normalize_per_sample, float eps, float* minmax_work_dev, float* sum_dev, void* stream);
-int cwm_flow_map_finish(float* map_dev, int B, int HW, float scale, int normalize, float eps, void* stream);
+CWM_API int cwm_flow_map_finish(float* map_dev, int B, int HW, float scale, int normalize, float eps, void* stream);
 
 /* ---- collectives around the sharded counterfactual-sampling loop (SURVEY.md 8e / 8b "comm"; BASELINE configs[3]) ----------
  * The reference has no multi-GPU code: it chunks the S prompts of one frame pair over ONE device (prediction.py:513-540,
@@ -247,54 +277,28 @@ int cwm_flow_map_finish(float* map_dev, int B, int HW, float scale, int normaliz
  * PyTorch's -- else the ROCm install); cwm_comm_version() returns its NCCL_VERSION_CODE or -1. */
 #define CWM_COMM_ID_BYTES 128
 typedef struct cwm_comm cwm_comm;
-int cwm_comm_load(const char* rccl_path);
-int cwm_comm_version(void);
-int cwm_comm_unique_id(uint8_t* id_out);
-int cwm_comm_init(int rank, int nranks, const uint8_t* id_in, cwm_comm** out);
-void cwm_comm_destroy(cwm_comm* c);
-int cwm_comm_rank(const cwm_comm* c);
-int cwm_comm_size(const cwm_comm* c);
-int cwm_broadcast(cwm_comm* c, void* buf_dev, size_t bytes, int root, void* stream);
-int cwm_allgather(cwm_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
-int cwm_allgatherv(cwm_comm* c, const void* send_dev, void* recv_dev, const size_t* offsets, const size_t* counts, void* stream);
-int cwm_allreduce_sum_f32(cwm_comm* c, float* buf_dev, size_t count, void* stream);
+CWM_API int cwm_comm_load(const char* rccl_path);
+CWM_API int cwm_comm_version(void);
+CWM_API int cwm_comm_unique_id(uint8_t* id_out);
+CWM_API int cwm_comm_init(int rank, int nranks, const uint8_t* id_in, cwm_comm** out);
+CWM_API void cwm_comm_destroy(cwm_comm* c);
+CWM_API int cwm_comm_rank(const cwm_comm* c);
+CWM_API int cwm_comm_size(const cwm_comm* c);
+CWM_API int cwm_broadcast(cwm_comm* c, void* buf_dev, size_t bytes, int root, void* stream);
+CWM_API int cwm_allgather(cwm_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+CWM_API int cwm_allgatherv(cwm_comm* c, const void* send_dev, void* recv_dev, const size_t* offsets, const size_t* counts, void* stream);
+CWM_API int cwm_allreduce_sum_f32(cwm_comm* c, float* buf_dev, size_t count, void* stream);
 
-/* Tuning hook (tools/autotune_step.py): fix the output-tile configuration of every GEMM launch of one shape -- M, N, K as launched (K padded to
- * 64), epi 0 fp32 / 1 bf16+GELU / 2 bf16 / 3 QKV scatter, overlapped = inside a two-lane forward -- to cfg 1 (128x128), 4 (256x256 8-phase) or 6 (4 for
- * the whole rounds + 1 for the remaining rows); cfg 0 removes the entry, M <= 0 clears the table.  Every configuration gives bit-identical results. */
-int cwm_gemm_tile_override(int M, int N, int K, int epi, int overlapped, int cfg);
-
-/* ---- diagnostics: single-kernel micro-benchmarks on random operands (tools/microbench.py) ---------
- * epi: 0 = fp32 out + bias + in-place residual (proj/fc2 form), 1 = bias + GELU -> bf16 (fc1 form),
- *      3 = QKV head scatter (N must be 3*64*heads, M = batch*n_tok with n_tok = M / batch).
- * Runs `iters` back-to-back launches after 3 warm-up launches and returns the mean launch time. */
-int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters, double* avg_us);
-int cwm_bench_attention(int B, int H, int N, int mode, int iters, double* avg_us);
-/* duty-cycle probe: the same GEMM with an idle gap of gap_us after every launch; mean duration of the GEMM launches alone
- * (is the chip's clock under MFMA load set by the instantaneous or by the time-averaged power?  tools/power_probe.py) */
-int cwm_bench_gemm_gapped(int M, int N, int K, int mode, int epi, int iters, int gap_us, double* avg_us);
-/* development switches (PROCESS-WIDE, not per model handle: for tests and measurements, never for production use -- a second
- * model in the same process sees the same values): "gemm_tile" (0 automatic per shape, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 8-phase,
- * 6: 8-phase rounds + 128x128 remainder rows), "gemm_direct" (1, default: bf16-output epilogues store 16 bytes per lane straight from the accumulators;
- * 2: the fp32-output epilogues too; 0: every epilogue through the LDS staging buffer), "gemm_staged" (0: the per-fragment epilogue of round 1),
- * "gemm_debug" (bit mask of ablations / A-B switches: 1 skip the epilogue's global stores, 2 skip the epilogue, 4 no 4-stage ring for small launches, 8 skip every
- * LayerNorm launch (timing only), 16 small launches on 4 instead of 8 waves, 32 no split-K, 64 the 128x128 kernel as 4-wave workgroups, 128 the one-lane tile
- * choice also inside a two-lane call, 256 small launches keep 128-row tiles where the default takes 64x128 ones, 512 bf16-output GEMMs with K < 512 stay on 128x128 tiles), "attn_kernel" (0 automatic, 1: 4-wave, 3: software-pipelined 4-wave),
- * "min_lane_rows" (encoder rows per half batch from which cwm_forward splits into two lanes; default 3000), "attn_remap" (0: plain workgroup order instead of one XCD per (batch, head) with the ragged query tiles last), "attn_tail" (0: the regular schedule
- * also for a ragged last query tile of <= 32 rows instead of splitting its keys over the four waves), "attn_ksplit" (0: a nearly empty last round of
- * workgroups runs its items whole instead of cutting them into key ranges),
- * "prune_last_block" (0: run the last decoder block over all tokens),
- * "conj_attn" (0: the fp32 VALU cross / context attention kernels of the IMU-conditioned model instead of the MFMA ones), "conj_ctx_stream" (0: the
- * context stream's blocks on the lane's own stream instead of a side stream between cross blocks); queries: "attn_prof" / "gemm_prof" (per-workgroup
- * timers of builds with -DCWM_ATTN_PROF / -DCWM_GEMM_PROF) */
-int cwm_debug_set(const char* key, int value);
-
-const char* cwm_last_error(void);
+CWM_API const char* cwm_last_error(void);
 /* "cwm_hip <version> gfx950" */
-const char* cwm_version(void);
+CWM_API const char* cwm_version(void);
 /* Hash of the sources this library was built from (counterfactualworldmodels_amd/build.py: source_hash); the Python
  * binding compares it at load time so that a stale in-tree .so is rebuilt instead of silently bound. */
-const char* cwm_source_hash(void);
+CWM_API const char* cwm_source_hash(void);
+/* `HIP version ...; AMD clang version ...` of the hipcc that compiled this library.  The kernels carry hand-counted s_waitcnt instructions whose
+ * correctness depends on the ISA the compiler emits around them; tools/asm_lds_lint.py checks that ISA and records the compiler it passed on
+ * (csrc/LINT_PASSED.json), build.py and bench.py compare the two. */
+CWM_API const char* cwm_compiler_version(void);
 
 #ifdef __cplusplus
 }

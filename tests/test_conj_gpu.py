@@ -176,9 +176,6 @@ def test_mfma_and_valu_conj_attention_agree(which):
     projections in the GEMM operand layout) against the exact-fp32 VALU kernels they replace (csrc/conj_kernels.hip, debug switch
     "conj_attn" = 0): same forward output within the split-bf16 rounding, for ragged visible counts, masked context tokens
     (fewer than 25 context keys), head_dim 32 (tiny) and 192 / 96 with 25 / 50 context tokens (imu400), in both modes."""
-    from counterfactualworldmodels_amd import _lib
-
-    lib = _lib.get_lib()
     if which == "tiny":
         g = np.load(os.path.join(GOLDEN, "conj_tiny.npz"))
         m = build(TINY_CONJ, int(g["seed"]))
@@ -195,28 +192,22 @@ def test_mfma_and_valu_conj_attention_agree(which):
         mc = torch.zeros(3, 25, dtype=torch.bool, device="cuda")
         mc[1, 3] = True
         mc[2, 7:12] = True
-    try:
-        for mode, tol in (("parity", 1e-4), ("fast", 1e-1)):
-            m.mode = mode
-            _lib.check(lib.cwm_debug_set(b"conj_attn", 1))
-            y1 = m(x, mask, x_context=imu, mask_context=mc)
-            _lib.check(lib.cwm_debug_set(b"conj_attn", 0))
-            y0 = m(x, mask, x_context=imu, mask_context=mc)
-            err = (y1 - y0).abs().max().item()
-            print(f"[{which} {mode}] MFMA vs VALU conj attention: {err:.2e}")
-            assert torch.isfinite(y1).all() and err <= tol, (mode, err)
-            assert torch.equal(y1.abs().sum(-1) == 0, y0.abs().sum(-1) == 0)
-    finally:
-        _lib.check(lib.cwm_debug_set(b"conj_attn", 1))
+    for mode, tol in (("parity", 1e-4), ("fast", 1e-1)):
+        m.mode = mode
+        m.set_option("conj_attn", 1)
+        y1 = m(x, mask, x_context=imu, mask_context=mc)
+        m.set_option("conj_attn", 0)
+        y0 = m(x, mask, x_context=imu, mask_context=mc)
+        err = (y1 - y0).abs().max().item()
+        print(f"[{which} {mode}] MFMA vs VALU conj attention: {err:.2e}")
+        assert torch.isfinite(y1).all() and err <= tol, (mode, err)
+        assert torch.equal(y1.abs().sum(-1) == 0, y0.abs().sum(-1) == 0)
 
 
 def test_context_side_stream_is_bitwise_neutral():
-    """cwm_debug_set("conj_ctx_stream"): the IMU stream's blocks and the context side of every cross block run on a side HIP stream per
+    """Option "conj_ctx_stream": the IMU stream's blocks and the context side of every cross block run on a side HIP stream per
     lane, exchanging projections with the lane's stream through events (csrc/conj_model.hip run_cross).  Pure scheduling: outputs must be
     bit-identical to the one-stream order, call after call (a missing event would show as a race), for one and two lanes."""
-    from counterfactualworldmodels_amd import _lib
-
-    lib = _lib.get_lib()
     g = np.load(os.path.join(GOLDEN, "conj_imu400_b2.npz"))
     cfg = C.CONJ_CONFIGS["imu400_base_4x4patch_2frames_1tube"]
     m = build(cfg, int(g["seed"]))
@@ -227,14 +218,10 @@ def test_context_side_stream_is_bitwise_neutral():
     mc = torch.zeros(B, 25, dtype=torch.bool, device="cuda")
     mc[2, 5] = True
     m(x[:1], mask[:1], x_context=imu[:1], mask_context=mc[:1])   # creates the library handle
-    try:
-        for lanes in (2, 1):
-            m.set_lanes(lanes)
-            _lib.check(lib.cwm_debug_set(b"conj_ctx_stream", 0))
-            ref = m(x, mask, x_context=imu, mask_context=mc)
-            _lib.check(lib.cwm_debug_set(b"conj_ctx_stream", 1))
-            for rep in range(4):
-                assert torch.equal(m(x, mask, x_context=imu, mask_context=mc), ref), (lanes, rep)
-    finally:
-        _lib.check(lib.cwm_debug_set(b"conj_ctx_stream", 1))
-        m.set_lanes(2)
+    for lanes in (2, 1):
+        m.set_lanes(lanes)
+        m.set_option("conj_ctx_stream", 0)
+        ref = m(x, mask, x_context=imu, mask_context=mc)
+        m.set_option("conj_ctx_stream", 1)
+        for rep in range(4):
+            assert torch.equal(m(x, mask, x_context=imu, mask_context=mc), ref), (lanes, rep)

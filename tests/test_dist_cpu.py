@@ -154,6 +154,40 @@ def test_chunks_are_row_ranges_of_the_local_block():
     assert CALLS == [4, 4, 2]
 
 
+def test_gather_pointer_arithmetic_for_every_rank_of_the_8_gpu_layout():
+    """`RcclComm.gather_args` (the pointer arithmetic behind cwm_allgather / cwm_allgatherv) for every rank of the layouts the multi-GPU node will
+    see first: 256 prompts on 2 / 4 / 8 ranks in chunks of 32 (equal blocks back to back -> ncclAllGather in place: send == recv + rank * bytes,
+    everything inside the result), and ragged layouts (250 prompts, empty shards) -> per-rank byte offsets that never overlap."""
+    row, base = 3 * 224 * 224 * 4, 0x7F0000000000
+    for world in (2, 4, 8):
+        bounds = [cdist.shard_range(256, r, world) for r in range(world)]
+        n_chunks = -(-max(h - l for l, h in bounds) // 32)
+        assert n_chunks == 8 // world
+        for c in range(n_chunks):
+            offs = [min(l + c * 32, h) for l, h in bounds]
+            cnts = [min(l + (c + 1) * 32, h) - o for (l, h), o in zip(bounds, offs)]
+            assert cnts == [32] * world
+            for r in range(world):
+                args = cdist.RcclComm.gather_args(base, row, offs, cnts, r)
+                if world == 8:  # one chunk per rank: the blocks are back to back -> the ring collective, in place
+                    kind, send, recv, nbytes = args
+                    assert kind == "allgather" and nbytes == 32 * row
+                    assert send == recv + r * nbytes and recv == base
+                    assert recv + world * nbytes == base + 256 * row
+                else:           # chunk c of every rank: equal blocks 256 / world rows apart -> per-root broadcasts at byte offsets
+                    kind, send, recv, o, n = args
+                    assert kind == "allgatherv" and recv == base and n == [32 * row] * world
+                    assert o == [(q * (256 // world) + 32 * c) * row for q in range(world)] and send == base + o[r]
+    for total, world in ((250, 8), (3, 8), (33, 4)):
+        bounds = [cdist.shard_range(total, r, world) for r in range(world)]
+        offs, cnts = [l for l, _ in bounds], [h - l for l, h in bounds]
+        for r in range(world):
+            kind, send, recv, o, n = cdist.RcclComm.gather_args(base, row, offs, cnts, r)
+            assert kind == "allgatherv" and recv == base and n == [k * row for k in cnts] and o == [k * row for k in offs]
+            assert (send is None) == (cnts[r] == 0) and (send is None or send == base + offs[r] * row)
+            assert sum(n) == total * row and max(a + b for a, b in zip(o, n)) == total * row
+
+
 def test_shard_range_partitions():
     for total in (0, 1, 7, 256, 257):
         for world in (1, 2, 3, 8):

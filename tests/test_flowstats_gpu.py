@@ -100,12 +100,63 @@ def test_option_prologues_match_reference_outputs():
     assert (slab - full[:, 3:10]).abs().max().item() <= TOL * max(1.0, full.abs().max().item())
 
 
-def test_unsupported_options_fail_loudly():
-    fl = torch.zeros(1, 2, 8, 8, 4, device="cuda")
-    with pytest.raises(NotImplementedError):
-        FS.compute_flow_corrs(fl, distance_func=lambda a, b: (a - b).abs().mean(1, True))   # only the reference's default features run on the device
+def test_user_distance_func_and_nan_columns():
+    """`compute_flow_corrs(distance_func=<callable>)` (segmentation.py:485, :503-513): the caller's function runs as PyTorch on the device over the
+    pooled samples, its [B, P, S] result goes through the device prologues / covariance -- against the oracle's restatement with the same callable
+    (the reference's own default passed explicitly must reproduce the fused default path).  And the NaN semantics of the prologues as torch has
+    them: argsort orders NaNs last (always a permutation), amax / clamp / std propagate a NaN column, one position (P = 1) z-scores to NaN, and
+    every NaN of the matrix becomes 0 (segmentation.py:541)."""
+    g = torch.Generator().manual_seed(21)
+    fl = torch.randn(2, 2, 16, 24, 12, generator=g)
+    dev = fl.cuda()
+
+    def l1(a, b):
+        return (a - b).abs().mean(1, True)
+
+    def channel_mse(a, b):   # utils.ChannelMSE(dim=1) restated: sqrt(mean_c((a - b)^2))
+        return (a - b).square().mean(1, True).sqrt()
+
+    for fn, kw in ((l1, dict(use_covariance=True)), (l1, dict(zscore=True, downsample=2)), (channel_mse, dict(use_covariance=True, downsample=2))):
+        out = FS.compute_flow_corrs(dev, distance_func=fn, **kw).cpu()
+        ds = kw.get("downsample", 1)
+        pooled = torch.nn.functional.avg_pool3d(fl.permute(0, 1, 4, 2, 3), (1, ds, ds), stride=(1, ds, ds)).permute(0, 1, 3, 4, 2)
+        x = fn(pooled, torch.zeros_like(pooled)).reshape(2, -1, 12)
+        ref = []
+        for b in range(2):
+            xb = x[b]
+            if kw.get("zscore"):
+                xb = (xb - xb.mean(0)[None]) / xb.std(0).clamp(min=1e-12)[None]
+            c = torch.cov(xb) if kw.get("use_covariance") else torch.corrcoef(xb)
+            c[torch.isnan(c)] = 0
+            ref.append(c)
+        ref = torch.stack(ref).view(out.shape)
+        assert (out - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item()), (fn.__name__, kw)
+    same = FS.compute_flow_corrs(dev, distance_func=channel_mse, use_covariance=True, downsample=2)
+    assert (same - FS.compute_flow_corrs(dev, use_covariance=True, downsample=2)).abs().max().item() <= TOL
+    # NaN semantics
+    x = torch.randn(1, 6, 9, generator=g)
+    x[0, 2, 4] = float("nan")
+    x[0, 2, 7] = float("nan")
+    x[0, 5, 0] = float("nan")
+    xr = FS.transform_features(x.cuda().clone(), do_spearman=True).cpu()
+    assert torch.equal(xr, torch.argsort(x, dim=-1, stable=True).float())          # NaNs last, in index order: a permutation in every row
+    xn = FS.transform_features(x.cuda().clone(), normalize=True).cpu()
+    ref = x[0] / x[0].amax(0, True).clamp(min=1e-12)
+    assert torch.equal(torch.isnan(xn[0]), torch.isnan(ref)) and (torch.nan_to_num(xn[0]) - torch.nan_to_num(ref)).abs().max().item() <= 1e-6
+    xz = FS.transform_features(x.cuda().clone(), zscore=True).cpu()
+    ref = (x[0] - x[0].mean(0)[None]) / x[0].std(0).clamp(min=1e-12)[None]
+    assert torch.equal(torch.isnan(xz[0]), torch.isnan(ref)) and (torch.nan_to_num(xz[0]) - torch.nan_to_num(ref)).abs().max().item() <= 1e-5
+    one = FS.transform_features(torch.randn(1, 1, 5, generator=g).cuda(), zscore=True)                                # P = 1: std = NaN
+    assert torch.isnan(one).all()
+    c = FS.compute_flow_corrs(torch.randn(1, 2, 1, 1, 5, generator=g).cuda(), zscore=True, use_covariance=True)      # ... and the matrix is 0
+    assert c.shape == (1, 1, 1, 1, 1, 1) and c.item() == 0.0
+
+
+def test_unsupported_inputs_fail_loudly():
     with pytest.raises(RuntimeError):
         FS.compute_flow_corrs(torch.zeros(1, 2, 8, 8, 4))   # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        FS.compute_flow_corrs(torch.zeros(1, 2, 8, 8, 4), distance_func=lambda a, b: (a - b).abs().mean(1, True))
 
 
 def test_full_grid_properties():

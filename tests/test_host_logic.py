@@ -209,27 +209,80 @@ def test_bench_helpers_on_cpu(tmp_path, monkeypatch):
     assert r.returncode == 2 and "launcher started 1" in r.stderr
 
 
-def test_hand_placed_lds_waits_cover_every_asm_read():
-    """tools/asm_lds_lint.py on the gfx950 ISA of attention_pipe.hip (hipcc cross-compiles without a GPU): no instruction reads a register that an inline-asm
-    `ds_read_b64_tr_b16` writes before the hand-counted `s_waitcnt lgkmcnt` that covers the read.  hipcc does not know these registers are written late and may
-    copy them; round 4 shipped such a copy for a few hours (5 % of the ViT-L/4 batch-8 forwards wrong in one sample, two lanes only)."""
+def _lint():
     import shutil
+    import sys
 
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         pytest.skip("hipcc not available")
-    import sys
-
     tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
     if tools not in sys.path:
         sys.path.insert(0, tools)
     import asm_lds_lint
 
+    return asm_lds_lint
+
+
+def test_hand_placed_lds_waits_cover_every_asm_read():
+    """tools/asm_lds_lint.py on the gfx950 ISA of attention_pipe.hip (hipcc cross-compiles without a GPU): no instruction reads a register that an inline-asm
+    `ds_read_b64_tr_b16` writes before the hand-counted `s_waitcnt lgkmcnt` that covers the read, and no branch or label sits between such a read and its
+    wait.  hipcc does not know these registers are written late and may copy them at a control-flow merge; round 4 shipped such a copy for a few hours (5 % of
+    the ViT-L/4 batch-8 forwards wrong in one sample, two lanes only)."""
+    asm_lds_lint = _lint()
     text = asm_lds_lint.compile_isa("attention_pipe.hip")
-    assert text.count("ds_read_b64_tr_b16") > 100          # the lint looks at the code it is meant for
+    assert len(__import__("re").findall(r";;#ASMSTART\n\s*ds_read_b64_tr_b16", text)) > 100          # the lint looks at the code it is meant for
     hits = asm_lds_lint.lint_isa(text)
     assert not hits, hits[:5]
-    # the rule fires on the hazard: a use between the read and its wait
-    bad = "_Zk:\n\tds_read_b64_tr_b16 v[4:5], v1\n\tv_mov_b64_e32 v[8:9], v[4:5]\n\ts_waitcnt lgkmcnt(0)\n\ts_endpgm\n"
+    A, E = ";;#ASMSTART\n", ";;#ASMEND\n"
+    rd = lambda r, a="v1": A + "\tds_read_b64_tr_b16 %s, %s\n" % (r, a) + E
+    wt = lambda n: A + "\ts_waitcnt lgkmcnt(%d)\n" % n + E
+    # the rules fire on the hazards: a use between the read and its wait ...
+    bad = "_Zk:\n" + rd("v[4:5]") + "\tv_mov_b64_e32 v[8:9], v[4:5]\n" + wt(0) + "\ts_endpgm\n"
     assert len(asm_lds_lint.lint_isa(bad)) == 2
-    ok = "_Zk:\n\tds_read_b64_tr_b16 v[4:5], v1\n\tds_read_b64_tr_b16 v[6:7], v1\n\ts_waitcnt lgkmcnt(1)\n\tv_mov_b64_e32 v[8:9], v[4:5]\n\ts_waitcnt lgkmcnt(0)\n\ts_endpgm\n"
+    # ... a branch or a label (control-flow merge) with a read outstanding ...
+    bad = "_Zk:\n" + rd("v[4:5]") + "\ts_cbranch_vccnz .LBB0_2\n\tv_mfma_f32_32x32x16_bf16 v[10:25], v[30:33], v[34:37], v[10:25]\n.LBB0_2:\n" + wt(0) + "\ts_endpgm\n"
+    assert [h[3] for h in asm_lds_lint.lint_isa(bad)] == [-1, -1]
+    # ... and a compiler-issued LDS read behind the asm ones shifts what a counted wait retires
+    bad = "_Zk:\n" + rd("v[4:5]") + "\tds_read_b128 v[40:43], v2\n" + wt(1) + "\tv_mov_b64_e32 v[8:9], v[4:5]\n" + wt(0) + "\ts_endpgm\n"
+    assert asm_lds_lint.lint_isa(bad) == []          # (one younger operation may stay outstanding: the asm read itself has returned)
+    bad = "_Zk:\n" + rd("v[4:5]") + rd("v[6:7]") + "\tds_read_b128 v[40:43], v2\n" + wt(2) + "\tv_mov_b64_e32 v[8:9], v[6:7]\n" + wt(0) + "\ts_endpgm\n"
+    assert len(asm_lds_lint.lint_isa(bad)) == 2      # lgkmcnt(2) leaves v[6:7] and the b128 in flight
+    ok = "_Zk:\n" + rd("v[4:5]") + rd("v[6:7]") + wt(1) + "\tv_mov_b64_e32 v[8:9], v[4:5]\n" + wt(0) + "\ts_cbranch_scc1 .LBB0_1\n.LBB0_1:\n\ts_endpgm\n"
     assert asm_lds_lint.lint_isa(ok) == []
+    # compiler-managed transposed reads (the builtin: no ASMSTART) are the compiler's business
+    ok = "_Zk:\n\tds_read_b64_tr_b16 v[4:5], v1\n\ts_cbranch_scc1 .LBB0_1\n.LBB0_1:\n\ts_waitcnt lgkmcnt(0)\n\ts_endpgm\n"
+    assert asm_lds_lint.lint_isa(ok) == []
+
+
+def test_counted_vmcnt_waits_match_the_lds_dma_the_compiler_emitted():
+    """The second family of hand-counted waits: LDS-DMA (`global_load_lds_dwordx4`) kept in flight across raw barriers and retired by `s_waitcnt vmcnt(N)`
+    (gemm.hip: the 8-phase kernel's vmcnt(6), the deep-ring kernel's vmcnt(2 PER) / vmcnt(PER)).  N counts instructions, so the ISA of every such loop must
+    hold exactly the pieces the source counted and no other vector-memory instruction (a spill, a hoisted or duplicated piece).  Fires on a synthetic fault of
+    each kind; the compiler a build uses is compared with the one this lint last passed on (csrc/LINT_PASSED.json, build.check_lint_record)."""
+    asm_lds_lint = _lint()
+    from counterfactualworldmodels_amd import build
+
+    text = asm_lds_lint.compile_isa("gemm.hip")
+    import re
+
+    assert len(re.findall(r";;#ASMSTART\n\s*s_waitcnt vmcnt\([1-9]", text)) >= 12   # 2 x (prologue + loop) of the 8-phase kernel, 2 per deep-ring kernel
+    assert asm_lds_lint.lint_vmcnt(text) == []
+    assert asm_lds_lint.lint_isa(text) == []
+    # every kernel with a counted wait has a spec derived from its template arguments
+    for name in re.findall(r"^(_Z\w+):", text, flags=re.M):
+        if "gemm8p_kernel" in name:
+            assert asm_lds_lint.vmcnt_spec(name)["loop"] == {6: (8, 8)}
+    first = text.index("_ZN3cwm13gemm8p_kernelILi2EEEvNS_10GemmParamsE:")
+    loop = text.index("Loop Header", first)
+    piece = text.index("global_load_lds_dwordx4", loop)
+    eol = text.index("\n", piece)
+    spill = text[:eol + 1] + "\tscratch_store_dword off, v1, off offset:4\n" + text[eol + 1:]
+    assert any("vector-memory instruction inside a loop" in h[2] for h in asm_lds_lint.lint_vmcnt(spill))
+    dup = text[:eol + 1] + "\t" + text[piece:eol + 1] + text[eol + 1:]
+    assert any("9 LDS-DMA" in h[2] for h in asm_lds_lint.lint_vmcnt(dup))
+    imm = text[:first] + text[first:].replace("s_waitcnt vmcnt(6)", "s_waitcnt vmcnt(7)")
+    assert any("vmcnt(7) is not one the source places" in h[2] for h in asm_lds_lint.lint_vmcnt(imm))
+    # the record of the compiler the lint passed on is current (re-run `python tools/asm_lds_lint.py --record` after a toolchain bump)
+    rec = build.lint_record()
+    assert rec.get("hipcc") == build.hipcc_version(), "csrc/LINT_PASSED.json names another compiler: %r" % rec.get("hipcc")
+    assert build.check_lint_record(verbose=False)

@@ -279,30 +279,85 @@ def test_weight_edits_are_detected_without_walking_the_state_dict():
 
 def test_qkv_epilogue_variants_agree_end_to_end():
     """Direct, LDS-staged and per-fragment GEMM epilogues (QKV head scatter included) and every tile configuration: same forward output,
-    bit for bit (all of them apply the same product sequence to every accumulator)."""
+    bit for bit (all of them apply the same product sequence to every accumulator).  The options are per model handle (cwm_model_set_option)."""
     g = np.load(os.path.join(GOLDEN, "tiny_8x8_k4.npz"))
     seed, x, mask = case_inputs(g, TINY)
-    lib = _lib.get_lib()
     outs = {}
-    try:
-        for mode in ("parity", "fast"):
-            m = build(TINY, seed, mode=mode)
-            G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
-            for staged, direct in ((1, 1), (1, 0), (0, 0), (1, 2)):
-                for tile in (0, 1, 3, 4):
-                    _lib.check(lib.cwm_debug_set(b"gemm_staged", staged))
-                    _lib.check(lib.cwm_debug_set(b"gemm_direct", direct))
-                    _lib.check(lib.cwm_debug_set(b"gemm_tile", tile))
-                    outs[(mode, staged * 10 + direct, tile)] = m(G._preprocess(x.cuda()), mask.cuda()).cpu()
-            ref = outs[(mode, 11, 0)]
-            for key, y in outs.items():
-                if key[0] == mode:
-                    assert torch.equal(y, ref), key
-    finally:
-        _lib.check(lib.cwm_debug_set(b"gemm_staged", 1))
-        _lib.check(lib.cwm_debug_set(b"gemm_direct", 1))
-        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
+    for mode in ("parity", "fast"):
+        m = build(TINY, seed, mode=mode)
+        G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+        for staged, direct in ((1, 1), (1, 0), (0, 0), (1, 2)):
+            for tile in (0, 1, 4, 6):
+                m.set_option("gemm_staged", staged)
+                m.set_option("gemm_direct", direct)
+                m.set_option("gemm_tile", tile)
+                outs[(mode, staged * 10 + direct, tile)] = m(G._preprocess(x.cuda()), mask.cuda()).cpu()
+        ref = outs[(mode, 11, 0)]
+        for key, y in outs.items():
+            if key[0] == mode:
+                assert torch.equal(y, ref), key
     assert np.abs(outs[("parity", 11, 0)].numpy() - g["y_tokens"]).max() <= 2e-4
+
+
+def test_fused_index_prologue_is_bitwise_equal_to_the_four_launches():
+    """Round 5: mask -> permutation, its inverse, the per-row visible-count check and the patch gather run as ONE launch (index_gather_kernel)
+    instead of memset + mask_to_perm + patch_gather + perm_to_rank.  Same tokens, same video, bit for bit, for the tiny model and ViT-B/8 (one and two
+    lanes), with the un-embed (which reads the inverse permutation) and without; a row with the wrong visible count is still refused, whichever row of
+    whichever lane it is in, and a later good call on the same handle is unaffected (the row words are rewritten by every call: no memset)."""
+    for cfg, name in ((TINY, "tiny_8x8_k4.npz"), (C.CONFIGS["base_8x8patch_2frames_1tube"], "base8_k8_b2.npz")):
+        g = np.load(os.path.join(GOLDEN, name))
+        seed, x, mask = case_inputs(g, cfg)
+        reps = 5 if cfg is TINY else 8   # ViT-B/8: batch 16 = two lanes
+        xb, mb = x.repeat(reps, 1, 1, 1, 1).cuda(), mask.repeat(reps, 1).cuda()
+        m = build(cfg, seed)
+        outs = []
+        for fused in (1, 0):
+            m.set_option("index_fused", fused)
+            tok, vid = m.predict_video(xb, mb)
+            outs.append((tok.clone(), vid.clone(), m(prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)._preprocess(xb), mb).clone()))
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b), name
+        m.set_option("index_fused", 1)
+        for bad_row in (0, xb.shape[0] - 1):
+            bad = mb.clone()
+            col = int(torch.nonzero(bad[bad_row])[0])
+            bad[bad_row, col] = False   # one more visible token in one row
+            with pytest.raises(_lib.CwmHipError) as ei:
+                m.predict_video(xb, bad)
+            assert ei.value.code == _lib.ERR_MASK
+            tok, vid = m.predict_video(xb, mb)
+            assert torch.equal(tok, outs[0][0]) and torch.equal(vid, outs[0][1])
+
+
+def test_options_are_per_model_handle():
+    """Two models in one process with different execution options do not see each other's settings (until round 4 the switches were process-wide
+    globals).  Model A is forced onto the 256x256 8-phase GEMM kernel and the 4-wave attention kernel, model B keeps the defaults (which never pick
+    the 8-phase kernel for this small model); called alternately, the per-handle kernel timers show A's launches on the wide kernel and none of B's,
+    both reproduce their own results bit for bit, and an unknown option is refused."""
+    g = np.load(os.path.join(GOLDEN, "tiny_8x8_k4.npz"))
+    seed, x, mask = case_inputs(g, TINY)
+    a, b = build(TINY, seed), build(TINY, seed)
+    G = prediction.PredictorBasedGenerator(predictor=a, imagenet_normalize_inputs=True, temporal_dim=2)
+    xp, mk = G._preprocess(x.cuda()), mask.cuda()
+    a.set_option("attn_kernel", 1)   # before the first forward: applied when the handle is created
+    ya, yb = a(xp, mk), b(xp, mk)
+    a.set_option("gemm_tile", 4)     # on the live handle
+    for m in (a, b):
+        m.timing_enable(_lib.KCLASS_GEMM, True)
+    for _ in range(3):
+        assert torch.equal(a(xp, mk), ya)   # (every tile configuration is bit-identical: test above)
+        assert torch.equal(b(xp, mk), yb)
+    wide = {}
+    for name, m in (("a", a), ("b", b)):
+        m.timing_collect(_lib.KCLASS_GEMM)
+        wide[name] = (m.timing_collect(_lib.KCLASS_GEMM_WIDE)["launches"], m.timing_collect(_lib.KCLASS_GEMM_NARROW)["launches"])
+        m.timing_enable(_lib.KCLASS_GEMM, False)
+    assert wide["a"][0] > 0 and wide["a"][1] == 0, wide
+    assert wide["b"][0] == 0 and wide["b"][1] > 0, wide
+    assert (ya - yb).abs().max().item() <= 5e-5
+    with pytest.raises(RuntimeError):
+        b.set_option("no_such_option", 1)
+    assert torch.equal(b(xp, mk), yb)
 
 
 def test_nothing_masked_returns_all_tokens():
@@ -326,41 +381,30 @@ def test_last_decoder_block_pruning_is_exact():
     the pruned GEMMs have fewer rows, so the small-launch heuristic may split K differently and re-associate the fp32 sums -- and with
     every attention tile on the regular schedule: pruning changes WHICH query rows form the ragged last tile, whose key-split
     schedule (attention_tail.h) rounds P at other values.  In the default configuration the two agree to rounding.)"""
-    lib = _lib.get_lib()
     cases = [(TINY, "tiny_8x8_k4.npz"), (C.CONFIGS["base_8x8patch_2frames_1tube"], "base8_k8_b2.npz")]
-    try:
-        _lib.check(lib.cwm_debug_set(b"gemm_debug", 32))
-        _lib.check(lib.cwm_debug_set(b"attn_tail", 0))
-        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 0))
-        for cfg, name in cases:
-            g = np.load(os.path.join(GOLDEN, name))
-            seed, x, mask = case_inputs(g, cfg)
-            for mode in ("parity", "fast"):
-                m = build(cfg, seed, mode)
-                G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
-                outs = []
-                for prune in (1, 0):
-                    _lib.check(lib.cwm_debug_set(b"prune_last_block", prune))
-                    outs.append(m(G._preprocess(x.cuda()), mask.cuda()).cpu())
-                assert torch.equal(outs[0], outs[1]), (name, mode, (outs[0] - outs[1]).abs().max().item())
-        _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
-        _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
-        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1))
-        for cfg, name in cases:  # library defaults (split-K where the heuristic takes it, key-split attention tails): equal to rounding
-            g = np.load(os.path.join(GOLDEN, name))
-            seed, x, mask = case_inputs(g, cfg)
-            m = build(cfg, seed, "parity")
+    for cfg, name in cases:
+        g = np.load(os.path.join(GOLDEN, name))
+        seed, x, mask = case_inputs(g, cfg)
+        for mode in ("parity", "fast"):
+            m = build(cfg, seed, mode)
+            for k, v in (("gemm_debug", 32), ("attn_tail", 0), ("attn_ksplit", 0)):
+                m.set_option(k, v)
             G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
             outs = []
             for prune in (1, 0):
-                _lib.check(lib.cwm_debug_set(b"prune_last_block", prune))
+                m.set_option("prune_last_block", prune)
                 outs.append(m(G._preprocess(x.cuda()), mask.cuda()).cpu())
-            assert (outs[0] - outs[1]).abs().max().item() <= 5e-5
-    finally:
-        _lib.check(lib.cwm_debug_set(b"prune_last_block", 1))
-        _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
-        _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
-        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1))
+            assert torch.equal(outs[0], outs[1]), (name, mode, (outs[0] - outs[1]).abs().max().item())
+    for cfg, name in cases:  # library defaults (split-K where the heuristic takes it, key-split attention tails): equal to rounding
+        g = np.load(os.path.join(GOLDEN, name))
+        seed, x, mask = case_inputs(g, cfg)
+        m = build(cfg, seed, "parity")
+        G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+        outs = []
+        for prune in (1, 0):
+            m.set_option("prune_last_block", prune)
+            outs.append(m(G._preprocess(x.cuda()), mask.cuda()).cpu())
+        assert (outs[0] - outs[1]).abs().max().item() <= 5e-5
 
 
 def test_two_lanes_match_one_lane_and_report_mask_errors_of_both():

@@ -312,3 +312,44 @@ def test_rccl_comm_single_rank_on_device():
         assert y.shape == (3, 1, 3, 32, 32)
     finally:
         comm.close()
+
+
+def test_rccl_gather_block_layouts_on_one_rank():
+    """What breaks first on a multi-GPU node is pointer arithmetic.  The 8-rank / 256-prompt gather is `ncclAllGather` in place over 8 equal
+    blocks of 32 rows, rank r's block at row 32 r (dist.py `RcclComm.gather_args`); the other shapes take the grouped-broadcast
+    `cwm_allgatherv` with per-rank byte offsets.  One GPU cannot host 8 ranks (RCCL refuses two ranks on a device), so: (a) the pure pointer
+    function is checked for every rank of the 8-rank layout (tests/test_dist_cpu.py does the same without a GPU), and (b) the REAL collectives
+    run on a one-rank communicator whose single block sits where rank r's would -- rows 32 r .. 32 r + 31 of the 256-row result, and ragged
+    offsets for the allgatherv form -- and must leave that block intact and every other row untouched (an off-by-a-block send / receive
+    pointer would move data)."""
+    comm = cdist.RcclComm(0, 1, cdist.RcclComm.new_unique_id(), torch.device("cuda:0"))
+    try:
+        rows, width = 256, 3 * 224 * 2  # (a narrow stand-in for the [256, 1, 3, 224, 224] result: the arithmetic is in rows)
+        for r in range(8):
+            out = torch.full((rows, width), -1.0, device="cuda")
+            block = torch.randn(32, width, device="cuda")
+            out[32 * r:32 * r + 32] = block
+            ref = out.clone()
+            kind, send, recv, nbytes = cdist.RcclComm.gather_args(out.data_ptr(), width * 4, [32 * q for q in range(8)], [32] * 8, r)
+            assert kind == "allgather" and send == out.data_ptr() + r * 32 * width * 4 and recv == out.data_ptr() and nbytes == 32 * width * 4
+            comm.all_gather_rows(out, [32 * r], [32])        # the one-rank communicator's block = rank r's slot
+            assert comm.last_collective == "ncclAllGather"
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), r
+        # ragged: 250 prompts on 8 ranks = 32, 32, 31 ... rows; chunk 1 of a 2-chunk schedule: some ranks have nothing left
+        for offs, cnts in (([100], [31]), ([7], [1]), ([255], [1])):
+            out = torch.full((rows, width), -1.0, device="cuda")
+            out[offs[0]:offs[0] + cnts[0]] = 2.0
+            ref = out.clone()
+            # (a one-block layout is "equal and contiguous" by definition: force the allgatherv form through the C ABI directly)
+            import ctypes as C
+
+            from counterfactualworldmodels_amd import _lib
+
+            sizes = (C.c_size_t * 1)(cnts[0] * width * 4)
+            o = (C.c_size_t * 1)(offs[0] * width * 4)
+            _lib.check(_lib.get_lib().cwm_allgatherv(comm._handle, out.data_ptr() + offs[0] * width * 4, out.data_ptr(), o, sizes, comm._stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (offs, cnts)
+    finally:
+        comm.close()

@@ -14,7 +14,7 @@ x = torch.from_numpy(S.synthetic_frames(B, cfg.main, 0)).cuda().transpose(1, 2)
 mask = torch.from_numpy(S.synthetic_masks(B, cfg.main, 4, 0)).cuda()
 imu = (torch.randn(B, 6, 400, generator=torch.Generator().manual_seed(0)) * 0.1).cuda()
 mc = torch.zeros(B, 25, dtype=torch.bool, device="cuda")
-lib = _lib.get_lib()
+lib = _lib.get_dev_lib()
 step = lambda: m(x, mask, x_context=imu, mask_context=mc, normalize=True, check=False)
 step()
 m.set_lanes(lanes)
@@ -26,7 +26,7 @@ def run():
 ys = {}
 for rep in range(3):
     for v in (va, vb):
-        _lib.check(lib.cwm_debug_set(key, v))
+        m.set_option(key.decode() if isinstance(key, bytes) else key, v)
         dt = run()
         ys[v] = step()
         print("%s=%d lanes %d: %.3f ms/step  %.1f frames/s" % (key.decode(), v, lanes, 1e3 * dt, B / dt), flush=True)

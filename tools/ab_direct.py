@@ -14,7 +14,7 @@ from counterfactualworldmodels_amd import _lib  # noqa: E402
 from tools.microbench import GEMM_SHAPES, MID_SHAPES, L4_SHAPES, B1_SHAPES  # noqa: E402
 
 torch.cuda.init()
-lib = _lib.get_lib()
+lib = _lib.get_dev_lib()
 
 
 def setk(key, v):

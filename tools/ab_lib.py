@@ -1,4 +1,5 @@
-"""Same-box A/B of two builds of the library: python tools/ab_lib.py LIB_A LIB_B [gemm|attn|step ...]  (each measured in its own child process,
+"""Same-box A/B of two builds of the library (same C ABI; side builds: CWM_HIP_LIB_OUT=... python -m counterfactualworldmodels_amd.build, which also writes
+<name>_dev.so): python tools/ab_lib.py LIB_A LIB_B [gemm|attn|step ...]  (each measured in its own child process,
 alternating A B A B).  gemm: the ViT-B/8 GEMM shapes, parity mode, default tile rule; attn: the attention shapes, both modes; step: the
 ViT-B/8 batch-32 step on two lanes and on one."""
 import os
@@ -13,7 +14,7 @@ from counterfactualworldmodels_amd import _lib, config as CF, synthetic as S, vm
 from tools.microbench import ATTN_SHAPES, GEMM_SHAPES
 what = sys.argv[1].split(",")
 torch.cuda.init()
-lib = _lib.get_lib(); us = C.c_double()
+lib = _lib.get_dev_lib(); us = C.c_double()
 if "gemm" in what:
     for name, M, N, K, epi in GEMM_SHAPES:
         best = 1e30
@@ -50,7 +51,7 @@ if "step" in what:
 what = ",".join(sys.argv[3:]) or "gemm,step"
 for rep in range(2):
     for tag, lib in (("A", sys.argv[1]), ("B", sys.argv[2])):
-        env = dict(os.environ, CWM_HIP_LIB=os.path.abspath(lib))
+        env = dict(os.environ, CWM_HIP_LIB=os.path.abspath(lib))  # (its development twin <name>_dev.so is found beside it: _lib.dev_library_path)
         out = subprocess.run([sys.executable, "-c", CHILD, what], env=env, capture_output=True, text=True)
         for line in out.stdout.strip().split("\n"):
             print("%s%d %-22s %s" % (tag, rep, os.path.basename(lib), line), flush=True)

@@ -15,7 +15,7 @@ m = m.cuda().eval()
 x = torch.from_numpy(S.synthetic_frames(B, cfg, 0)).cuda()
 mask = torch.from_numpy(S.synthetic_masks(B, cfg, kv, 0, clump)).cuda()
 nv = cfg.tokens_per_frame + kv
-lib = _lib.get_lib()
+lib = _lib.get_dev_lib()
 m.predict_video(x, mask, n_vis=nv)
 m.set_lanes(lanes)
 DEFAULTS = {"gemm_debug": 0, "gemm_tile": 0, "attn_ksplit": 1, "attn_tail": 1}
@@ -26,7 +26,7 @@ def run():
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / 20
 for rep in range(3):
     for st, label in zip(settings, sys.argv[2:]):
-        for k in keys: _lib.check(lib.cwm_debug_set(k.encode(), DEFAULTS.get(k, 0)))
-        for k, v in st: _lib.check(lib.cwm_debug_set(k.encode(), int(v)))
+        for k in keys: m.set_option(k, DEFAULTS.get(k, 0))
+        for k, v in st: m.set_option(k, int(v))
         dt = run()
         print("%-36s lanes %d: %.3f ms/step  %.0f frames/s" % (label, lanes, 1e3 * dt, B / dt), flush=True)

@@ -14,7 +14,7 @@ m = m.cuda().eval()
 x = torch.from_numpy(S.synthetic_frames(B, cfg, 0)).cuda()
 mask = torch.from_numpy(S.synthetic_masks(B, cfg, kv, 0, clump)).cuda()
 nv = cfg.tokens_per_frame + kv
-lib = _lib.get_lib()
+lib = _lib.get_dev_lib()
 m.predict_video(x, mask, n_vis=nv)
 m.set_lanes(lanes)
 def run():
@@ -24,6 +24,6 @@ def run():
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / 20
 for rep in range(3):
     for v in (va, vb):
-        _lib.check(lib.cwm_debug_set(key, v))
+        m.set_option(key.decode() if isinstance(key, bytes) else key, v)
         dt = run()
         print("%s=%d lanes %d: %.3f ms/step  %.0f frames/s" % (key.decode(), v, lanes, 1e3 * dt, B / dt), flush=True)

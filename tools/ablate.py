@@ -10,7 +10,7 @@ from counterfactualworldmodels_amd import _lib  # noqa: E402
 
 M, N, epi, tile = (int(v) for v in sys.argv[1:5])
 torch.cuda.init()
-lib = _lib.get_lib()
+lib = _lib.get_dev_lib()
 us = C.c_double()
 _lib.check(lib.cwm_debug_set(b"gemm_tile", tile))
 for mode in ("fast", "parity"):

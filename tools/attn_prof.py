@@ -10,7 +10,7 @@ import torch  # noqa: E402
 from counterfactualworldmodels_amd import _lib  # noqa: E402
 
 torch.cuda.init()
-lib = _lib.get_lib()
+lib = _lib.get_dev_lib()
 us = C.c_double()
 B, H, N = (int(v) for v in sys.argv[1:4])
 _lib.check(lib.cwm_debug_set(b"attn_kernel", 3))

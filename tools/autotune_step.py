@@ -24,7 +24,9 @@ m = m.cuda().eval()
 x = torch.from_numpy(S.synthetic_frames(B, cfg, 0)).cuda()
 mask = torch.from_numpy(S.synthetic_masks(B, cfg, kv, 0, clump)).cuda()
 nv = cfg.tokens_per_frame + kv
-lib = _lib.get_lib()
+lib = _lib.get_dev_lib()
+_lib.check(lib.cwm_gemm_tile_override(0, 0, 0, 0, 0, 0), lib)  # installs the per-shape hook in this thread's options ...
+m.use_library(lib)                                             # ... which the model's handle, created in the dev library, starts from
 m.predict_video(x, mask, n_vis=nv)
 m.set_lanes(lanes)
 

@@ -14,11 +14,11 @@ imu = (torch.randn(B, 6, 400, generator=torch.Generator().manual_seed(0)) * 0.1)
 mc = torch.zeros(B, 25, dtype=torch.bool, device="cuda")
 step = lambda: m(x, mask, x_context=imu, mask_context=mc, normalize=True, check=False)
 step(); step()
-lib = _lib.get_lib()
+lib = _lib.get_dev_lib()
 for lanes in (2, 1):
     m.set_lanes(lanes)
     for ctx in (1, 0):
-        _lib.check(lib.cwm_debug_set(b"conj_ctx_stream", ctx))
+        m.set_option("conj_ctx_stream", ctx)
         step(); torch.cuda.synchronize()
         n = 6
         t0 = time.perf_counter()
@@ -28,4 +28,4 @@ for lanes in (2, 1):
         torch.cuda.synchronize(); t3 = time.perf_counter(); step(); t4 = time.perf_counter(); torch.cuda.synchronize(); t5 = time.perf_counter()
         print("lanes %d ctx_stream %d: %.2f ms/step; host issue of %d queued calls %.2f ms each; one call on an empty queue: host %.2f ms, GPU done after %.2f ms" % (
             lanes, ctx, 1e3 * (t2 - t0) / n, n, 1e3 * (t1 - t0) / n, 1e3 * (t4 - t3), 1e3 * (t5 - t3)), flush=True)
-_lib.check(lib.cwm_debug_set(b"conj_ctx_stream", 1))
+m.set_option("conj_ctx_stream", 1)

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from counterfactualworldmodels_amd import _lib  # noqa: E402
 
 torch.cuda.init()
-lib = _lib.get_lib()
+lib = _lib.get_dev_lib()
 us = C.c_double()
 M, N, K = (int(v) for v in sys.argv[1:4])
 mode, epi = sys.argv[4], int(sys.argv[5])

@@ -14,7 +14,7 @@ def main():
     M, N, epi = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     variants = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "1,3,4").split(",")]
     torch.cuda.init()
-    lib = _lib.get_lib()
+    lib = _lib.get_dev_lib()
     us = C.c_double()
     for mode in ("fast", "parity"):
         for v in variants:

@@ -8,13 +8,13 @@ cfg = C.CONFIGS["base_8x8patch_2frames_1tube"]
 m = vmae.PretrainVisionTransformer(cfg, mode="parity")
 m.load_state_dict({k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, 0).items()})
 m = m.cuda().eval()
-lib = _lib.get_lib()
+lib = _lib.get_dev_lib()
 for B in (1, 2, 4, 8):
     x = torch.from_numpy(S.synthetic_frames(B, cfg, 0)).cuda()
     mask = torch.from_numpy(S.synthetic_masks(B, cfg, 8, 0)).cuda()
     for rep in range(2):
         for v in (va, vb):
-            _lib.check(lib.cwm_debug_set(key, v))
+            m.set_option(key.decode() if isinstance(key, bytes) else key, v)
             for _ in range(5): m.predict_video(x, mask, n_vis=792, check=False)
             torch.cuda.synchronize(); n = 40; t0 = time.perf_counter()
             for _ in range(n): m.predict_video(x, mask, n_vis=792, check=False)

@@ -18,7 +18,7 @@ from counterfactualworldmodels_amd import _lib  # noqa: E402
 from tools.microbench import GEMM_SHAPES, L4_SHAPES  # noqa: E402
 
 torch.cuda.init()
-lib = _lib.get_lib()
+lib = _lib.get_dev_lib()
 us = C.c_double()
 dev = torch.device("cuda:0")
 

@@ -5,7 +5,7 @@ import torch
 from counterfactualworldmodels_amd import _lib
 from tools.microbench import ATTN_SHAPES
 torch.cuda.init()
-lib = _lib.get_lib(); us = C.c_double()
+lib = _lib.get_dev_lib(); us = C.c_double()
 for name, B, H, N in ATTN_SHAPES + [("b8.enc.half", 16, 12, 792), ("b8.dec.half", 16, 6, 1568), ("b8.dec.last", 32, 6, 1568)]:
     for mode in ("parity", "fast"):
         row = []

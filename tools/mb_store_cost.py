@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 import torch
 from counterfactualworldmodels_amd import _lib
 torch.cuda.init()
-lib = _lib.get_lib(); us = C.c_double()
+lib = _lib.get_dev_lib(); us = C.c_double()
 _lib.check(lib.cwm_debug_set(b"gemm_tile", 4))
 for (M, N, K, epi, name) in [(4096, 1024, 768, 3, "64 tiles (quarter chip) qkv-like"), (8192, 2048, 768, 3, "256 tiles (one round)"), (16384, 4096, 768, 3, "1024 tiles (4 rounds)"),
                              (4096, 1024, 768, 1, "64 tiles gelu"), (8192, 2048, 768, 1, "256 tiles gelu"), (16384, 4096, 768, 1, "1024 tiles gelu")]:

@@ -64,7 +64,7 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,3,4").split(",")]
     torch.cuda.init()
-    lib = _lib.get_lib()
+    lib = _lib.get_dev_lib()
     us = C.c_double()
     if what in ("gemm", "gemm_l4", "gemm_mid"):
         for name, M, N, K, epi in {"gemm": GEMM_SHAPES, "gemm_l4": L4_SHAPES, "gemm_mid": MID_SHAPES}[what]:

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from counterfactualworldmodels_amd import _lib  # noqa: E402
 
 torch.cuda.init()
-lib = _lib.get_lib()
+lib = _lib.get_dev_lib()
 us = C.c_double()
 for name, M, N, K, epi in [("enc.fc2", 25344, 768, 3072, 0), ("enc.qkv-like fc1", 25344, 3072, 768, 1), ("8192^3", 8192, 8192, 8192, 0)]:
     for mode in ("parity", "fast"):
