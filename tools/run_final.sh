@@ -1,6 +1,6 @@
 # Final measurement set of a round (GPU box): python tests, benches of every BASELINE config, latency table, microbenchmarks.
-#   gpurun --timeout 3000 -- 'bash tools/run_final.sh r4 > gpurun_out/final_r4.log 2>&1'
-TAG=${1:-r4}
+#   gpurun --timeout 3000 -- 'bash tools/run_final.sh r5 > gpurun_out/final_r5.log 2>&1'
+TAG=${1:-r5}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1; tail -1 $OUT/pytest_gpu.log
@@ -14,7 +14,6 @@ timeout 600 python bench.py --workload prompts256 --steps 8 --warmup 2 > $OUT/be
 timeout 600 python tools/latency.py > $OUT/latency.log 2>&1
 timeout 600 python tools/microbench.py gemm > $OUT/microbench_gemm_b8.log 2>&1
 timeout 600 python tools/microbench.py attn > $OUT/microbench_attn.log 2>&1
-VARIANTS=0:0,1:0,4:0,6:0 timeout 600 python tools/mb_variants.py > $OUT/microbench_gemm_variants.log 2>&1
 timeout 600 python tools/ab_direct.py --no-check > $OUT/ab_gemm_direct.log 2>&1
 timeout 600 python tools/ab_step.py gemm_direct 0 1 2 > $OUT/ab_step_gemm_direct.log 2>&1
 KEY=attn_ksplit timeout 600 python tools/mb_attn.py > $OUT/microbench_attn_ksplit.log 2>&1
