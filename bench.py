@@ -30,7 +30,8 @@ from counterfactualworldmodels_amd import _lib, config as C, synthetic as S, vma
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0      # HBM3E (same guide)
-EDGE_CLASSES = (("layernorm_kernel", _lib.KCLASS_LAYERNORM), ("patch_gather_kernel", _lib.KCLASS_PATCH_GATHER),
+# (index_gather_kernel: round 5 -- mask -> permutation, its inverse, the row check AND the patch gather in one launch; rounds 1-4 booked the gather alone here)
+EDGE_CLASSES = (("layernorm_kernel", _lib.KCLASS_LAYERNORM), ("index_gather_kernel", _lib.KCLASS_PATCH_GATHER),
                 ("fill_mask_tokens_kernel", _lib.KCLASS_FILL_MASK), ("unembed_kernel", _lib.KCLASS_UNEMBED))
 
 # BASELINE configs[3]: 256 motion-counterfactual prompts over ONE frame pair, sharded over the ranks

@@ -29,7 +29,7 @@ def check_bitwise():
         return torch.randn(*shape, generator=g) * scale
 
     bad = 0
-    for tile in (1, 2, 3, 4):
+    for tile in (1, 4, 6):
         setk(b"gemm_tile", tile)
         for mode in ("parity", "fast"):
             for (M, N, K) in [(300, 272, 128), (1000, 1152, 192), (77, 48, 512), (513, 400, 384), (2049, 768, 768)]:
