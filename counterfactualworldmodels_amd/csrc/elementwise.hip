@@ -328,10 +328,9 @@ int launch_index_gather(const PatchGatherParams& p, const uint8_t* mask, int n_v
     CWM_REQUIRE(p.C == 3 || !p.normalize, "index_gather: imagenet normalisation needs 3 channels");
     CWM_REQUIRE(p.ld >= p.C * p.P * p.P && p.ld % 4 == 0, "index_gather: bad ld");
     CWM_REQUIRE(mask && perm && err_rows && p.n_rows > 0 && p.n_rows <= 12000, "index_gather: bad argument (rows per sample: %d)", p.n_rows);
-    // workgroups per sample: one gather item per thread, but at most one resident round of the chip in total (8 workgroups of 256 threads per CU) --
-    // every workgroup pays the mask scan once, so a second, nearly empty round would pay it for little (the gather loop is grid-strided)
-    const int want = (p.n_rows * p.C * p.P + 255) / 256;
-    const int per_sample = std::max(1, std::min(want, std::max(1, 8 * gemm_cu_count() / p.B)));
+    // one gather item per thread.  (Capping the grid at one resident round of the chip -- every workgroup pays the mask scan once -- and letting the
+    // grid-strided loop run twice measured SLOWER at batch 32: 28.6 against 22.2 us; the scan hides under the other workgroups' loads.)
+    const int per_sample = (p.n_rows * p.C * p.P + 255) / 256;
     const dim3 grid((unsigned)per_sample, (unsigned)p.B);
     const size_t smem = (size_t)p.n_rows * sizeof(int);
     if (planes == 1)

@@ -20,7 +20,7 @@ from counterfactualworldmodels_amd import build  # noqa: E402
 DEFAULT_PATH = ["gemm8p_kernel<", "gemm_bf16_kernel<2, 128, 128, 2, 4, 2>", "gemm_bf16_kernel<1, 128, 128, 2, 4, 2>",
                 "gemm_bf16_kernel<2, 128, 128, 2, 4, 4>", "gemm_bf16_kernel<1, 128, 128, 2, 4, 4>", "gemm_bf16_kernel<2, 64, 128, 1, 4, 4>",
                 "gemm_bf16_kernel<1, 64, 128, 1, 4, 4>", "attention_pipe_kernel", "attention_kernel",
-                "layernorm_kernel", "patch_gather_kernel", "unembed3_kernel", "fill_mask_tokens4_kernel", "mask_to_perm_kernel", "shift_prompts_kernel",
+                "layernorm_kernel", "patch_gather_kernel", "index_gather_kernel", "unembed3_kernel", "fill_mask_tokens4_kernel", "mask_to_perm_kernel", "shift_prompts_kernel",
                 "cross_attn_mfma_kernel", "small_attn_mfma_kernel"]
 
 
