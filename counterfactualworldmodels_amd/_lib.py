@@ -198,6 +198,7 @@ DEV_SIGNATURES = {
     "cwm_bench_gemm_gapped": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_double)]),
     "cwm_bench_attention": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cwm_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "cwm_debug_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
 }
 
 _lib: Optional[C.CDLL] = None

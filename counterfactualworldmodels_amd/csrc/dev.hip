@@ -62,6 +62,12 @@ extern "C" int cwm_debug_set(const char* key, int value) {
     return CWM_OK;
 }
 
+extern "C" int cwm_debug_get(const char* key, int* value) {
+    CWM_REQUIRE(key && value, "cwm_debug_get: null argument");
+    CWM_REQUIRE(tuning_get(thread_tuning(), key, value) == 0, "cwm_debug_get: unknown key %s", key);
+    return CWM_OK;
+}
+
 // Per-shape overrides of the tile choice (the tuning hook behind tools/autotune_step.py).  All configurations give bit-identical results
 // (tests/test_kernels_gpu.py), so an override can only change the speed.  The table is process-wide; it reaches a launch through
 // Tuning.tile_hook, which the first override installs in this thread's options (models created afterwards inherit it).

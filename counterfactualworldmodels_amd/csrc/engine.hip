@@ -53,18 +53,30 @@ Tuning& thread_tuning() {
     static thread_local Tuning t;
     return t;
 }
-int tuning_set(Tuning& t, const char* key, int value) {
-    struct Field { const char* name; int Tuning::*member; };
+namespace {
+struct TuningField { const char* name; int Tuning::*member; };
+}
+static const TuningField* tuning_field(const char* key) {
+    typedef TuningField Field;
     static const Field fields[] = {{"gemm_tile", &Tuning::gemm_tile}, {"gemm_debug", &Tuning::gemm_debug}, {"gemm_staged", &Tuning::gemm_staged},
                                    {"gemm_direct", &Tuning::gemm_direct}, {"attn_kernel", &Tuning::attn_kernel}, {"attn_remap", &Tuning::attn_remap},
                                    {"attn_tail", &Tuning::attn_tail}, {"attn_ksplit", &Tuning::attn_ksplit}, {"prune_last_block", &Tuning::prune_last_block}, {"index_fused", &Tuning::index_fused},
                                    {"min_lane_rows", &Tuning::min_lane_rows}, {"conj_ctx_stream", &Tuning::conj_ctx_stream}, {"conj_attn", &Tuning::conj_attn}};
     for (const Field& f : fields)
-        if (!strcmp(key, f.name)) {
-            t.*(f.member) = value;
-            return 0;
-        }
-    return -1;
+        if (!strcmp(key, f.name)) return &f;
+    return nullptr;
+}
+int tuning_set(Tuning& t, const char* key, int value) {
+    const TuningField* f = tuning_field(key);
+    if (!f) return -1;
+    t.*(f->member) = value;
+    return 0;
+}
+int tuning_get(const Tuning& t, const char* key, int* value) {
+    const TuningField* f = tuning_field(key);
+    if (!f) return -1;
+    *value = t.*(f->member);
+    return 0;
 }
 
 __global__ void pack_weight_kernel(const float* src, int N, int K, bf16* hi, bf16* il, int Npad, int Kpad) {

@@ -32,6 +32,7 @@ const Tuning& default_tuning();
 // development library's cwm_debug_set changed this THREAD's copy (libcwm_hip.so exports no way to)
 Tuning& thread_tuning();
 int tuning_set(Tuning& t, const char* key, int value);  // 0, or -1 for an unknown key
+int tuning_get(const Tuning& t, const char* key, int* value);
 
 enum GemmEpilogue : int {
     EPI_F32 = 0,        // C = acc + bias (+ resid[rowmap])            fp32 out

@@ -32,6 +32,8 @@ CWM_API int cwm_bench_gemm_gapped(int M, int N, int K, int mode, int epi, int it
  * A model that already exists is changed with cwm_model_set_option / cwm_conj_set_option.  Also the profiling queries "attn_prof" / "gemm_prof"
  * (per-workgroup timers of builds with -DCWM_ATTN_PROF / -DCWM_GEMM_PROF). */
 CWM_API int cwm_debug_set(const char* key, int value);
+/* The value of an option in this thread's copy (what a handle created on this thread now would start from). */
+CWM_API int cwm_debug_get(const char* key, int* value);
 
 
 #ifdef __cplusplus

@@ -73,3 +73,38 @@ def test_struct_layout_matches_header():
     assert _lib.new_forward_args().struct_size == ctypes.sizeof(_lib.CwmForwardArgs)
     assert _lib.new_conj_forward_args().struct_size == ctypes.sizeof(_lib.CwmConjForwardArgs)
     assert _lib.get_lib().cwm_compiler_version().decode() == build.hipcc_version().replace('"', "'")
+
+
+def test_development_switches_are_per_thread_not_per_process():
+    """The only switchboard left is the development library's, and it is THREAD-local (kernels.h thread_tuning): a value set on one thread is not
+    seen on another, every thread starts from the defaults, and the production library has no such entry point at all.  (Per-MODEL independence
+    needs a device: tests/test_model_gpu.py::test_options_are_per_model_handle.)  No GPU needed: the options are host state."""
+    import threading
+
+    d = _lib.get_dev_lib()
+
+    def get(key):
+        v = ctypes.c_int(-123)
+        assert d.cwm_debug_get(key, ctypes.byref(v)) == 0
+        return v.value
+
+    defaults = {b"attn_kernel": 0, b"gemm_tile": 0, b"gemm_direct": 1, b"attn_remap": 1, b"prune_last_block": 1, b"index_fused": 1, b"min_lane_rows": 0}
+    assert {k: get(k) for k in defaults} == defaults
+    seen, barrier = {}, threading.Barrier(2)
+
+    def worker(name, kernel, tile):
+        assert {k: get(k) for k in defaults} == defaults          # a fresh thread: the defaults, whatever other threads did
+        assert d.cwm_debug_set(b"attn_kernel", kernel) == 0 and d.cwm_debug_set(b"gemm_tile", tile) == 0
+        barrier.wait()                                             # both threads have written ...
+        seen[name] = (get(b"attn_kernel"), get(b"gemm_tile"))      # ... and each still reads its own
+
+    ts = [threading.Thread(target=worker, args=("a", 1, 4)), threading.Thread(target=worker, args=("b", 3, 6))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert seen == {"a": (1, 4), "b": (3, 6)}
+    assert {k: get(k) for k in defaults} == defaults               # the main thread never saw either
+    v = ctypes.c_int()
+    assert d.cwm_debug_get(b"no_such_switch", ctypes.byref(v)) != 0
+    assert not hasattr(ctypes.CDLL(build.LIB_PATH), "cwm_debug_get")
