@@ -313,32 +313,25 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128 && WM * WN ==
 //    tile (phase 4) that leaves the three youngest half-tiles in flight.
 // Half-tile schedule (t = K tile, buffer t & 1):   P1(t): A1(t+1)   P2(t): A0(t+2)   P3(t): W0(t+2)   P4(t): W1(t+2)
 // so the wait in P4(t) retires all of tile t+1, which is first read one barrier later, in P1(t+1).
+// Half-width column tile (round 5): when the tile's columns 128 .. 255 all lie past N (N mod 256 in 1 .. 128: the decoder's N = 384 and 1152), the
+// quadrants (., 1) are all padding -- their MFMA clusters, their W1 fragment reads and the W1 half-tile's LDS-DMA are skipped (every barrier stays:
+// the hand-off reasoning below is unchanged), the counted wait becomes vmcnt(4) (a K tile issues three half-tiles instead of four) and the epilogue
+// runs over two pieces instead of four.  A half tile holds a CU for ~0.6 of a full tile's time; with it N = 384 runs as 1.5 column tiles on this
+// kernel instead of three 128x128 tiles per row block on the L2-feed-bound small kernel.  Same product sequence per accumulator: bit-identical.
 // Write-after-read: A half-tiles are staged by the group that reads them (waves 0-3 stage and read rows 0-63,
 // waves 4-7 rows 64-127), so one phase after the reads suffices; W half-tiles are read by both groups, and
 // the leading group re-stages them two phases after the read (W0 read in P1 -> staged in P3, W1 P2 -> P4).
 
-template <int PLANES>
-__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
+// One 256x256 tile (HALF: its columns 128 .. 255 are all padding -- see above) of the 8-phase kernel.
+template <int PLANES, bool HALF>
+__device__ __forceinline__ void gemm8p_tile(const GemmParams& p, char* smem, int m0, int n0) {
     GEMM_PROF_BEGIN();
     constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 128 B
     constexpr int BUF_BYTES = 4 * HALF_BYTES;  // A0 | A1 | W0 | W1
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-
-    const int tiles_m = (p.M + 255) / 256;
-    const int tiles_n = (p.N + 255) / 256;
-    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    constexpr int GROUP_M = 4;  // (group heights 1 .. 12 measured within +-1 % of each other on every model shape)
-    const int group_sz = GROUP_M * tiles_n;
-    const int g = id / group_sz;
-    const int first_m = g * GROUP_M;
-    const int gm = min(tiles_m - first_m, GROUP_M);
-    const int in_g = id - g * group_sz;
-    const int m0 = (first_m + (in_g % gm)) * 256, n0 = (in_g / gm) * 256;
 
     // ---- LDS-DMA sources: wave w stages pieces 2w, 2w+1 (rows 16w .. 16w+15) of every half-tile ----
     // (direct epilogue with bf16 outputs: W rows permuted inside every 32-row group, gemm_device.h epilogue_direct)
@@ -429,17 +422,31 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
 
     const int nk = p.K / (64 / PLANES);
     // ---- prologue: all of tile 0, then A0 / W0 / W1 of tile 1 ----
-    stage(H_A0{}, 0, 0);
-    stage(H_W0{}, 0, 0);
-    stage(H_W1{}, 0, 0);
-    stage(H_A1{}, 0, 0);
-    if (nk > 1) {
-        stage(H_A0{}, 1, 1);
-        stage(H_W0{}, 1, 1);
-        stage(H_W1{}, 1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // (the waits leave tile 1's pieces in flight: three half-tiles = 6 pieces, two = 4 for a half-width tile)
+    if constexpr (!HALF) {
+        stage(H_A0{}, 0, 0);
+        stage(H_W0{}, 0, 0);
+        stage(H_W1{}, 0, 0);
+        stage(H_A1{}, 0, 0);
+        if (nk > 1) {
+            stage(H_A0{}, 1, 1);
+            stage(H_W0{}, 1, 1);
+            stage(H_W1{}, 1, 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stage(H_A0{}, 0, 0);
+        stage(H_W0{}, 0, 0);
+        stage(H_A1{}, 0, 0);
+        if (nk > 1) {
+            stage(H_A0{}, 1, 1);
+            stage(H_W0{}, 1, 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     CWM_PHASE_BARRIER();
     if (wr == 1) CWM_PHASE_BARRIER();  // the second wave group runs one barrier behind the first
@@ -455,23 +462,25 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
         mfma_quadrant(acc[0][0], bw0);
         CWM_PHASE_BARRIER();
         // ---- P2: quadrant (0, 1) ----
-        read_w(base, 1, bw1);
+        if constexpr (!HALF) read_w(base, 1, bw1);
         if (t + 2 < nk) stage(H_A0{}, buf, t + 2);
         CWM_PHASE_BARRIER();
-        mfma_quadrant(acc[0][1], bw1);
+        if constexpr (!HALF) mfma_quadrant(acc[0][1], bw1);
         CWM_PHASE_BARRIER();
         // ---- P3: quadrant (1, 1) ----
         read_a(base, 1);
         if (t + 2 < nk) stage(H_W0{}, buf, t + 2);
         CWM_PHASE_BARRIER();
-        mfma_quadrant(acc[1][1], bw1);
+        if constexpr (!HALF) mfma_quadrant(acc[1][1], bw1);
         CWM_PHASE_BARRIER();
-        // ---- P4: quadrant (1, 0); retire tile t+1 ----
-        if (t + 2 < nk) {
+        // ---- P4: quadrant (1, 0); retire tile t+1 (A1(t+1) was issued in P1: the two / three half-tiles issued since may stay in flight) ----
+        if (t + 2 >= nk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (HALF) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
             stage(H_W1{}, buf, t + 2);
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         CWM_PHASE_BARRIER();
         mfma_quadrant(acc[1][0], bw0);
@@ -500,9 +509,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
         int4* tab = reinterpret_cast<int4*>(smem);
         epilogue_row_table(p, tab, m0, 256, tid);
         __syncthreads();
-        epilogue_direct<PLANES, 4>(
-            p, [&](int pi, int i, int j) { return acc[pi >> 1][pi & 1][i][j]; }, [&](int pi) { return (pi >> 1) * 128 + wr * 64; },
-            [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, tab, lane);
+        if constexpr (HALF)
+            epilogue_direct<PLANES, 2>(
+                p, [&](int pi, int i, int j) { return acc[pi][0][i][j]; }, [&](int pi) { return pi * 128 + wr * 64; }, [&](int) { return n0 + wc * 32; }, tab, lane);
+        else
+            epilogue_direct<PLANES, 4>(
+                p, [&](int pi, int i, int j) { return acc[pi >> 1][pi & 1][i][j]; }, [&](int pi) { return (pi >> 1) * 128 + wr * 64; },
+                [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, tab, lane);
         GEMM_PROF_END();
         return;
     }
@@ -510,9 +523,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
         int4* tab = reinterpret_cast<int4*>(smem + 8 * 8192);
         epilogue_row_table(p, tab, m0, 256, tid);
         __syncthreads();
-        epilogue_piece_seq<PLANES, 4>(
-            p, [&](int pi, int i, int j) { return acc[pi >> 1][pi & 1][i][j]; }, [&](int pi) { return (pi >> 1) * 128 + wr * 64; },
-            [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, smem + wave * 8192, tab, lane);
+        if constexpr (HALF)
+            epilogue_piece_seq<PLANES, 2>(
+                p, [&](int pi, int i, int j) { return acc[pi][0][i][j]; }, [&](int pi) { return pi * 128 + wr * 64; }, [&](int) { return n0 + wc * 32; },
+                smem + wave * 8192, tab, lane);
+        else
+            epilogue_piece_seq<PLANES, 4>(
+                p, [&](int pi, int i, int j) { return acc[pi >> 1][pi & 1][i][j]; }, [&](int pi) { return (pi >> 1) * 128 + wr * 64; },
+                [&](int pi) { return n0 + (pi & 1) * 128 + wc * 32; }, smem + wave * 8192, tab, lane);
         GEMM_PROF_END();
         return;
     }
@@ -533,6 +551,25 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
                     epilogue_frag<PLANES>(p, rm, nb, ncol, acc[qm][qn][i][j]);
                 }
         }
+}
+
+template <int PLANES>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_m = (p.M + 255) / 256;
+    const int tiles_n = (p.N + 255) / 256;
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    constexpr int GROUP_M = 4;  // (group heights 1 .. 12 measured within +-1 % of each other on every model shape)
+    const int group_sz = GROUP_M * tiles_n;
+    const int g = id / group_sz;
+    const int first_m = g * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    const int in_g = id - g * group_sz;
+    const int m0 = (first_m + (in_g % gm)) * 256, n0 = (in_g / gm) * 256;
+    // two instances of the tile, chosen once per workgroup (launch-uniform per tile column): each has its own main loop with ONE counted wait --
+    // no branch on the tile kind inside the loops (tools/asm_lds_lint.py checks the two loops against their own piece counts)
+    if (n0 + 128 >= p.N && !(p.debug & 1024)) gemm8p_tile<PLANES, true>(p, smem, m0, n0);
+    else gemm8p_tile<PLANES, false>(p, smem, m0, n0);
 }
 
 // Split-K workspace of the deep-ring kernel: kSplitKSlots fp32 slabs of one 128x128 tile + arrival counters (zeroed once; the kernel
@@ -631,8 +668,13 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
         //    the direct epilogue the 8-phase kernel wins there too (decoder qkv 149 -> 140 us, fc1 214 -> 191 us, profiles/r4_ab_gemm_direct.log)
         cfg = 1;
         const bool bf16_out = p.epi != EPI_F32;
-        if (p.K >= ((bf16_out && !(t.gemm_debug & 512)) ? 256 : 512) && p.M >= 512 && (p.N >= 1024 || (p.N >= 512 && p.N % 256 == 0))) {
-            const int64_t tiles = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        // N: whole 256-column tiles, or wide enough that a ragged last one weighs little -- or, since round 5, a last tile that is exactly a half-width
+        // one (N mod 256 = 128: the decoder's N = 384 as 1.5 column tiles; "gemm_debug" bit 1024 restores the round-4 rule and kernel)
+        const bool half_ok = !(t.gemm_debug & 1024) && p.N >= 384 && p.N % 256 == 128;
+        if (p.K >= ((bf16_out && !(t.gemm_debug & 512)) ? 256 : 512) && p.M >= 512 && (p.N >= 1024 || (p.N >= 512 && p.N % 256 == 0) || half_ok)) {
+            // (a half-width last column tile holds its CU for ~0.6 of a full tile's time: counted as such when the fill of the rounds is judged)
+            const int64_t tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+            const int64_t tiles = (half_ok && p.N % 256 == 128) ? tiles_m * (tiles_n - 1) + (tiles_m * 3 + 4) / 5 : tiles_m * tiles_n;
             const int cus = gemm_cu_count();
             if (tiles < cus) {
                 // one partial round: from half the CUs up.  Inside a two-lane call the other lane fills the idle CUs, and the launches whose tile is long (K >= 1024:
@@ -655,6 +697,10 @@ int gemm_choose_tile(const GemmParams& p, int planes) {
                 const int last = (int)(tiles % cus);
                 const bool full_enough = (bf16_out || p.K >= 1024) ? last * 2 >= cus : last * 5 >= cus * 4;
                 if (last == 0 || full_enough) cfg = 4;
+                else if (half_ok && p.N < 512) cfg = tiles < 2 * cus ? 1 : 4;  // N = 384 alone on the chip: a badly filled SECOND round goes to the 128x128 kernel
+                                                                               // (dec.fc2 of a one-lane batch 32: 195 us either way in parity mode, 78 vs 88 us in
+                                                                               // fast mode), from two whole rounds on the 8-phase kernel wins (the IMU model's
+                                                                               // batch-16 dec.fc2: 373 -> 358 us; profiles/r5_mb_halftile.log)
                 else if (p.K >= 1024 || p.N >= 1024) cfg = 6;
             }
         }

@@ -12,7 +12,8 @@ struct Tuning {
     int gemm_tile = 0;     // 0 automatic per shape (gemm_choose_tile), 1: 128x128, 4: 256x256 8-phase, 6: 8-phase rounds + 128x128 remainder rows
     int gemm_debug = 0;    // bit mask of ablations / A-B switches: 1 skip the epilogue's global stores, 2 skip the epilogue, 4 no 4-stage ring for small launches,
                            // 8 skip every LayerNorm launch (timing only), 32 no split-K, 128 the one-lane tile choice also inside a two-lane call, 256 small launches keep
-                           // 128-row tiles where the default takes 64x128 ones, 512 bf16-output GEMMs with K < 512 stay on 128x128 tiles
+                           // 128-row tiles where the default takes 64x128 ones, 512 bf16-output GEMMs with K < 512 stay on 128x128 tiles, 1024 no half-width column tiles in the
+                           // 8-phase kernel (and N = 384 back on 128x128 tiles)
     int gemm_staged = 1;   // 0: the per-fragment epilogue of round 1 everywhere (it stays the fallback for unaligned widths)
     int gemm_direct = 1;   // 1: bf16-output epilogues store 16 bytes per lane straight from the accumulators; 2: the fp32-output ones too; 0: LDS-staged everywhere
     int attn_kernel = 0;   // 0 automatic, 1: 4-wave kernel (attention.hip), 3: software-pipelined kernel (attention_pipe.hip)

@@ -112,7 +112,7 @@ CWM_API int cwm_model_set_lanes(cwm_model* m, int lanes); /* 1 .. 4; more than t
  *   "gemm_staged"  0: the per-fragment epilogue of round 1
  *   "gemm_debug"   bit mask: 1 skip the epilogue's global stores (timing only), 2 skip the epilogue (timing only), 4 no 4-stage ring for small launches,
  *                  8 skip every LayerNorm launch (timing only), 32 no split-K, 128 the one-lane tile choice also inside a two-lane call, 256 small launches
- *                  keep 128-row tiles, 512 bf16-output GEMMs with K < 512 stay on 128x128 tiles
+ *                  keep 128-row tiles, 512 bf16-output GEMMs with K < 512 stay on 128x128 tiles, 1024 no half-width column tiles in the 8-phase kernel
  *   "attn_kernel"  0 automatic, 1: 4-wave kernel, 3: software-pipelined kernel
  *   "attn_remap"   0: plain workgroup order instead of one XCD per (batch, head) with the ragged query tiles last
  *   "attn_tail"    0: the regular schedule also for a ragged last query tile of <= 32 rows

@@ -265,13 +265,13 @@ def test_counted_vmcnt_waits_match_the_lds_dma_the_compiler_emitted():
     text = asm_lds_lint.compile_isa("gemm.hip")
     import re
 
-    assert len(re.findall(r";;#ASMSTART\n\s*s_waitcnt vmcnt\([1-9]", text)) >= 12   # 2 x (prologue + loop) of the 8-phase kernel, 2 per deep-ring kernel
+    assert len(re.findall(r";;#ASMSTART\n\s*s_waitcnt vmcnt\([1-9]", text)) >= 16   # 2 modes x 2 tile instances x (prologue + loop) of the 8-phase kernel, 2 per deep-ring kernel
     assert asm_lds_lint.lint_vmcnt(text) == []
     assert asm_lds_lint.lint_isa(text) == []
     # every kernel with a counted wait has a spec derived from its template arguments
     for name in re.findall(r"^(_Z\w+):", text, flags=re.M):
         if "gemm8p_kernel" in name:
-            assert asm_lds_lint.vmcnt_spec(name)["loop"] == {6: (8, 8)}
+            assert asm_lds_lint.vmcnt_spec(name)["loop"] == {6: (8, 8), 4: (6, 6)}   # full tile / half-width column tile
     first = text.index("_ZN3cwm13gemm8p_kernelILi2EEEvNS_10GemmParamsE:")
     loop = text.index("Loop Header", first)
     piece = text.index("global_load_lds_dwordx4", loop)
@@ -282,6 +282,11 @@ def test_counted_vmcnt_waits_match_the_lds_dma_the_compiler_emitted():
     assert any("9 LDS-DMA" in h[2] for h in asm_lds_lint.lint_vmcnt(dup))
     imm = text[:first] + text[first:].replace("s_waitcnt vmcnt(6)", "s_waitcnt vmcnt(7)")
     assert any("vmcnt(7) is not one the source places" in h[2] for h in asm_lds_lint.lint_vmcnt(imm))
+    swapped = text[:first] + text[first:].replace("s_waitcnt vmcnt(4)", "s_waitcnt vmcnt(6)")   # the half-width tile instance with the full tile's count
+    assert any("issues 6 LDS-DMA pieces" in h[2] for h in asm_lds_lint.lint_vmcnt(swapped))
+    pro = text.index("global_load_lds_dwordx4", first)
+    e2 = text.index("\n", pro)
+    assert any("among the prologue" in h[2] for h in asm_lds_lint.lint_vmcnt(text[:e2 + 1] + "\tglobal_load_dword v1, v[2:3], off\n" + text[e2 + 1:]))
     # the record of the compiler the lint passed on is current (re-run `python tools/asm_lds_lint.py --record` after a toolchain bump)
     rec = build.lint_record()
     assert rec.get("hipcc") == build.hipcc_version(), "csrc/LINT_PASSED.json names another compiler: %r" % rec.get("hipcc")

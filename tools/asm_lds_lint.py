@@ -131,8 +131,9 @@ def vmcnt_spec(kernel):
     """{immediate: (pieces per loop iteration, pieces issued before the wait in its iteration)} for the counted loop waits the kernel's source places,
     and [(pieces, immediate)] for its straight-line prologue wait; None for kernels without counted waits."""
     m = re.search(r"gemm8p_kernelILi(\d)E", kernel)
-    if m:  # P1: A1(t+1)  P2: A0(t+2)  P3: W0(t+2)  P4: W1(t+2), two pieces per wave each; vmcnt(6) leaves the three youngest half-tiles in flight
-        return {"loop": {6: (8, 8)}, "prologue": [(14, 6)]}
+    if m:  # P1: A1(t+1)  P2: A0(t+2)  P3: W0(t+2)  P4: W1(t+2), two pieces per wave each; vmcnt(6) leaves the three youngest half-tiles in flight.
+        # Half-width column tiles (round 5) skip W1: three half-tiles per K tile, vmcnt(4) leaves the two youngest in flight
+        return {"loop": {6: (8, 8), 4: (6, 6)}, "prologue": [(14, 6), (10, 4)]}
     m = re.search(r"gemm_bf16_kernelILi(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", kernel)
     if m:
         _, bm, bn, wm, wn, stages = (int(x) for x in m.groups())
@@ -263,7 +264,7 @@ def lint_vmcnt(text):
                     hits.append((kernel, ln, "vmcnt(%d): the loop iteration issues %d LDS-DMA pieces, %d of them before the wait; the source counted %d / %d"
                                  % (imm, n, before, want[0], want[1])))
             static = sum(1 for k in body for ins in blocks[k]["ins"] if ins[1] == "global_load_lds_dwordx4")
-            per_iter = max(v[0] for v in spec["loop"].values())
+            per_iter = max(v[0] for v in best.values()) if best else 0  # (a loop unswitched on a launch-uniform flag holds one variant's pieces only)
             if best and static != per_iter:
                 hits.append((kernel, blocks[start]["ins"][0][0] if blocks[start]["ins"] else 0,
                              "the loop holds %d LDS-DMA instructions, the source issues %d per iteration (a duplicated or hoisted piece?)" % (static, per_iter)))
@@ -272,26 +273,37 @@ def lint_vmcnt(text):
         for imm in spec["loop"]:
             if imm not in seen_loop_imms:
                 hits.append((kernel, 0, "the source's loop wait vmcnt(%d) was not found on any path around a loop" % imm))
-        # rule c: straight-line prologue waits (outside any loop): pieces since the function start along the textual order of the non-loop blocks
+        # rule c: the prologue waits.  The code in front of a main loop is scanned in LAYOUT order (its branches re-test launch-uniform conditions --
+        # K of one tile? -- that a path enumeration cannot relate to each other; the source issues the pieces and the wait in one straight sequence, and
+        # that is what the text must show): pieces from the region's start up to each counted wait; any other vector-memory instruction between the
+        # first piece and the region's last counted wait is a hit.  A region = the blocks between two loops (a kernel with two tile instances has two).
         want = list(spec["prologue"])
-        n = 0
+        regions, cur = [], []
         for b in blocks:
             if b["loop"]:
-                break
-            for ln, op, l, asm in b["ins"]:
+                if cur:
+                    regions.append(cur)
+                cur = []
+            else:
+                cur.append(b)
+        if cur:
+            regions.append(cur)
+        for reg in regions:
+            seq = [ins for b in reg for ins in b["ins"]]
+            is_counted = lambda ins: ins[3] and ins[1] == "s_waitcnt" and re.search(r"vmcnt\(([1-9]\d*)\)", ins[2])
+            last = max([i for i, ins in enumerate(seq) if is_counted(ins)] or [-1])
+            n = 0
+            for i, (ln, op, l, asm) in enumerate(seq[:last + 1]):
                 if op == "global_load_lds_dwordx4":
                     n += 1
-                elif _vm_op(op):
-                    hits.append((kernel, ln, "vector-memory instruction among the prologue's LDS-DMA pieces: `%s`" % l)) if n and want else None
-                elif asm and op == "s_waitcnt":
-                    mm = re.search(r"vmcnt\(([1-9]\d*)\)", l)
-                    if mm:
-                        if not want:
-                            hits.append((kernel, ln, "unexpected counted prologue wait `%s`" % l))
-                        else:
-                            pieces, imm = want.pop(0)
-                            if (n, int(mm.group(1))) != (pieces, imm):
-                                hits.append((kernel, ln, "prologue: %d pieces then vmcnt(%s); the source counted %d then vmcnt(%d)" % (n, mm.group(1), pieces, imm)))
+                elif _vm_op(op) and n:
+                    hits.append((kernel, ln, "vector-memory instruction among the prologue's LDS-DMA pieces: `%s`" % l))
+                elif is_counted((ln, op, l, asm)):
+                    got = (n, int(re.search(r"vmcnt\((\d+)\)", l).group(1)))
+                    if got in want:
+                        want.remove(got)
+                    else:
+                        hits.append((kernel, ln, "prologue: %d pieces then vmcnt(%d); the source counted %s" % (got[0], got[1], spec["prologue"])))
         for pieces, imm in want:
             hits.append((kernel, 0, "the source's prologue wait vmcnt(%d) after %d pieces was not found" % (imm, pieces)))
     return hits
