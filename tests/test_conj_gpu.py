@@ -225,3 +225,57 @@ def test_context_side_stream_is_bitwise_neutral():
         m.set_option("conj_ctx_stream", 1)
         for rep in range(4):
             assert torch.equal(m(x, mask, x_context=imu, mask_context=mc), ref), (lanes, rep)
+
+
+def test_forward_args_struct_size_versions():
+    """`struct_size` (ABI 0.6): a caller compiled against the 0.4 header -- whose `cwm_conj_forward_args` ended at `stream`, before `y_ctx_tokens_dev` was appended -- passes the
+    shorter struct and gets the main output (the library copies what the caller has and reads the rest as "not requested", instead of taking stack garbage for an output pointer);
+    the full struct also fills the context output; sizes that are no version of the struct are refused.  Same for `cwm_forward_args`."""
+    import ctypes as Ct
+
+    from counterfactualworldmodels_amd import _lib
+
+    g = np.load(os.path.join(GOLDEN, "conj_tiny_ctx.npz"))
+    m = build(TINY_CONJ, int(g["seed"]))
+    G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+    x, mask, imu, mc = (torch.from_numpy(g[k]).cuda() for k in ("x", "mask", "imu", "mask_context"))
+    xp = G._preprocess(x).contiguous()
+    y_ref, yc_ref = m(xp, mask, x_context=imu, mask_context=mc, output_main=True, output_context=True)
+    m(xp, mask, x_context=imu, mask_context=mc, output_main=True, output_context=False)
+    lib, h = _lib.get_lib(), m._handle
+    vis, vis_c = (~mask).sum(1), (~mc).sum(1)
+    y, yc = torch.full_like(y_ref, 7.0), torch.full_like(yc_ref, 7.0)
+    full = _lib.CwmConjForwardArgs(Ct.sizeof(_lib.CwmConjForwardArgs), xp.data_ptr(), xp.stride(0), xp.stride(1), xp.stride(2), 0, mask.data_ptr(), xp.shape[0], int(vis.max()),
+                                   imu.data_ptr(), mc.data_ptr(), int(vis_c.max()), y.data_ptr(), _lib.MODE_PARITY, 1, _lib.current_stream_handle(xp.device), yc.data_ptr())
+    assert lib.cwm_conj_forward(h, Ct.byref(full)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref) and torch.equal(yc, yc_ref)
+    # the 0.4 layout: everything up to and including `stream`; the bytes behind it in the caller's frame are garbage the library must not read
+    old_size = _lib.CwmConjForwardArgs.stream.offset + Ct.sizeof(Ct.c_void_p)
+    y.fill_(7.0)
+    yc.fill_(7.0)
+    full.struct_size = old_size
+    full.y_ctx_tokens_dev = 0xDEAD0000  # (what a short struct's tail would look like to a library that ignored the size)
+    assert lib.cwm_conj_forward(h, Ct.byref(full)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref) and bool((yc == 7.0).all())
+    for bad in (0, 8, old_size - 8, 1 << 20):
+        full.struct_size = bad
+        assert lib.cwm_conj_forward(h, Ct.byref(full)) == _lib.ERR_INVALID and b"struct_size" in lib.cwm_last_error()
+    # the plain model's struct
+    from test_model_gpu import TINY, build as build_plain, case_inputs
+
+    gp = np.load(os.path.join(GOLDEN, "tiny_8x8_k4.npz"))
+    seed, xs, ms = case_inputs(gp, TINY)
+    mp = build_plain(TINY, seed)
+    Gp = prediction.PredictorBasedGenerator(predictor=mp, imagenet_normalize_inputs=True, temporal_dim=2)
+    xq, mq = Gp._preprocess(xs.cuda()).contiguous(), ms.cuda().contiguous()
+    yr = mp(xq, mq)
+    yo = torch.empty_like(yr)
+    a = _lib.CwmForwardArgs(Ct.sizeof(_lib.CwmForwardArgs), xq.data_ptr(), xq.stride(0), xq.stride(1), xq.stride(2), 0, mq.data_ptr(), xq.shape[0], int((~mq[0]).sum()),
+                            yo.data_ptr(), None, None, _lib.MODE_PARITY, 1, _lib.current_stream_handle(xq.device))
+    assert lib.cwm_forward(mp._handle, Ct.byref(a)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(yo, yr)
+    a.struct_size = 0
+    assert lib.cwm_forward(mp._handle, Ct.byref(a)) == _lib.ERR_INVALID
