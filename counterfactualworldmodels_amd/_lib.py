@@ -251,8 +251,24 @@ def get_lib() -> C.CDLL:
                 lib = _bind(path)
                 if lib.cwm_source_hash().decode() != want:
                     raise RuntimeError("libcwm_hip.so still does not match the sources after a rebuild")
+        _warn_if_unlinted_compiler(lib)
         _lib = lib
         return lib
+
+
+def _warn_if_unlinted_compiler(lib) -> None:
+    """The kernels carry hand-counted `s_waitcnt` instructions that are only as right as the ISA the compiler emitted around them (tools/asm_lds_lint.py);
+    a library compiled by another hipcc than the one the lint last passed on (csrc/LINT_PASSED.json) says so once, at load time."""
+    try:
+        rec = _build.lint_record().get("hipcc")
+        comp = lib.cwm_compiler_version().decode()
+    except Exception:  # a library from before the entry point existed / no record in an installed copy
+        return
+    if rec and comp and rec != comp:
+        import warnings
+
+        warnings.warn("libcwm_hip.so was compiled by `%s`, but the ISA lint of its hand-counted waits last passed on `%s`: run `python tools/asm_lds_lint.py --record` "
+                      "(and the GPU soak, tests/test_soak_gpu.py) before trusting this build" % (comp, rec), RuntimeWarning, stacklevel=3)
 
 
 def dev_library_path() -> str:
