@@ -12,7 +12,7 @@
 // with the hardware transpose read --, and the four (max, sum, O^T) partials are merged pairwise through LDS at the end.
 // The result differs from the unsplit schedule by the order of the fp32 additions and by WHERE the split-bf16 rounding of P falls (every
 // wave exponentiates against its own running maximum): ~1e-5 relative, inside the parity tolerance like the regular schedule;
-// cwm_debug_set("attn_tail", 0) keeps the regular schedule (the kernels' bitwise cross-check uses it).
+// option "attn_tail" = 0 (cwm_model_set_option) keeps the regular schedule (the kernels' bitwise cross-check uses it).
 #pragma once
 #include "attention_device.h"
 
