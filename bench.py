@@ -2,6 +2,7 @@
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --workload prompts256 --gpus N          # BASELINE configs[3] alone: 256 prompts on one frame pair, sharded over N ranks
+    python bench.py --workload flowstats | prompt_build      # the kernels after / before the predictor path (one GPU)
                                                             # (strong scaling; per_rank_ms = every rank's {build, broadcast, own_prompts, predict, gather})
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -127,7 +128,7 @@ def cpu_baseline(cfg, k_vis, clump, seed, budget_s=20.0):
     # 0.78 s/forward vs 0.90 (8), 0.93 (32), 1.6 (64), 3.2 (128), 45 (256, oversubscribed)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     W = {k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, seed).items()}
-    B = 2
+    B = 8 if cfg.num_tokens <= 2048 else 2  # (ViT-B/8: batch 8 -- ~3 s per pass on 16 threads; the 6272-token models take ~10x longer per sample: batch 2)
     x = torch.from_numpy(S.synthetic_frames(B, cfg, seed))
     mask = torch.from_numpy(S.synthetic_masks(B, cfg, k_vis, seed, clump))
     spec = O.SPECS[cfg.name]
@@ -137,7 +138,7 @@ def cpu_baseline(cfg, k_vis, clump, seed, budget_s=20.0):
         while True:
             O.predict(W, spec, x, mask, frame=None)
             n += 1
-            if time.perf_counter() - t0 > budget_s or n >= 8:
+            if time.perf_counter() - t0 > budget_s or n >= 6:
                 break
         dt = time.perf_counter() - t0
     return {
@@ -166,8 +167,9 @@ def prompts_measure(args, rank, local_rank, world, distributed, model=None, step
         model.load_state_dict({k: torch.from_numpy(v) for k, v in S.synthetic_state_dict(cfg, 0).items()})
         model = model.to(dev).eval()
     G = segmentation.FlowGenerator(predictor=model, imagenet_normalize_inputs=True, temporal_dim=2)
-    x0 = torch.from_numpy(S.synthetic_frames(1, cfg, 0))[:, 0:1] if rank == 0 else None  # one image; frame 2 := frame 1
-    table = torch.from_numpy(S.synthetic_prompts(PROMPTS["total"], cfg, 0)) if rank == 0 else None
+    # (inputs resident in HBM when the timed region starts, like the frame pairs of the headline workload: rank 0 holds the image and the prompt table)
+    x0 = torch.from_numpy(S.synthetic_frames(1, cfg, 0))[:, 0:1].to(dev) if rank == 0 else None  # one image; frame 2 := frame 1
+    table = torch.from_numpy(S.synthetic_prompts(PROMPTS["total"], cfg, 0)).to(dev) if rank == 0 else None
     hooks = cdist.prompt_hooks(G, frame=-1)
     comm = cdist.get_comm(dev)   # N > 1: RCCL through the C ABI (cwm_comm_init); the torch group only hands the id around
     shapes = ((1, 1, cfg.in_chans) + tuple(cfg.img_size), (PROMPTS["total"], 4), cfg.num_tokens)
@@ -311,7 +313,7 @@ def run_imu(args, rank, local_rank, world, distributed):
     dom = max(("gemm_wide", "gemm_narrow", "attention"), key=lambda k: stats[k]["total_ms"])
     planes = 2 if args.mode == "parity" else 1
     names = {"gemm_wide": "cwm::gemm8p_kernel<%d>" % planes, "gemm_narrow": "cwm::gemm_bf16_kernel<%d, 128, 128, 2, 4, 2>" % planes,
-             "attention": "cwm::attention_%s" % ("pipe_kernel<2, 4>" if planes == 2 else "kernel<1>"),
+             "attention": "cwm::attention_pipe_kernel<%d, 4>" % planes,
              "cross_attention": "cwm::cross_attn_mfma_kernel (+ combine)", "context_self_attention": "cwm::small_attn_mfma_kernel"}
     dom_entry = entry(stats[dom])
     out["roofline"] = dict(dom_entry, bound="mfma", kernel=names[dom], edge_kernels=edge, **profile_fields("imu4", args.mode, names[dom], dom_entry["frac"]),
@@ -324,6 +326,193 @@ def run_imu(args, rank, local_rank, world, distributed):
     if rank == 0:
         out["build"] = build_info()
         print(json.dumps(out))
+
+
+# ---- the kernels on either side of the predictor path (prompt construction before it, flow-sample statistics after it) -------
+PEAK_F32_MFMA_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md (exact fp32 products: what torch.cov computes)
+
+
+def _stage_ms(fn, steps):
+    """Mean device time of `fn` over `steps` calls between two HIP events on torch's current stream -- the stream every C-ABI call of these workloads
+    launches on (`_lib.current_stream_handle`)."""
+    fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(steps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / steps
+
+
+def _hbm_entry(bytes_per_call, ms, kernels):
+    gbs = bytes_per_call / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "avg_us": 1e3 * ms, "bytes_per_call": bytes_per_call,
+            "kernels": kernels}
+
+
+def aux_traffic(workload, key):
+    """HBM bytes per launch of one kernel from the committed FETCH_SIZE / WRITE_SIZE passes of this command (profiles/pmc_summary_latest.json), or None."""
+    t, _, _ = pmc_profile(workload, "f32", key)
+    return t
+
+
+def flowstats_measure(S_samples, steps, dev, cpu=False):
+    """One frame pair's S counterfactual flow samples [1, 2, 224, 224, S] (the reference's layout: sample axis innermost) through the reductions of
+    segmentation.py:250-276, 479-547 at downsample 2 (P = 112 x 112 = 12544 positions): pooled magnitudes -> z-score prologue -> covariance [P, P] ->
+    mean motion map.  Every stage timed on its own; `value` is samples reduced per second over the default chain (features + covariance + motion map)."""
+    from counterfactualworldmodels_amd import flowstats as FS
+
+    H = W = 224
+    ds = 2
+    P = (H // ds) * (W // ds)
+    g = torch.Generator().manual_seed(0)
+    flows = (torch.randn(1, 2, H, W, S_samples, generator=g) * 2).to(dev)
+    x = FS.flow_features(flows, ds)
+    stages = {}
+    f_bytes = flows.numel() * 4
+    x_bytes = x.numel() * 4
+    ms = _stage_ms(lambda: FS.flow_features(flows, ds), steps)
+    stages["features"] = _hbm_entry(f_bytes + x_bytes, ms, ["flow_features_kernel"])
+    ms = _stage_ms(lambda: FS.transform_features(x.clone(), zscore=True), steps) - _stage_ms(lambda: x.clone(), steps)
+    stages["zscore_prologue"] = _hbm_entry(4 * x_bytes, ms, ["flow_colstats_kernel (2 passes over x)", "flow_apply_kernel (read + write)"])
+    ms_cov = _stage_ms(lambda: FS.feature_cov_rows(x, 0, P, True), steps)
+    out_bytes = P * P * 4
+    flops = 2.0 * P * P * S_samples
+    cov = _hbm_entry(out_bytes + 3 * x_bytes, ms_cov, ["flow_center_kernel", "flow_cov_kernel"])
+    tf = flops / (ms_cov * 1e-3) / 1e12
+    cov["as_mfma"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS, "flops_per_call": flops,
+                      "note": "fp32-input MFMA (exact fp32 products); the algorithmic count is the full [P, P] product 2 P^2 S that torch.cov performs"}
+    stages["covariance"] = cov
+    ms = _stage_ms(lambda: FS.compute_mean_motion_map(flows, normalize_per_sample=True), steps)
+    stages["motion_map"] = _hbm_entry(2 * f_bytes + H * W * 4 * 3, ms, ["flow_mag_minmax_kernel", "flow_motion_sum_kernel", "flow_map_finish_kernel"])
+
+    def chain():
+        FS.compute_flow_corrs(flows, downsample=ds, use_covariance=True)
+        FS.compute_mean_motion_map(flows, normalize_per_sample=True)
+
+    for _ in range(2):
+        chain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        chain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"value": S_samples * steps / dt, "ms_per_step": 1e3 * dt / steps, "stages": stages, "samples": S_samples, "positions": P}
+    if cpu:
+        from oracle import flowstats_oracle as FO
+
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        fc = flows.cpu()
+        t0 = time.perf_counter()
+        n = 0
+        while n < 4 and time.perf_counter() - t0 < 20.0:
+            FO.compute_flow_corrs(fc, ds, True)
+            FO.compute_mean_motion_map(fc, normalize_per_sample=True, normalize=True)
+            n += 1
+        dtc = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": S_samples * n / dtc, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "%d passes of the same chain (S = %d, 224x224, downsample 2) through oracle/flowstats_oracle.py, torch CPU fp32 on %d threads"
+                                         % (n, S_samples, torch.get_num_threads())}
+    return res
+
+
+def run_flowstats(args):
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    main_S, other_S = 256, 24
+    r = flowstats_measure(main_S, args.steps, dev, cpu=not args.no_cpu_baseline)
+    r2 = flowstats_measure(other_S, args.steps, dev)
+    cov = r["stages"]["covariance"]
+    roof = dict(cov["as_mfma"], kernel="cwm::flow_cov_kernel (+ flow_center_kernel)", avg_launch_us=cov["avg_us"], traffic=aux_traffic("flowstats", "cwm::flow_cov_kernel"),
+                as_hbm={k: cov[k] for k in ("achieved", "peak", "unit", "frac", "bytes_per_call")},
+                stages={k: v for k, v in r["stages"].items() if k != "covariance"},
+                note="S = 256: 2 P^2 S = 80.6 GFLOP of exact-fp32 MFMA against a 629-MB result: the fp32 matrix pipe bounds it (0.51 ms at peak vs 0.08 ms of HBM write); "
+                     "at S = 24 (secondary) the same kernel is bound by the 629-MB write.  HIP events around the stage's calls on the launching stream")
+    out = {
+        "metric": "counterfactual flow samples reduced/sec (224x224, downsample 2: features -> covariance [12544^2] -> motion map)", "value": r["value"], "unit": "samples/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": 2, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "config": {"workload": "flow-sample statistics of one frame pair (SURVEY.md 8 f-4; segmentation.py:250-276, 479-547), S = 256 samples",
+                                        "samples": main_S, "positions": r["positions"], "downsample": 2},
+        "roofline": roof,
+        "secondary": {"samples": other_S, "value": r2["value"], "unit": "samples/s", "ms_per_step": r2["ms_per_step"], "stages": r2["stages"],
+                      "note": "S = 24 (the demo notebooks' sample count): the covariance stage is bound by the HBM write of the [P, P] result"},
+        "build": build_info(),
+    }
+    if "cpu_baseline" in r:
+        out["cpu_baseline"] = r["cpu_baseline"]
+    print(json.dumps(out))
+
+
+def run_prompt_build(args):
+    """device-side construction of the 256 motion-counterfactual prompts of BASELINE configs[3] from one image (frames [256, 2, 3, 224, 224]
+    = 308 MB + masks [256, 1568]); reference: the per-sample loop of segmentation.py:324-338 over perturbation.py:245-289."""
+    from counterfactualworldmodels_amd import dist as cdist, segmentation
+
+    cfg = C.CONFIGS[PROMPTS["cfg"]]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    model = vmae.PretrainVisionTransformer(cfg, mode=args.mode)
+    G = segmentation.FlowGenerator(predictor=model, imagenet_normalize_inputs=True, temporal_dim=2)
+    x0 = torch.from_numpy(S.synthetic_frames(1, cfg, 0))[:, 0:1].to(dev)
+    table_h = torch.from_numpy(S.synthetic_prompts(PROMPTS["total"], cfg, 0))
+    table = table_h.to(dev)
+    build, rect, _ = cdist.prompt_hooks(G, frame=-1)
+    n = PROMPTS["total"]
+    frame_bytes = n * 2 * 3 * cfg.img_size[0] * cfg.img_size[1] * 4
+    mask_bytes = n * cfg.num_tokens
+    in_bytes = 3 * cfg.img_size[0] * cfg.img_size[1] * 4
+    xs, ms_ = build(x0, table)
+    assert xs.shape == (n, 2, 3) + tuple(cfg.img_size) and ms_.shape == (n, cfg.num_tokens)
+    t_all = _stage_ms(lambda: build(x0, table), args.steps)
+    t_masks = _stage_ms(lambda: build(x0, table, frames=False), args.steps)
+    t_32 = _stage_ms(lambda: build(x0, table[:32]), args.steps)
+    # the frames kernel alone through the C ABI (no torch index ops around it)
+    passive = (torch.arange(cfg.num_tokens, device=dev) >= cfg.tokens_per_frame)[None].expand(n, -1).contiguous()
+    active = passive.clone()
+    gw = cfg.img_size[1] // cfg.patch
+    active[torch.arange(n, device=dev), cfg.tokens_per_frame + table[:, 0].long() * gw + table[:, 1].long()] = False
+    shifts = table[:, 2:4].contiguous()
+    xb = x0.expand(-1, 2, -1, -1, -1)
+    t_kernel = _stage_ms(lambda: G._shift_rows(xb, passive, active, shifts, 1, True, samples_per_movie=n, masks=False), args.steps)
+    t_mask_kernel = _stage_ms(lambda: G._shift_rows(xb, passive, active, shifts, 1, True, samples_per_movie=n, frames=False), args.steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        build(x0, table)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {
+        "metric": "motion-counterfactual prompts built/sec (2x224x224 frames + 1568-token masks, ViT-B/8 grid)", "value": n * args.steps / dt, "unit": "prompts/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": 1, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 copies, u8 masks",
+        "data": "synthetic", "config": {"workload": "device-side construction of the 256 prompts of BASELINE configs[3] (SURVEY.md 8 f-1; segmentation.py:324-338, "
+                                                    "perturbation.py:245-289)", "prompts": n, "predictor_grid": cfg.name},
+        "roofline": dict(_hbm_entry(frame_bytes + in_bytes, t_kernel, ["shift_prompts_x_kernel"]), kernel="cwm::shift_prompts_x_kernel", avg_launch_us=1e3 * t_kernel,
+                         traffic=aux_traffic("prompt_build", "cwm::shift_prompts_x_kernel"),
+                         other_kernel={"cwm::shift_prompts_mask_kernel": _hbm_entry(3 * mask_bytes, t_mask_kernel, ["shift_prompts_mask_kernel"])},
+                         host_call_ms={"frames + masks, 256 prompts (torch index ops + both kernels)": t_all, "masks only, 256 prompts (rank 0 of a sharded call)": t_masks,
+                                       "frames + masks, 32 prompts (one rank's shard at 8 ranks)": t_32},
+                         note="algorithmic bytes = 256 x 1.2 MB of frames written + the 602-KB image read once; HIP events around the C-ABI call on the launching stream"),
+        "build": build_info(),
+    }
+    if not args.no_cpu_baseline:
+        from oracle import vmae_oracle as O
+
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        xc = x0.cpu().expand(-1, 2, -1, -1, -1).contiguous()
+        pas, act = passive.cpu().t()[None].contiguous(), active.cpu().t()[None].contiguous()  # [1, Nt, S]
+        sh = [tuple(int(v) for v in r) for r in table_h[:, 2:4].tolist()]
+        t0 = time.perf_counter()
+        k = 0
+        while k < 3 and time.perf_counter() - t0 < 20.0:
+            O.create_motion_counterfactuals(xc, pas, act, sh, cfg.patch, frame=1, fix_passive=True)
+            k += 1
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n * k / dtc, "unit": "prompts/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "%d passes over the same 256 prompts through oracle/vmae_oracle.py create_motion_counterfactuals (the reference's per-sample loop)" % k}
+    print(json.dumps(out))
 
 
 def count_gpus_without_hip():
@@ -378,7 +567,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="base8", choices=sorted(WORKLOADS) + ["prompts256", "imu4"])
+    ap.add_argument("--workload", default="base8", choices=sorted(WORKLOADS) + ["prompts256", "imu4", "flowstats", "prompt_build"])
     ap.add_argument("--mode", default="parity", choices=["parity", "fast"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -388,6 +577,11 @@ def main():
                     help="2 (library default): the batch runs as two half batches on two HIP streams; 1: one stream")
     args = ap.parse_args()
 
+    if args.workload in ("flowstats", "prompt_build"):  # one-GPU edge workloads: no launcher, no process group
+        if args.gpus != 1:
+            sys.stderr.write("bench.py: --workload %s measures one GPU\n" % args.workload)
+            sys.exit(2)
+        return run_flowstats(args) if args.workload == "flowstats" else run_prompt_build(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -494,7 +688,7 @@ def main():
     kernels = {  # (names as rocprofv3 prints them)
         "cwm::gemm8p_kernel<%d>" % planes: gemm_wide,                          # 256x256 8-phase: qkv, fc1, whole rounds of fc2
         "cwm::gemm_bf16_kernel<%d, 128, 128, 2, 4, 2>" % planes: gemm_narrow,  # 128x128, 8 waves: proj, narrow outputs, remainders
-        "cwm::attention_%s" % ("pipe_kernel<2, 4>" if planes == 2 else "kernel<1>"): attn,   # softmax(q k^T) v
+        "cwm::attention_pipe_kernel<%d, 4>" % planes: attn,   # softmax(q k^T) v
     }
 
     def tflops(st):

@@ -166,12 +166,15 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     ),
+    "cwm_mask_row_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "cwm_mask_flip_picks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "cwm_shift_prompts": (
         C.c_int,
         [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p] * 6,
     ),
     "cwm_flow_features": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "cwm_flow_cov": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 4),
+    "cwm_flow_transform_work_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "cwm_flow_transform": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "cwm_flow_motion_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)] + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cwm_flow_map_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_void_p]),
@@ -195,11 +198,25 @@ SIGNATURES = {
 DEV_SIGNATURES = {
     "cwm_gemm_tile_override": (C.c_int, [C.c_int] * 6),
     "cwm_bench_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
-    "cwm_bench_gemm_gapped": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_double)]),
     "cwm_bench_attention": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "cwm_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
     "cwm_debug_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
 }
+
+# the keys cwm_model_set_option / cwm_conj_set_option know (include/cwm_hip.h; csrc/engine.hip tuning_field)
+OPTION_KEYS = ("gemm_tile", "gemm_debug", "gemm_staged", "gemm_direct", "attn_kernel", "attn_remap", "attn_tail", "attn_ksplit", "prune_last_block", "index_fused",
+               "min_lane_rows", "conj_ctx_stream", "conj_attn")
+GEMM_DEBUG_TIMING_ONLY = 1 | 2 | 8  # ablation bits that make a forward return wrong outputs: refused by the production setters (development library: cwm_debug_set)
+
+
+def validate_option(key: str, value: int) -> None:
+    """What the library's setters would refuse, raised BEFORE a model stores the option for a handle it does not have yet (a bad key remembered there
+    would fail every later handle creation with an unrelated-looking error)."""
+    if key not in OPTION_KEYS:
+        raise CwmHipError(-1, "unknown option %s (known: %s)" % (key, ", ".join(OPTION_KEYS)))
+    if key == "gemm_debug" and int(value) & GEMM_DEBUG_TIMING_ONLY:
+        raise CwmHipError(-1, "gemm_debug bits 1, 2 and 8 are timing-only ablations (wrong outputs): development library only (cwm_debug_set)")
+
 
 _lib: Optional[C.CDLL] = None
 _dev_lib: Optional[C.CDLL] = None

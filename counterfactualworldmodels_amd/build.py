@@ -172,8 +172,30 @@ def _build_locked(out_path, extra, obj_dir, force, verbose):
     os.replace(tmp, dev_out)
     with open(stamp, "w") as fh:
         fh.write(shash)
+    if force and out_path == LIB_PATH:
+        clean_stale()
     check_lint_record()
     return out_path
+
+
+def clean_stale() -> list:
+    """`--force` on the production library also clears what earlier rounds left under build/: objects of sources that no longer exist and the
+    `side_*` directories of one-off side builds (CWM_HIPCC_EXTRA profiling builds) -- they travelled with every push to the GPU box.  Returns what it removed."""
+    root = os.path.join(PKG_DIR, "build")
+    gone = []
+    keep = {s + ".o" for s in SOURCES + DEV_SOURCES} | {"source_hash.txt", ".lock"}
+    prod = os.path.join(root, "prod")
+    if os.path.isdir(prod):
+        for f in os.listdir(prod):
+            if f not in keep:
+                os.remove(os.path.join(prod, f))
+                gone.append(os.path.join("prod", f))
+    if os.path.isdir(root):
+        for d in os.listdir(root):
+            if d.startswith("side_"):
+                shutil.rmtree(os.path.join(root, d), ignore_errors=True)
+                gone.append(d)
+    return gone
 
 
 if __name__ == "__main__":

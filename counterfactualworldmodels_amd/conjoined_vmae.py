@@ -135,7 +135,6 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
         """conjoined_vmae.py:722-732 with output_main only: the main stream sees (x, mask) unchanged ('rgb01')."""
         return ((x, mask, None),)
 
-    # ---- C-ABI plumbing ------------------------------------------------------------------------------
     # ---- C-ABI plumbing --------------------------------------------------------------------------
     def _library(self):
         """The shared object this module's handle lives in: libcwm_hip.so unless `use_library` chose the development one."""
@@ -153,11 +152,12 @@ class ConjoinedPaddedVisionTransformer(WeightSync, nn.Module):
 
     def set_option(self, key: str, value: int):
         """One execution option of THIS model (include/cwm_hip.h cwm_conj_set_option: "attn_kernel", "gemm_tile", "prune_last_block" ...): per handle, never
-        process-wide.  Options set before the first forward are applied when the handle is created."""
-        opts = self.__dict__.setdefault("_options", {})
-        opts[key] = int(value)
-        if getattr(self, "_handle", None) is not None:
+        process-wide.  Options set before the first forward are applied when the handle is created.  An unknown key / a refused value raises and leaves nothing behind."""
+        if getattr(self, "_handle", None) is not None:  # the library validates; remembered (for a re-created handle) only once it accepted
             self._check(self._library().cwm_conj_set_option(self._handle, key.encode(), int(value)))
+        else:
+            _lib.validate_option(key, int(value))
+        self.__dict__.setdefault("_options", {})[key] = int(value)
 
     def _ensure_handle(self, device: torch.device) -> int:
         lib = self._library()

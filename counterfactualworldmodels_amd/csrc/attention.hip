@@ -288,16 +288,17 @@ int launch_attention(const AttnParams& p_in, int planes, hipStream_t stream) {
     CWM_REQUIRE((int64_t)p.n_tok * 128 < (1ll << 31), "attention: %d tokens exceed the 32-bit tile offsets within one (batch, head)", p.n_tok);
     CWM_REQUIRE(p.q_off >= 0 && p.n_q >= 0 && p.q_off + p.n_q <= p.n_tok, "attention: query rows [%d, %d) outside the %d tokens", p.q_off, p.q_off + p.n_q, p.n_tok);
     const int nqb = ((p.n_q > 0 ? p.n_q : p.n_tok) + 127) / 128;
-    // Measured (tools/microbench.py attn, MI355X; profiles/r1q_microbench_attn.log):
-    //   parity mode: the software-pipelined kernel (3) is 10-13 % faster than the 4-wave kernel (1) on every model shape --
-    //     each wave overlaps the MFMAs of one tile with the softmax of the previous one; under this load the chip settles at
-    //     ~1.55-1.6 GHz (s_memtime vs s_memrealtime, tools/attn_prof.py), where both the matrix pipe and the VALU issue port
-    //     are ~70 % busy;
-    //   fast mode: one MFMA per product leaves the loop VALU-bound: kernel 1 is 1-5 % ahead on the B/8 sequences (792, 1568 tokens),
-    //     kernel 3 2-4 % ahead on the L/4 ones (3168, 6272) -> by sequence length;
-    //   (a staggered 8-wave kernel, "2", tied kernel 1 in parity mode and lost 25-35 % in fast mode: removed in round 4).
+    // Measured (tools/microbench.py attn_sweep / attn, MI355X, round 6: profiles/r6_microbench_attn_sweep.log, r6_microbench_attn.log -- 12 heads, ~2.4e8 score
+    // elements per launch at every length):
+    //   parity mode: the software-pipelined kernel (3) -- each wave overlaps the MFMAs of one tile with the softmax of the previous one -- is ahead from ~200 tokens
+    //     (196: 273 vs 280 us; 792: 203 vs 229; 1568: 178 vs 201; 6272: 1599 vs 1834), the 4-wave kernel (1) below (128: 114 vs 122; 40: 41.6 vs 43.3);
+    //   fast mode: one MFMA per product leaves the loop VALU-bound and the crossover sits higher: kernel 1 ahead up to ~400 tokens (256: 133 vs 146 us; 392: 141 vs 142),
+    //     a tie at 512 (102.3 vs 102.2), kernel 3 ahead from there (792: 106.7 vs 109.7; 1568: 88 vs 99; 6272: 756 vs 840).
+    //   Every sequence of the three model families (792 ... 6336 tokens) therefore runs kernel 3 in both modes; kernel 1 serves short sequences (test-sized grids).
+    //   (Rounds 1-5 kept kernel 1 in fast mode below 2048 tokens on the strength of a round-1 log that later kernel-3 work had overtaken: 2 % of the fast-mode step.
+    //   A staggered 8-wave kernel, "2", tied kernel 1 in parity mode and lost 25-35 % in fast mode: removed in round 4.)
     // Both produce bit-identical outputs (tests/test_kernels_gpu.py); Tuning.attn_kernel forces one.
-    const int kern = tn.attn_kernel ? tn.attn_kernel : ((planes == 2 || p.n_tok >= 2048) ? 3 : 1);
+    const int kern = tn.attn_kernel ? tn.attn_kernel : (p.n_tok >= (planes == 2 ? 160 : 512) ? 3 : 1);
     if (kern == 3) return launch_attention_pipe(p, planes, stream);
     CWM_REQUIRE(kern == 1, "attention: unknown kernel %d (1: 4-wave, 3: software-pipelined)", kern);
     const dim3 grid(nqb, p.batch * p.heads);

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_pipe_kerne
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qcol = lane & 31, hh = lane >> 5;
-    int N = p.n_tok;
+    const int N = p.n_tok;
     const int NQ = p.n_q > 0 ? p.n_q : N;
     const int nkt_all = (N + 63) / 64;
     // work item of this workgroup (1-D grid in dispatch order).  Key-split tail round: the items of a last round that would fill at most half of

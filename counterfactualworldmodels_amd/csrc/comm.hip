@@ -143,6 +143,7 @@ extern "C" int cwm_comm_size(const cwm_comm* c) { return c ? c->nranks : -1; }
 
 extern "C" int cwm_broadcast(cwm_comm* c, void* buf_dev, size_t bytes, int root, void* stream) {
     CWM_REQUIRE(c && buf_dev && root >= 0 && root < c->nranks, "cwm_broadcast: bad argument");
+    if (int rc = cwm_require_device(c->device, "cwm_broadcast")) return rc;
     if (bytes == 0) return CWM_OK;
     CWM_RCCL_CHECK(g_rccl.Broadcast(buf_dev, buf_dev, bytes, kNcclUint8, root, c->comm, (hipStream_t)stream));
     return CWM_OK;
@@ -150,6 +151,7 @@ extern "C" int cwm_broadcast(cwm_comm* c, void* buf_dev, size_t bytes, int root,
 
 extern "C" int cwm_allgather(cwm_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream) {
     CWM_REQUIRE(c && send_dev && recv_dev, "cwm_allgather: bad argument");
+    if (int rc = cwm_require_device(c->device, "cwm_allgather")) return rc;
     if (bytes_per_rank == 0) return CWM_OK;
     CWM_RCCL_CHECK(g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, kNcclUint8, c->comm, (hipStream_t)stream));
     return CWM_OK;
@@ -157,6 +159,7 @@ extern "C" int cwm_allgather(cwm_comm* c, const void* send_dev, void* recv_dev, 
 
 extern "C" int cwm_allgatherv(cwm_comm* c, const void* send_dev, void* recv_dev, const size_t* offsets, const size_t* counts, void* stream) {
     CWM_REQUIRE(c && recv_dev && offsets && counts, "cwm_allgatherv: bad argument");
+    if (int rc = cwm_require_device(c->device, "cwm_allgatherv")) return rc;
     CWM_REQUIRE(send_dev || counts[c->rank] == 0, "cwm_allgatherv: null send buffer for a non-empty block");
     // one fused group of per-root broadcasts: rank r's block lands at recv + offsets[r] on every rank (its own block too)
     CWM_RCCL_CHECK(g_rccl.GroupStart());
@@ -177,6 +180,7 @@ extern "C" int cwm_allgatherv(cwm_comm* c, const void* send_dev, void* recv_dev,
 
 extern "C" int cwm_allreduce_sum_f32(cwm_comm* c, float* buf_dev, size_t count, void* stream) {
     CWM_REQUIRE(c && buf_dev, "cwm_allreduce_sum_f32: bad argument");
+    if (int rc = cwm_require_device(c->device, "cwm_allreduce_sum_f32")) return rc;
     if (count == 0) return CWM_OK;
     CWM_RCCL_CHECK(g_rccl.AllReduce(buf_dev, buf_dev, count, kNcclFloat32, kNcclSum, c->comm, (hipStream_t)stream));
     return CWM_OK;

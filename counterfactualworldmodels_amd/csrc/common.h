@@ -81,6 +81,11 @@ void cwm_set_error(const char* fmt, ...);
 // "done" flag would leave a second device without it (engine.hip; thread-safe).  Returns 0 or CWM_ERR_HIP.
 int cwm_set_max_lds(const void* kernel, int bytes);
 
+// A handle (model, communicator) belongs to the HIP device that was current when it was created: its weights, workspace, streams and RCCL
+// communicator live there, and a launch from another current device would run on the wrong GPU without any error.  0 when the calling thread's
+// current device is `handle_device`, else CWM_ERR_INVALID with a message naming `what` (engine.hip).
+int cwm_require_device(int handle_device, const char* what);
+
 #define CWM_HIP_CHECK(expr)                                                                  \
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \

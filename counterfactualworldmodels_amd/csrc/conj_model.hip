@@ -586,6 +586,7 @@ extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* 
     memset(&a_copy, 0, sizeof(a_copy));
     memcpy(&a_copy, a_in, std::min<size_t>(a_in->struct_size, sizeof(a_copy)));
     const cwm_conj_forward_args* a = &a_copy;
+    if (int rc = cwm_require_device(m->eng.device, "cwm_conj_forward")) return rc;
     CWM_REQUIRE(a->x_dev && a->mask_dev && a->ctx_dev && a->ctx_mask_dev && a->y_tokens_dev, "cwm_conj_forward: x, mask, context, context mask and y are required");
     CWM_REQUIRE(a->mode == CWM_MODE_FAST || a->mode == CWM_MODE_PARITY, "cwm_conj_forward: bad mode %d", a->mode);
     const int B = a->batch, vm = a->n_vis_max, vc = a->n_vis_ctx_max;
@@ -641,7 +642,9 @@ extern "C" int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* 
 
 extern "C" int cwm_conj_set_option(cwm_conj_model* m, const char* key, int value) {
     CWM_REQUIRE(m && key, "cwm_conj_set_option: null argument");
-    CWM_REQUIRE(tuning_set(m->eng.tune, key, value) == 0, "cwm_conj_set_option: unknown option %s", key);
+    const int rc = tuning_set_production(m->eng.tune, key, value);
+    CWM_REQUIRE(rc != -2, "cwm_conj_set_option: gemm_debug bits 1, 2 and 8 are timing-only ablations (wrong outputs): development library only (cwm_debug_set)");
+    CWM_REQUIRE(rc == 0, "cwm_conj_set_option: unknown option %s", key);
     return CWM_OK;
 }
 

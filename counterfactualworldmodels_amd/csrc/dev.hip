@@ -13,6 +13,8 @@
 
 using namespace cwm;
 
+void cwm_set_pretend_device(int d);  // engine.hip
+
 namespace {
 struct Scratch {
     std::vector<void*> ptrs;
@@ -58,6 +60,10 @@ extern "C" int cwm_debug_set(const char* key, int value) {
     CWM_REQUIRE(key, "cwm_debug_set: null key");
     if (!strcmp(key, "gemm_prof")) return gemm_prof_dump();            // query (profiling builds)
     if (!strcmp(key, "attn_prof")) return attention_pipe_prof(value);  // query (profiling builds)
+    if (!strcmp(key, "pretend_device")) {  // the device index this thread's wrong-device checks see (-1: the real one): tests on a one-GPU box
+        cwm_set_pretend_device(value);
+        return CWM_OK;
+    }
     CWM_REQUIRE(tuning_set(thread_tuning(), key, value) == 0, "cwm_debug_set: unknown key %s", key);
     return CWM_OK;
 }
@@ -152,60 +158,6 @@ extern "C" int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters,
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *avg_us = 1e3 * ms / iters;
-    return CWM_OK;
-}
-
-// One wave idling for `us` microseconds (100 MHz s_memrealtime): a low-power gap between two launches of the duty-cycle probe.
-__global__ void idle_kernel(int us) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(64);
-}
-
-// Duty-cycle probe (tools/power_probe.py): `iters` launches of one GEMM with an idle gap of gap_us after each; returns the mean
-// duration of the GEMM launches alone (one HIP event pair per launch, the first quarter discarded as warm-up).
-extern "C" int cwm_bench_gemm_gapped(int M, int N, int K, int mode, int epi, int iters, int gap_us, double* avg_us) {
-    CWM_REQUIRE(avg_us && M > 0 && N > 0 && K > 0 && iters >= 4 && gap_us >= 0, "cwm_bench_gemm_gapped: bad argument");
-    const int planes = mode == CWM_MODE_PARITY ? 2 : 1;
-    const int Kp = round_up(K, 64), Np = round_up(N, 256);
-    Scratch sc;
-    bf16* A = sc.get<bf16>((size_t)2 * M * Kp);
-    bf16* W = sc.get<bf16>((size_t)2 * Np * Kp);
-    float* bias = sc.get<float>(Np);
-    float* Cm = sc.get<float>((size_t)M * N);
-    bf16* G = sc.get<bf16>((size_t)2 * M * N + 64 * 1024);
-    CWM_REQUIRE(A && W && bias && Cm && G, "cwm_bench_gemm_gapped: out of device memory");
-    fill_bf16(A, (int64_t)2 * M * Kp, 1, 1.0f);
-    fill_bf16(W, (int64_t)2 * Np * Kp, 2, 0.05f);
-    fill_f32(bias, Np, 3, 0.1f);
-    fill_f32(Cm, (int64_t)M * N, 4, 1.0f);
-    GemmParams p;
-    memset(&p, 0, sizeof(p));
-    p.A = A; p.lda = Kp; p.W = W;
-    p.M = M; p.N = N; p.K = Kp; p.bias = bias;
-    if (epi == 1) {
-        p.epi = EPI_BF16_GELU; p.out_hi = G; p.ldo = N;
-    } else {
-        p.epi = EPI_F32; p.C = Cm; p.ldc = N; p.resid = Cm; p.ldr = N;
-    }
-    p.tune = &thread_tuning();
-    std::vector<hipEvent_t> ev(2 * iters);
-    for (auto& e : ev) CWM_HIP_CHECK(hipEventCreate(&e));
-    for (int i = 0; i < iters; ++i) {
-        CWM_HIP_CHECK(hipEventRecord(ev[2 * i], 0));
-        if (int rc = launch_gemm(p, planes, 0)) return rc;
-        CWM_HIP_CHECK(hipEventRecord(ev[2 * i + 1], 0));
-        if (gap_us > 0) hipLaunchKernelGGL(idle_kernel, dim3(1), dim3(64), 0, 0, gap_us);
-    }
-    CWM_HIP_CHECK(hipDeviceSynchronize());
-    double tot = 0;
-    int n = 0;
-    for (int i = iters / 4; i < iters; ++i, ++n) {
-        float ms = 0.f;
-        CWM_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
-        tot += ms;
-    }
-    for (auto& e : ev) (void)hipEventDestroy(e);
-    *avg_us = 1e3 * tot / n;
     return CWM_OK;
 }
 

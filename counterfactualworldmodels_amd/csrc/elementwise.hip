@@ -241,40 +241,93 @@ __global__ __launch_bounds__(256) void index_gather_kernel(const PatchGatherPara
     const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int L = p.perm_stride ? p.perm_stride : p.Nt;  // mask row length (padded predictors: real tokens + pad slots)
     const uint8_t* m = mask + (size_t)b * L;
-    const int per = (L + 255) / 256;
-    const int lo = min(t * per, L), hi = min(lo + per, L);
-    int c = 0;
-    for (int i = lo; i < hi; ++i) c += (m[i] == 0);
-    int incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int before = incl - c;
-    for (int w2 = 0; w2 < wave; ++w2) before += wave_tot[w2];
-    const int total_vis = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    const bool lead = blockIdx.x == 0;
+    // perm / rank of the sample are written by ALL of its workgroups (every one has the whole scan anyway): thread slice t belongs to workgroup t mod nw.
+    // Until round 5 workgroup 0 wrote all L entries alone: 25 dependent rounds of scattered 4-byte stores on the critical path of a 34-us launch.
+    const int nw = min((int)gridDim.x, 256);
+    const bool writer = (t % nw) == (int)blockIdx.x;
     int* pr = perm_out + (size_t)b * L;
     int* rk = rank_out ? rank_out + (size_t)b * L : nullptr;
-    int v = before;
-    for (int i = lo; i < hi; ++i) {
-        if (m[i] == 0) {
-            if (v < p.n_rows) vis_tab[v] = i;
-            if (lead) {
-                pr[v] = i;
-                if (rk) rk[i] = v;
+    int total_vis;
+    if ((L & 15) == 0 && L <= 256 * 32 && ((uintptr_t)mask & 15) == 0) {
+        // Round 6: the thread's slice of the mask row -- 16 or 32 consecutive bytes -- comes in with one or two 16-byte loads and STAYS in registers for the
+        // second pass.  (Round 5: (L + 255) / 256 = 25 single-byte loads per thread at a 25-byte lane stride, twice; on the long rows of ViT-L/4 and the IMU model
+        // -- L = 6272 / 6336 -- that scan, repeated by each of the sample's ~150 workgroups, was the launch: 34 / 51 us for 10 - 19 MB.)
+        const int per = L <= 256 * 16 ? 16 : 32;
+        const int lo = t * per;
+        u32x4 w0 = u32x4{0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u}, w1 = w0;  // (past the row: "masked", never counted)
+        if (lo < L) w0 = *reinterpret_cast<const u32x4*>(m + lo);
+        if (per == 32 && lo + 16 < L) w1 = *reinterpret_cast<const u32x4*>(m + lo + 16);
+        const int n_mine = lo >= L ? 0 : min(per, L - lo);
+        auto zero_bytes = [](unsigned x) {  // number of bytes of x that are 0 (any non-zero byte = masked, as `m[i] == 0` read it)
+            const unsigned y = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+            return __popc(~(y | x | 0x7F7F7F7Fu));
+        };
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c += zero_bytes(w0[q]) + zero_bytes(w1[q]);
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int v = incl - c;
+        for (int w2 = 0; w2 < wave; ++w2) v += wave_tot[w2];
+        total_vis = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (k < n_mine) {
+                const unsigned word = k < 16 ? w0[(k >> 2) & 3] : w1[(k >> 2) & 3];
+                const bool visible = ((word >> (8 * (k & 3))) & 0xFFu) == 0;
+                const int i = lo + k;
+                if (visible) {
+                    if (v < p.n_rows) vis_tab[v] = i;
+                    if (writer) {
+                        pr[v] = i;
+                        if (rk) rk[i] = v;
+                    }
+                    ++v;
+                } else if (writer) {
+                    const int pos = total_vis + (i - v);
+                    pr[pos] = i;
+                    if (rk) rk[i] = pos;
+                }
             }
-            ++v;
-        } else if (lead) {
-            const int pos = total_vis + (i - v);
-            pr[pos] = i;
-            if (rk) rk[i] = pos;
+        }
+    } else {  // rows that are not whole 16-byte groups (test-sized grids): the byte loop
+        const int per = (L + 255) / 256;
+        const int lo = min(t * per, L), hi = min(lo + per, L);
+        int c = 0;
+        for (int i = lo; i < hi; ++i) c += (m[i] == 0);
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int v = incl - c;
+        for (int w2 = 0; w2 < wave; ++w2) v += wave_tot[w2];
+        total_vis = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        for (int i = lo; i < hi; ++i) {
+            if (m[i] == 0) {
+                if (v < p.n_rows) vis_tab[v] = i;
+                if (writer) {
+                    pr[v] = i;
+                    if (rk) rk[i] = v;
+                }
+                ++v;
+            } else if (writer) {
+                const int pos = total_vis + (i - v);
+                pr[pos] = i;
+                if (rk) rk[i] = pos;
+            }
         }
     }
-    if (lead && t == 0) err_rows[b] = total_vis != n_vis ? 1 : 0;
+    if (blockIdx.x == 0 && t == 0) err_rows[b] = total_vis != n_vis ? 1 : 0;
     __syncthreads();
 
     const int per_row = p.C * p.P;
@@ -489,23 +542,27 @@ int launch_unembed(const UnembedParams& p, hipStream_t stream) {
 // fix_passive: 0 = the movie as given; 1 = every frame := frame 0 (`make_static_movie`); 2 = `MakeStatic` (perturbation.py:120-145)
 // applied before the shift: only the patches that `masks` leaves visible are replaced by their frame-0 pixels.
 // ---------------------------------------------------------------------------------------------
+// One thread = 4 horizontally adjacent pixels of FOUR consecutive image rows (y = 4 yq .. 4 yq + 3: one patch row block, P is a multiple of 4), so the
+// source decision -- which patch, which frame -- is taken once for four independent 16-byte loads and stores.  (Until round 5: one 16-byte store per thread
+// behind six integer divisions and a dependent mask byte load; profiles/r6_bench_prompt_build*.json.)  The prompts are written once and read once by the
+// predictor's gather: streaming (non-temporal) stores.
 __global__ __launch_bounds__(256) void shift_prompts_x_kernel(const ShiftPromptParams p) {
-    const int w4 = p.W / 4;
-    const int64_t total = (int64_t)p.B * p.S * p.T * p.C * p.H * w4;
+    const int w4 = p.W / 4, h4 = p.H / 4;
+    const int64_t total = (int64_t)p.B * p.S * p.T * p.C * h4 * w4;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     int64_t r = gid;
     const int x4 = (int)(r % w4); r /= w4;
-    const int y = (int)(r % p.H); r /= p.H;
+    const int yq = (int)(r % h4); r /= h4;
     const int c = (int)(r % p.C); r /= p.C;
     const int t = (int)(r % p.T);
     const int i = (int)(r / p.T);
     const int b = i / p.S;
-    const int x0 = x4 * 4;
+    const int x0 = x4 * 4, y = yq * 4;
     int ft = p.fix_passive == 1 ? 0 : t;
     int sy = y, sx = x0;
+    const int gw = p.W / p.P, gh = p.H / p.P, n = gh * gw;
     if (t == p.frame) {
-        const int gw = p.W / p.P, gh = p.H / p.P, n = gh * gw;
         const int dy = p.shifts[2 * i], dx = p.shifts[2 * i + 1];
         const int pi = y / p.P - dy, pj = x0 / p.P - dx;
         if (pi >= 0 && pi < gh && pj >= 0 && pj < gw && p.active[(size_t)i * p.T * n + (size_t)p.frame * n + pi * gw + pj] == 0) {
@@ -514,11 +571,15 @@ __global__ __launch_bounds__(256) void shift_prompts_x_kernel(const ShiftPromptP
         }
     }
     if (p.fix_passive == 2) {  // MakeStatic (perturbation.py:120-145): the patches `masks` leaves visible take their frame-0 pixels
-        const int gw = p.W / p.P, n = (p.H / p.P) * gw;
         if (p.masks[(size_t)i * p.T * n + (size_t)t * n + (sy / p.P) * gw + sx / p.P] == 0) ft = 0;
     }
-    const float4 v = *reinterpret_cast<const float4*>(p.x + ((((size_t)b * p.T + ft) * p.C + c) * p.H + sy) * p.W + sx);
-    *reinterpret_cast<float4*>(p.x_out + ((((size_t)i * p.T + t) * p.C + c) * p.H + y) * p.W + x0) = v;
+    const float* src = p.x + ((((size_t)b * p.T + ft) * p.C + c) * p.H + sy) * p.W + sx;
+    float* dst = p.x_out + ((((size_t)i * p.T + t) * p.C + c) * p.H + y) * p.W + x0;
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)k * p.W);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<f32x4*>(dst + (size_t)k * p.W));
 }
 
 __global__ __launch_bounds__(256) void shift_prompts_mask_kernel(const ShiftPromptParams p) {
@@ -543,10 +604,82 @@ int launch_shift_prompts(const ShiftPromptParams& p, hipStream_t stream) {
     CWM_REQUIRE(p.P % 4 == 0 && p.W % 4 == 0 && p.H % p.P == 0 && p.W % p.P == 0, "shift_prompts: bad patch/image size");
     CWM_REQUIRE(p.frame >= 0 && p.frame < p.T, "shift_prompts: frame out of range");
     CWM_REQUIRE(p.fix_passive >= 0 && p.fix_passive <= 2, "shift_prompts: fix_passive must be 0, 1 or 2");
-    const int64_t tx = (int64_t)p.B * p.S * p.T * p.C * p.H * (p.W / 4);
+    CWM_REQUIRE(p.H % 4 == 0, "shift_prompts: the image height must be a multiple of 4");
+    const int64_t tx = (int64_t)p.B * p.S * p.T * p.C * (p.H / 4) * (p.W / 4);
     const int64_t tm = (int64_t)p.B * p.S * p.T * (p.H / p.P) * (p.W / p.P);
-    hipLaunchKernelGGL(shift_prompts_x_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(shift_prompts_mask_kernel, dim3((unsigned)((tm + 255) / 256)), dim3(256), 0, stream, p);
+    // either output may be absent: the sharded loop builds the masks of ALL prompts on rank 0 (the rectangulariser is the one cross-row step) but frames only for
+    // the rows a rank predicts (dist.py)
+    if (p.x_out) hipLaunchKernelGGL(shift_prompts_x_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, stream, p);
+    if (p.mask_out) hipLaunchKernelGGL(shift_prompts_mask_kernel, dim3((unsigned)((tm + 255) / 256)), dim3(256), 0, stream, p);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// `RectangularizeMasks` on device masks (masking.py:90-132) without reading the masks back: the host needs only the per-row COUNTS to decide
+// the target and to draw the reference's `torch.randperm(#candidates)[:surplus]` per changed row (the draws depend on the counts alone); the
+// picks -- "the k-th masked (or visible) token of row r in ascending order" -- come back as a small table and are applied here, every pick of a
+// row against the row as it was BEFORE any of them (the reference indexes one `torch.where` list per row).  Integer-exact.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_row_counts_kernel(const uint8_t* __restrict__ mask, int Nt, int* __restrict__ counts) {
+    __shared__ int red[4];
+    const uint8_t* m = mask + (size_t)blockIdx.x * Nt;
+    int c = 0;
+    for (int i = threadIdx.x; i < Nt; i += 256) c += (m[i] != 0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// table: [R | rows[R] | offsets[R + 1] | to_value[R] | picks[offsets[R]]]; one workgroup per changed row
+constexpr int kFlipMaxTokens = 16384;
+__global__ __launch_bounds__(256) void mask_flip_picks_kernel(uint8_t* __restrict__ mask, int Nt, const int* __restrict__ table) {
+    __shared__ unsigned bits[kFlipMaxTokens / 32];
+    __shared__ int wave_tot[4];
+    const int R = table[0], r = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row = table[1 + r], p0 = table[1 + R + r], p1 = table[1 + R + r + 1], to = table[2 + 2 * R + r];
+    const int* picks = table + 2 + 3 * R;
+    uint8_t* m = mask + (size_t)row * Nt;
+    for (int i = t; i < (Nt + 31) / 32; i += 256) bits[i] = 0u;
+    __syncthreads();
+    for (int q = p0 + t; q < p1; q += 256) {
+        const int k = picks[q];
+        if (k >= 0 && k < Nt) atomicOr(&bits[k >> 5], 1u << (k & 31));
+    }
+    const int per = (Nt + 255) / 256;
+    const int lo = min(t * per, Nt), hi = min(lo + per, Nt);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += ((m[i] != 0) != (to != 0));  // candidates: tokens whose state is not `to` yet
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();  // (also: the bitmap is complete)
+    int v = incl - c;
+    for (int w2 = 0; w2 < wave; ++w2) v += wave_tot[w2];
+    for (int i = lo; i < hi; ++i) {
+        if ((m[i] != 0) != (to != 0)) {
+            if (bits[v >> 5] & (1u << (v & 31))) m[i] = (uint8_t)(to ? 1 : 0);
+            ++v;
+        }
+    }
+}
+
+int launch_mask_row_counts(const uint8_t* mask, int B, int Nt, int* counts, hipStream_t stream) {
+    hipLaunchKernelGGL(mask_row_counts_kernel, dim3((unsigned)B), dim3(256), 0, stream, mask, Nt, counts);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_mask_flip_picks(uint8_t* mask, int Nt, const int* table, int n_rows, hipStream_t stream) {
+    CWM_REQUIRE(Nt <= kFlipMaxTokens, "mask_flip_picks: rows of %d tokens exceed the %d-token pick bitmap", Nt, kFlipMaxTokens);
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(mask_flip_picks_kernel, dim3((unsigned)n_rows), dim3(256), 0, stream, mask, Nt, table);
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -32,6 +32,18 @@ int cwm_set_max_lds(const void* kernel, int bytes) {
     done.insert({dev, kernel});
     return 0;
 }
+// (development library only -- csrc/dev.hip "pretend_device": the device index this THREAD's checks see instead of hipGetDevice's, so that the
+// wrong-device refusal can be exercised on a one-GPU box; -1 = off.  libcwm_hip.so exports no way to set it.)
+static thread_local int g_pretend_device = -1;
+void cwm_set_pretend_device(int d) { g_pretend_device = d; }
+int cwm_require_device(int handle_device, const char* what) {
+    int cur = -1;
+    CWM_HIP_CHECK(hipGetDevice(&cur));
+    if (g_pretend_device >= 0) cur = g_pretend_device;
+    CWM_REQUIRE(cur == handle_device, "%s: the handle was created on HIP device %d but the calling thread's current device is %d (hipSetDevice(%d) first)", what,
+                handle_device, cur, handle_device);
+    return 0;
+}
 extern "C" const char* cwm_version(void) { return "cwm_hip 0.6.0 gfx950"; }
 #ifndef CWM_SRC_HASH
 #define CWM_SRC_HASH "unknown"
@@ -71,6 +83,13 @@ int tuning_set(Tuning& t, const char* key, int value) {
     if (!f) return -1;
     t.*(f->member) = value;
     return 0;
+}
+// What cwm_model_set_option / cwm_conj_set_option accept: every option, minus the values that make a forward return WRONG outputs with CWM_OK -- the
+// timing-only ablation bits of "gemm_debug" (1 skip the epilogue's stores, 2 skip the epilogue, 8 skip every LayerNorm).  Those stay reachable through
+// the development library alone (cwm_debug_set on the thread that then creates the model).  0, -1 unknown key, -2 development-only value.
+int tuning_set_production(Tuning& t, const char* key, int value) {
+    if (!strcmp(key, "gemm_debug") && (value & (1 | 2 | 8))) return -2;
+    return tuning_set(t, key, value);
 }
 int tuning_get(const Tuning& t, const char* key, int* value) {
     const TuningField* f = tuning_field(key);
@@ -240,6 +259,7 @@ int Engine::make_pos_embedding_f32(float** dst, int n_pos, int d, int extra_rows
 
 int Engine::load_weight(const char* key, const float* data, int on_device, const int64_t* shape, int ndim) {
     CWM_REQUIRE(key && data && shape, "load_weight: null argument");
+    if (int rc = cwm_require_device(device, "load_weight")) return rc;
     auto it = slots.find(key);
     CWM_REQUIRE(it != slots.end(), "unexpected key in state_dict: %s", key);
     Slot& s = it->second;

@@ -62,18 +62,72 @@ __global__ void flow_center_kernel(const float* __restrict__ x, int rows, int S,
 }
 
 // ---- covariance / correlation slab: out[b][i - row0][j] = scale * sum_s xc[b][i][s] xc[b][j][s] ---------------------------
-// 128 x 128 output tile per 256-thread workgroup, 64 x 64 per wave = 4 x 4 fragments of v_mfma_f32_16x16x4_f32.
+// 128 x 128 output tile per 256-thread workgroup, 64 x 64 per wave = 4 x 4 fragments of v_mfma_f32_16x16x4_f32 (exact fp32 products).
 // D^T orientation: A operand = the j rows, B operand = the i rows, so lane l holds out[i = 16 fi + l % 16][j = 16 fj + 4 (l / 16) + r].
-constexpr int kCovBK = 32;  // samples staged per step
-__global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__ xc, const float* __restrict__ inv_std, int P, int S, int row0,
-                                                       int nrows, int use_cov, float* __restrict__ out) {
-    __shared__ float lds_i[128][kCovBK + 1];
-    __shared__ float lds_j[128][kCovBK + 1];
+// Round 6 (profiles/r6_bench_flowstats*.json: 1.45 ms at S = 256 = 0.35 of the fp32 matrix peak, 281 us at S = 24 = 2.2 TB/s of writes):
+//  * the matrix is symmetric: a call for the WHOLE matrix (row0 = 0, nrows = P) computes the tiles on and above the diagonal only and writes every
+//    off-diagonal tile twice, once transposed -- half the MFMA work, the same bytes (SYM).  Row slabs (the sharded form) keep the rectangular grid;
+//  * operands come in as 16-byte loads into registers one K step AHEAD of the MFMAs that consume them (the loads of step k + 1 are in flight under the
+//    MFMAs of step k; until round 5 every step began with an exposed global -> LDS round trip between two barriers);
+//  * the epilogue goes through LDS so that every store instruction writes whole 256-byte row segments in both orientations (until round 5: 16 rows x 64 B
+//    per instruction straight from the accumulators).
+constexpr int kCovBK = 32;     // samples staged per step
+constexpr int kCovPitch = 36;  // floats per staged operand row: 16-byte aligned rows, and rows r, r + 1 sit 36 mod 64 banks apart (fragment reads conflict-free)
+constexpr int kCovEpiPitch = 68;
+
+__device__ __forceinline__ void cov_load_step(const float* __restrict__ xb, int P, int S, int r0, int k0, int tid, bool vec, f32x4 (&v)[4]) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int e = tid + 256 * n, r = e >> 3, k = k0 + (e & 7) * 4;
+        const int row = r0 + r;
+        f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < P) {
+            const float* src = xb + (size_t)row * S + k;
+            if (vec) {
+                if (k < S) q = *reinterpret_cast<const f32x4*>(src);  // (S % 4 == 0: the four samples are in range together)
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (k + c < S) q[c] = src[c];
+            }
+        }
+        v[n] = q;
+    }
+}
+
+__device__ __forceinline__ void cov_store_step(float* lds, int tid, const f32x4 (&v)[4]) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int e = tid + 256 * n;
+        *reinterpret_cast<f32x4*>(lds + (e >> 3) * kCovPitch + (e & 7) * 4) = v[n];
+    }
+}
+
+template <bool SYM>
+__global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__ xc, const float* __restrict__ inv_std, int P, int S, int row0, int nrows,
+                                                       int use_cov, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 128 * kCovPitch];  // operand tiles i | j; the epilogue's four wave buffers afterwards
+    float* lds_i = lds;
+    float* lds_j = lds + 128 * kCovPitch;
     const int b = blockIdx.z;
-    const int i0 = row0 + blockIdx.y * 128, j0 = blockIdx.x * 128;
+    int ti, tj;
+    if constexpr (SYM) {  // linear id -> (ti, tj), tj >= ti, rows of the upper triangle in order
+        const int T = (P + 127) / 128, id = blockIdx.x;
+        int t = (int)(((2.0f * T + 1.0f) - sqrtf((2.0f * T + 1.0f) * (2.0f * T + 1.0f) - 8.0f * (float)id)) * 0.5f);
+        t = max(0, min(t, T - 1));
+        while (t > 0 && t * T - t * (t - 1) / 2 > id) --t;                   // first id of row t: t T - t (t - 1) / 2
+        while (t + 1 < T && (t + 1) * T - (t + 1) * t / 2 <= id) ++t;
+        ti = t;
+        tj = t + (id - (t * T - t * (t - 1) / 2));
+    } else {
+        ti = blockIdx.y;
+        tj = blockIdx.x;
+    }
+    const int i0 = row0 + ti * 128, j0 = tj * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const float* xb = xc + (size_t)b * P * S;
+    const bool vec = (S & 3) == 0;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -81,23 +135,26 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    f32x4 vi[4], vj[4];
+    cov_load_step(xb, P, S, i0, 0, tid, vec, vi);
+    cov_load_step(xb, P, S, j0, 0, tid, vec, vj);
+    cov_store_step(lds_i, tid, vi);
+    cov_store_step(lds_j, tid, vj);
+    __syncthreads();
     for (int k0 = 0; k0 < S; k0 += kCovBK) {
-        // stage 128 rows x 32 samples of both operands (zero fill past P / S)
-        for (int e = tid; e < 128 * kCovBK; e += 256) {
-            const int r = e / kCovBK, k = e - r * kCovBK;
-            const bool kin = k0 + k < S;
-            lds_i[r][k] = (kin && i0 + r < P) ? xb[(size_t)(i0 + r) * S + k0 + k] : 0.f;
-            lds_j[r][k] = (kin && j0 + r < P) ? xb[(size_t)(j0 + r) * S + k0 + k] : 0.f;
+        const bool more = k0 + kCovBK < S;
+        if (more) {  // next step's operands: in flight under this step's MFMAs
+            cov_load_step(xb, P, S, i0, k0 + kCovBK, tid, vec, vi);
+            cov_load_step(xb, P, S, j0, k0 + kCovBK, tid, vec, vj);
         }
-        __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < kCovBK; kk += 4) {
             const int kq = kk + (lane >> 4);
             float av[4], bv[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                av[t] = lds_j[wj * 64 + t * 16 + (lane & 15)][kq];  // A operand: rows = j
-                bv[t] = lds_i[wi * 64 + t * 16 + (lane & 15)][kq];  // B operand: columns = i
+                av[t] = lds_j[(wj * 64 + t * 16 + (lane & 15)) * kCovPitch + kq];  // A operand: rows = j
+                bv[t] = lds_i[(wi * 64 + t * 16 + (lane & 15)) * kCovPitch + kq];  // B operand: columns = i
             }
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi)
@@ -105,38 +162,77 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
                 for (int fj = 0; fj < 4; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fj], bv[fi], acc[fi][fj], 0, 0, 0);
         }
         __syncthreads();
+        if (more) {
+            cov_store_step(lds_i, tid, vi);
+            cov_store_step(lds_j, tid, vj);
+            __syncthreads();
+        }
     }
 
-    const float inv_n1 = 1.0f / (float)(S - 1);
+    // ---- epilogue: scale, clip, NaN -> 0 in registers; then through this wave's LDS buffer, 32 output rows at a time ----
+    const float inv_n1 = 1.0f / (float)(S - 1);  // torch.cov: unbiased (correction = 1)
+    const int ib = i0 + wi * 64, jb = j0 + wj * 64;
 #pragma unroll
     for (int fi = 0; fi < 4; ++fi) {
-        const int i = i0 + wi * 64 + fi * 16 + (lane & 15);
-        if (i >= P || i >= row0 + nrows) continue;
-        const float si = use_cov ? 1.0f : inv_std[(size_t)b * P + i];
+        const int i = ib + fi * 16 + (lane & 15);
+        const float si = (use_cov || i >= P) ? 1.0f : inv_std[(size_t)b * P + i];
 #pragma unroll
         for (int fj = 0; fj < 4; ++fj) {
-            const int j = j0 + wj * 64 + fj * 16 + (lane >> 4) * 4;
-            if (j >= P) continue;
-            f32x4 v = acc[fi][fj] * inv_n1;  // torch.cov: unbiased (correction = 1)
-            float o[4];
+            const int j = jb + fj * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float c = v[r];
+                float c = acc[fi][fj][r] * inv_n1;
                 if (!use_cov && j + r < P) {
                     c = c * si * inv_std[(size_t)b * P + j + r];
                     // torch.corrcoef clips to [-1, 1] and keeps a NaN (a constant row: 0 * inf) a NaN; fminf / fmaxf would turn it into -1
                     if (c == c) c = fminf(1.0f, fmaxf(-1.0f, c));
                 }
-                o[r] = (c != c) ? 0.f : c;  // NaN -> 0 (segmentation.py:541)
+                acc[fi][fj][r] = (c != c) ? 0.f : c;  // NaN -> 0 (segmentation.py:541)
             }
-            float* dst = out + ((size_t)b * nrows + (i - row0)) * P + j;
-            if (j + 3 < P && (P & 3) == 0) {
-                *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+        }
+    }
+    float* buf = lds + wave * (32 * kCovEpiPitch);  // 4 x 32 x 68 floats = 34816 B of the 36864-B operand area (every wave is past its last fragment read: barrier above)
+    const int i_end = min(P, row0 + nrows);
+    const bool row_vec = (P & 3) == 0;
+    // orient 0: rows = i, columns = j (the tile itself); orient 1 (SYM, off-diagonal tiles): rows = j, columns = i (its mirror image)
+    const int n_orient = (SYM && ti != tj) ? 2 : 1;
+    for (int orient = 0; orient < n_orient; ++orient) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (orient == 0) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int fj = 0; fj < 4; ++fj)
+                        *reinterpret_cast<f32x4*>(buf + (f * 16 + (lane & 15)) * kCovEpiPitch + fj * 16 + (lane >> 4) * 4) = acc[half * 2 + f][fj];
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (j + r < P) dst[r] = o[r];
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) buf[(f * 16 + (lane >> 4) * 4 + r) * kCovEpiPitch + fi * 16 + (lane & 15)] = acc[fi][half * 2 + f][r];
             }
+            __syncthreads();
+            const int rbase = (orient == 0 ? ib : jb) + half * 32, cbase = orient == 0 ? jb : ib;
+            const int r_end = orient == 0 ? i_end : P, r_off = orient == 0 ? row0 : 0;  // (the mirror image exists only when the call covers every row)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const int idx = lane + 64 * n, rr = idx >> 4, c4 = (idx & 15) * 4;
+                const int row = rbase + rr, col = cbase + c4;
+                if (row < r_end && col < P) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(buf + rr * kCovEpiPitch + c4);
+                    float* dst = out + ((size_t)b * nrows + (row - r_off)) * P + col;
+                    if (row_vec) {
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < P) dst[r] = v[r];
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -172,61 +268,111 @@ __global__ __launch_bounds__(256) void flow_argsort_rows_kernel(float* __restric
     }
 }
 
-// per column (b, s): {min, max, mean, unbiased std} over the P positions -> st[b][s]; sums in float64 (mean first, then the
-// squared deviations: two passes over a column that stays in L2)
-__global__ __launch_bounds__(256) void flow_colstats_kernel(const float* __restrict__ x, int P, int S, float4* __restrict__ st) {
+// per column (b, s): {min, max, mean, unbiased std} over the P positions -> st[b][s].
+// Round 6: the positions are cut into chunks, one workgroup per (64 columns, chunk) -- until round 5 ONE workgroup walked all P = 12544 positions of its 64
+// columns twice (4 workgroups for S = 256: 1.1 ms for a 12.8-MB matrix, profiles/r6_bench_flowstats_before.json).  Every thread keeps a float64 Welford state
+// (count, mean, M2) over its rows -- one pass, no cancellation --; the four row groups of a workgroup and then the chunks are merged with Chan's formula in a
+// FIXED order (deterministic).  A NaN is tracked explicitly (torch.amin / amax propagate it; a NaN-free column holding +inf and -inf has a NaN mean but
+// min = -inf, max = +inf).
+struct ColPartial {
+    double n, mean, m2;
+    float mn, mx;
+    int nan;
+    int pad;
+};
+
+__device__ __forceinline__ void col_merge(double& n, double& mean, double& m2, double nb, double meanb, double m2b) {
+    if (nb == 0.0) return;
+    if (n == 0.0) {
+        n = nb; mean = meanb; m2 = m2b;
+        return;
+    }
+    const double tot = n + nb, d = meanb - mean;
+    mean += d * (nb / tot);
+    m2 += m2b + d * d * (n * nb / tot);
+    n = tot;
+}
+
+constexpr int kColChunkRows = 112;  // positions per workgroup (P = 12544: 112 chunks x S / 64 column groups)
+
+__global__ __launch_bounds__(256) void flow_colpartial_kernel(const float* __restrict__ x, int P, int S, int n_chunks, ColPartial* __restrict__ part) {
+    __shared__ double rn[4][64], rmean[4][64], rm2[4][64];
     __shared__ float rmn[4][64], rmx[4][64];
-    __shared__ double rs[4][64];
-    const int b = blockIdx.y, s = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    __shared__ int rnan[4][64];
+    const int b = blockIdx.z, chunk = blockIdx.y, c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int s = blockIdx.x * 64 + c;
     const bool in = s < S;
+    const int p0 = chunk * kColChunkRows, p1 = min(P, p0 + kColChunkRows);
     const float* xb = x + (size_t)b * P * S + (in ? s : 0);
+    double n = 0.0, mean = 0.0, m2 = 0.0;
     float mn = INFINITY, mx = -INFINITY;
-    double sum = 0.0;  // (a NaN in the column makes the sum, and with it min / max / mean / std, NaN: torch.amin / amax / mean / std propagate it)
+    int has_nan = 0;
     if (in)
-        for (int p = rg; p < P; p += 4) {
+        for (int p = p0 + rg; p < p1; p += 4) {
             const float v = xb[(size_t)p * S];
+            has_nan |= (v != v) ? 1 : 0;
             mn = fminf(mn, v);
             mx = fmaxf(mx, v);
-            sum += (double)v;
+            n += 1.0;
+            const double d = (double)v - mean;
+            mean += d / n;
+            m2 += d * ((double)v - mean);
         }
-    rmn[rg][threadIdx.x & 63] = mn;
-    rmx[rg][threadIdx.x & 63] = mx;
-    rs[rg][threadIdx.x & 63] = sum;
-    __syncthreads();
-    const int c = threadIdx.x & 63;
-    const double mean = (rs[0][c] + rs[1][c] + rs[2][c] + rs[3][c]) / (double)P;
-    __syncthreads();
-    double sq = 0.0;
-    if (in)
-        for (int p = rg; p < P; p += 4) {
-            const double d = (double)xb[(size_t)p * S] - mean;
-            sq += d * d;
-        }
-    rs[rg][c] = sq;
+    rn[rg][c] = n; rmean[rg][c] = mean; rm2[rg][c] = m2;
+    rmn[rg][c] = mn; rmx[rg][c] = mx; rnan[rg][c] = has_nan;
     __syncthreads();
     if (rg == 0 && in) {
-        const double var = (rs[0][c] + rs[1][c] + rs[2][c] + rs[3][c]) / (double)(P - 1);  // P == 1: 0 / 0 = NaN, as torch.std
-        const bool has_nan = mean != mean;
-        const float qn = __builtin_nanf("");
-        st[(size_t)b * S + s] = make_float4(has_nan ? qn : fminf(fminf(rmn[0][c], rmn[1][c]), fminf(rmn[2][c], rmn[3][c])),
-                                            has_nan ? qn : fmaxf(fmaxf(rmx[0][c], rmx[1][c]), fmaxf(rmx[2][c], rmx[3][c])), (float)mean, (float)sqrt(var));
+        for (int g = 1; g < 4; ++g) {
+            col_merge(n, mean, m2, rn[g][c], rmean[g][c], rm2[g][c]);
+            mn = fminf(mn, rmn[g][c]);
+            mx = fmaxf(mx, rmx[g][c]);
+            has_nan |= rnan[g][c];
+        }
+        ColPartial o;
+        o.n = n; o.mean = mean; o.m2 = m2; o.mn = mn; o.mx = mx; o.nan = has_nan; o.pad = 0;
+        part[((size_t)b * n_chunks + chunk) * S + s] = o;
     }
 }
 
+__global__ void flow_colfinish_kernel(const ColPartial* __restrict__ part, int P, int S, int n_chunks, float4* __restrict__ st) {
+    const int b = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    float mn = INFINITY, mx = -INFINITY;
+    int has_nan = 0;
+    for (int ch = 0; ch < n_chunks; ++ch) {  // chunks in ascending order: the result does not depend on the launch
+        const ColPartial q = part[((size_t)b * n_chunks + ch) * S + s];
+        col_merge(n, mean, m2, q.n, q.mean, q.m2);
+        mn = fminf(mn, q.mn);
+        mx = fmaxf(mx, q.mx);
+        has_nan |= q.nan;
+    }
+    const double var = m2 / (double)(P - 1);  // P == 1: 0 / 0 = NaN, as torch.std
+    const float qn = __builtin_nanf("");
+    st[(size_t)b * S + s] = make_float4(has_nan ? qn : mn, has_nan ? qn : mx, (float)mean, (float)sqrt(var));
+}
+
 // elementwise forms; op: 1 x * (x > a), 2 (x > a), 3 ((x - min) > a * (max - min)), 4 x / max(colmax, eps), 5 (x - mean) / max(std, eps)
-__global__ void flow_apply_kernel(float* __restrict__ x, int64_t total, int P, int S, int op, float a, float eps, const float4* __restrict__ st) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const float v = x[i];
+// grid (column groups of 64, row blocks, B): a thread keeps its column's statistics in registers and walks 16 positions
+constexpr int kApplyRows = 16;
+__global__ __launch_bounds__(256) void flow_apply_kernel(float* __restrict__ x, int P, int S, int op, float a, float eps, const float4* __restrict__ st) {
+    const int b = blockIdx.z, s = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (s >= S) return;
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (op >= 3) c = st[(i / ((int64_t)P * S)) * S + (i % S)];
-    float o;
-    if (op == 1) o = v * ((v > a) ? 1.0f : 0.0f);
-    else if (op == 2) o = (v > a) ? 1.0f : 0.0f;
-    else if (op == 3) o = ((v - c.x) > a * (c.y - c.x)) ? 1.0f : 0.0f;
-    else if (op == 4) o = v / (c.y != c.y ? c.y : fmaxf(c.y, eps));   // tensor.clamp(min=eps) keeps a NaN
-    else o = (v - c.z) / (c.w != c.w ? c.w : fmaxf(c.w, eps));
-    x[i] = o;
+    if (op >= 3) c = st[(size_t)b * S + s];
+    const int p0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kApplyRows;
+    float* xb = x + (size_t)b * P * S + s;
+#pragma unroll 4
+    for (int p = p0; p < min(P, p0 + kApplyRows); ++p) {
+        const float v = xb[(size_t)p * S];
+        float o;
+        if (op == 1) o = v * ((v > a) ? 1.0f : 0.0f);
+        else if (op == 2) o = (v > a) ? 1.0f : 0.0f;
+        else if (op == 3) o = ((v - c.x) > a * (c.y - c.x)) ? 1.0f : 0.0f;
+        else if (op == 4) o = v / (c.y != c.y ? c.y : fmaxf(c.y, eps));   // tensor.clamp(min=eps) keeps a NaN
+        else o = (v - c.z) / (c.w != c.w ? c.w : fmaxf(c.w, eps));
+        xb[(size_t)p * S] = o;
+    }
 }
 
 // ---- motion maps ---------------------------------------------------------------------------------------------------------
@@ -296,6 +442,73 @@ __global__ void flow_motion_sum_kernel(const float* __restrict__ f, int64_t sb, 
     sum[i] = acc;
 }
 
+// ---- the reference layout [B, C, H, W, S] with the sample axis innermost and (H, W, S) packed (sw == S, sh == W S, ss == 1): round 6 -----------------
+// The kernels above give a thread one pixel (or one sample) and let it walk the other axis with a stride: every 4-byte load of a wave sits in a different
+// cache line (S = 256: 388 us for 2 x 103 MB, profiles/r6_bench_flowstats_before.json).  For the packed layout a channel plane is ONE contiguous array of
+// H W S floats: a workgroup takes 64 consecutive pixels = 64 S consecutive floats per channel, loads them with coalesced 4-byte loads (lanes along the
+// sample axis), keeps the magnitudes in LDS [64][S + 1] and then reduces along whichever axis the pass needs:
+//   pass 1 (per-sample range): thread s scans the 64 pixels of its column -> one atomicMin / atomicMax per (workgroup, sample) on the float bits (magnitudes
+//          are >= 0, where unsigned order = float order; min starts at 0xFFFFFFFF, max at 0);
+//   pass 2 (the sum over the samples): thread p walks the S samples of its pixel IN SAMPLE ORDER -- the same additions in the same order as the strided kernel
+//          above (bit-identical to it).
+constexpr int kMagPix = 64;
+
+__device__ __forceinline__ void mag_tile_to_lds(const float* __restrict__ f, int64_t sb, int64_t sc, int b, int C, int HW, int S, int pix0, float* mag) {
+    const int npix = min(kMagPix, HW - pix0);
+    const int n = npix * S;
+    const float* fb = f + b * sb + (int64_t)pix0 * S;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float v = fb[c * sc + e];
+            a += v * v;
+        }
+        const int pl = e / S;
+        mag[pl * (S + 1) + (e - pl * S)] = sqrtf(a);
+    }
+}
+
+__global__ __launch_bounds__(256) void flow_mag_minmax_packed_kernel(const float* __restrict__ f, int64_t sb, int64_t sc, int C, int HW, int S,
+                                                                     unsigned* __restrict__ mn_bits, unsigned* __restrict__ mx_bits) {
+    extern __shared__ float mag[];  // [64][S + 1]
+    const int b = blockIdx.y, pix0 = blockIdx.x * kMagPix;
+    mag_tile_to_lds(f, sb, sc, b, C, HW, S, pix0, mag);
+    __syncthreads();
+    const int npix = min(kMagPix, HW - pix0);
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        float mn = INFINITY, mx = -INFINITY;
+        for (int pl = 0; pl < npix; ++pl) {
+            const float m = mag[pl * (S + 1) + s];
+            mn = fminf(mn, m);
+            mx = fmaxf(mx, m);
+        }
+        if (mn == mn && mn != INFINITY) atomicMin(&mn_bits[(size_t)b * S + s], __float_as_uint(mn));
+        if (mx == mx && mx != -INFINITY) atomicMax(&mx_bits[(size_t)b * S + s], __float_as_uint(mx));
+    }
+}
+
+__global__ __launch_bounds__(256) void flow_motion_sum_packed_kernel(const float* __restrict__ f, int64_t sb, int64_t sc, int C, int HW, int S,
+                                                                     const unsigned* __restrict__ mn_bits, const unsigned* __restrict__ mx_bits, float eps,
+                                                                     float* __restrict__ sum) {
+    extern __shared__ float mag[];  // [64][S + 1]
+    const int b = blockIdx.y, pix0 = blockIdx.x * kMagPix;
+    mag_tile_to_lds(f, sb, sc, b, C, HW, S, pix0, mag);
+    __syncthreads();
+    const int npix = min(kMagPix, HW - pix0);
+    if ((int)threadIdx.x >= npix) return;
+    const float* row = mag + threadIdx.x * (S + 1);
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) {
+        float m = row[s];
+        if (mn_bits) {
+            const float lo = __uint_as_float(mn_bits[(size_t)b * S + s]), hi = __uint_as_float(mx_bits[(size_t)b * S + s]);
+            m = (m - lo) / fmaxf(hi - lo, eps);
+        }
+        acc += m;
+    }
+    sum[(size_t)b * HW + pix0 + threadIdx.x] = acc;
+}
+
 // map = sum * scale; if normalize: (map - min) / max(max - min, eps) over (H, W) per b.  One workgroup per b.
 __global__ void flow_map_finish_kernel(float* __restrict__ map, int HW, float scale, int normalize, float eps) {
     __shared__ float red[32];
@@ -336,8 +549,14 @@ extern "C" int cwm_flow_cov(const float* x_dev, int B, int P, int S, int row0, i
     hipStream_t s = (hipStream_t)stream;
     const int rows = B * P;
     hipLaunchKernelGGL(flow_center_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x_dev, rows, S, xc_work_dev, inv_std_work_dev);
-    const dim3 grid((unsigned)((P + 127) / 128), (unsigned)((nrows + 127) / 128), (unsigned)B);
-    hipLaunchKernelGGL(flow_cov_kernel, grid, dim3(256), 0, s, xc_work_dev, inv_std_work_dev, P, S, row0, nrows, use_covariance ? 1 : 0, out_dev);
+    const int T = (P + 127) / 128;
+    if (row0 == 0 && nrows == P) {  // the whole (symmetric) matrix: tiles on and above the diagonal, each off-diagonal one written twice
+        hipLaunchKernelGGL(flow_cov_kernel<true>, dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)B), dim3(256), 0, s, xc_work_dev, inv_std_work_dev, P, S, 0, P,
+                           use_covariance ? 1 : 0, out_dev);
+    } else {
+        const dim3 grid((unsigned)T, (unsigned)((nrows + 127) / 128), (unsigned)B);
+        hipLaunchKernelGGL(flow_cov_kernel<false>, grid, dim3(256), 0, s, xc_work_dev, inv_std_work_dev, P, S, row0, nrows, use_covariance ? 1 : 0, out_dev);
+    }
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -346,13 +565,20 @@ extern "C" int cwm_flow_transform(float* x_dev, int B, int P, int S, int spearma
                                   float* stats_work_dev, void* stream) {
     CWM_REQUIRE(x_dev && B > 0 && P > 0 && S > 0, "cwm_flow_transform: bad argument");
     CWM_REQUIRE(thresh_mode >= 0 && thresh_mode <= 3, "cwm_flow_transform: thresh_mode must be 0 (none), 1 (x * (x > t)), 2 (x > t) or 3 (range threshold)");
-    CWM_REQUIRE(!(thresh_mode == 3 || normalize || zscore) || stats_work_dev, "cwm_flow_transform: the column statistics need the [B][S][4] work buffer");
+    CWM_REQUIRE(!(thresh_mode == 3 || normalize || zscore) || stats_work_dev, "cwm_flow_transform: the column statistics need the work buffer (cwm_flow_transform_work_bytes)");
+    CWM_REQUIRE(((uintptr_t)stats_work_dev & 15) == 0, "cwm_flow_transform: the work buffer must be 16-byte aligned");
     CWM_REQUIRE(!spearman || S <= 4096, "cwm_flow_transform: Spearman ranks support at most 4096 samples (S=%d)", S);
     hipStream_t s = (hipStream_t)stream;
-    const int64_t total = (int64_t)B * P * S;
-    const unsigned eblocks = (unsigned)((total + 255) / 256);
     float4* st = reinterpret_cast<float4*>(stats_work_dev);
-    const dim3 sgrid((unsigned)((S + 63) / 64), (unsigned)B);
+    // work buffer (cwm_flow_transform_work_bytes): [B][S] float4 statistics, then the [B][n_chunks][S] partials of the column pass
+    const int n_chunks = (P + kColChunkRows - 1) / kColChunkRows;
+    ColPartial* part = stats_work_dev ? reinterpret_cast<ColPartial*>(stats_work_dev + (size_t)4 * B * S) : nullptr;
+    const dim3 pgrid((unsigned)((S + 63) / 64), (unsigned)n_chunks, (unsigned)B), fgrid((unsigned)((S + 63) / 64), (unsigned)B);
+    const dim3 agrid((unsigned)((S + 63) / 64), (unsigned)((P + 4 * kApplyRows - 1) / (4 * kApplyRows)), (unsigned)B);
+    auto colstats = [&]() {
+        hipLaunchKernelGGL(flow_colpartial_kernel, pgrid, dim3(256), 0, s, x_dev, P, S, n_chunks, part);
+        hipLaunchKernelGGL(flow_colfinish_kernel, fgrid, dim3(64), 0, s, part, P, S, n_chunks, st);
+    };
     if (spearman) {
         const size_t smem = (size_t)4 * S * sizeof(float);
         if (smem > 48 * 1024)
@@ -360,21 +586,27 @@ extern "C" int cwm_flow_transform(float* x_dev, int B, int P, int S, int spearma
         hipLaunchKernelGGL(flow_argsort_rows_kernel, dim3((unsigned)((B * P + 3) / 4)), dim3(256), smem, s, x_dev, B * P, S);
     }
     if (thresh_mode == 1 || thresh_mode == 2) {
-        hipLaunchKernelGGL(flow_apply_kernel, dim3(eblocks), dim3(256), 0, s, x_dev, total, P, S, thresh_mode, thresh, eps, st);
+        hipLaunchKernelGGL(flow_apply_kernel, agrid, dim3(256), 0, s, x_dev, P, S, thresh_mode, thresh, eps, st);
     } else if (thresh_mode == 3) {
-        hipLaunchKernelGGL(flow_colstats_kernel, sgrid, dim3(256), 0, s, x_dev, P, S, st);
-        hipLaunchKernelGGL(flow_apply_kernel, dim3(eblocks), dim3(256), 0, s, x_dev, total, P, S, 3, thresh, eps, st);
+        colstats();
+        hipLaunchKernelGGL(flow_apply_kernel, agrid, dim3(256), 0, s, x_dev, P, S, 3, thresh, eps, st);
     }
     if (normalize) {
-        hipLaunchKernelGGL(flow_colstats_kernel, sgrid, dim3(256), 0, s, x_dev, P, S, st);
-        hipLaunchKernelGGL(flow_apply_kernel, dim3(eblocks), dim3(256), 0, s, x_dev, total, P, S, 4, 0.f, eps, st);
+        colstats();
+        hipLaunchKernelGGL(flow_apply_kernel, agrid, dim3(256), 0, s, x_dev, P, S, 4, 0.f, eps, st);
     }
     if (zscore) {
-        hipLaunchKernelGGL(flow_colstats_kernel, sgrid, dim3(256), 0, s, x_dev, P, S, st);
-        hipLaunchKernelGGL(flow_apply_kernel, dim3(eblocks), dim3(256), 0, s, x_dev, total, P, S, 5, 0.f, eps, st);
+        colstats();
+        hipLaunchKernelGGL(flow_apply_kernel, agrid, dim3(256), 0, s, x_dev, P, S, 5, 0.f, eps, st);
     }
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+extern "C" size_t cwm_flow_transform_work_bytes(int B, int P, int S) {
+    if (B <= 0 || P <= 0 || S <= 0) return 0;
+    const size_t n_chunks = (size_t)(P + kColChunkRows - 1) / kColChunkRows;
+    return (size_t)16 * B * S + sizeof(ColPartial) * (size_t)B * n_chunks * S;
 }
 
 extern "C" int cwm_flow_motion_sum(const float* flows_dev, const int64_t* strides, int B, int C, int H, int W, int S, int normalize_per_sample,
@@ -382,6 +614,27 @@ extern "C" int cwm_flow_motion_sum(const float* flows_dev, const int64_t* stride
     CWM_REQUIRE(flows_dev && strides && sum_dev && B > 0 && C > 0 && H > 0 && W > 0 && S > 0, "cwm_flow_motion_sum: bad argument");
     CWM_REQUIRE(!normalize_per_sample || minmax_work_dev, "cwm_flow_motion_sum: per-sample normalisation needs the [B][S][2] work buffer");
     hipStream_t s = (hipStream_t)stream;
+    // the reference's layout (sample axis innermost, (H, W, S) packed): the coalesced kernels; any other strides: the strided ones
+    const size_t smem = (size_t)kMagPix * (S + 1) * sizeof(float);
+    if (strides[4] == 1 && strides[3] == S && strides[2] == (int64_t)W * S && smem <= 150 * 1024) {
+        const int HW = H * W;
+        const dim3 grid((unsigned)((HW + kMagPix - 1) / kMagPix), (unsigned)B);
+        unsigned *mn = nullptr, *mx = nullptr;
+        if (smem > 48 * 1024) {
+            if (int rc = cwm_set_max_lds((const void*)flow_mag_minmax_packed_kernel, (int)smem)) return rc;
+            if (int rc = cwm_set_max_lds((const void*)flow_motion_sum_packed_kernel, (int)smem)) return rc;
+        }
+        if (normalize_per_sample) {  // work buffer [B][S][2] floats used as [B][S] min bits | [B][S] max bits
+            mn = reinterpret_cast<unsigned*>(minmax_work_dev);
+            mx = mn + (size_t)B * S;
+            CWM_HIP_CHECK(hipMemsetAsync(mn, 0xFF, (size_t)B * S * sizeof(unsigned), s));
+            CWM_HIP_CHECK(hipMemsetAsync(mx, 0x00, (size_t)B * S * sizeof(unsigned), s));
+            hipLaunchKernelGGL(flow_mag_minmax_packed_kernel, grid, dim3(256), smem, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx);
+        }
+        hipLaunchKernelGGL(flow_motion_sum_packed_kernel, grid, dim3(256), smem, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx, eps, sum_dev);
+        CWM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     float2* mm = nullptr;
     if (normalize_per_sample) {
         mm = reinterpret_cast<float2*>(minmax_work_dev);

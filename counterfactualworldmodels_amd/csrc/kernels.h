@@ -33,6 +33,7 @@ const Tuning& default_tuning();
 // development library's cwm_debug_set changed this THREAD's copy (libcwm_hip.so exports no way to)
 Tuning& thread_tuning();
 int tuning_set(Tuning& t, const char* key, int value);  // 0, or -1 for an unknown key
+int tuning_set_production(Tuning& t, const char* key, int value);  // the production setters: -2 for the timing-only ablation bits of "gemm_debug" (engine.hip)
 int tuning_get(const Tuning& t, const char* key, int* value);
 
 enum GemmEpilogue : int {
@@ -140,6 +141,9 @@ int launch_layernorm(const LayerNormParams& p, int planes, hipStream_t stream);
 // mask[B,Nt] (1 = masked) -> perm[B,Nt] = [visible tokens ascending | masked tokens ascending];
 // err[0] is set to 1 if any row's visible count != n_vis.
 int launch_mask_to_perm(const uint8_t* mask, int B, int Nt, int n_vis, int* perm, int* err, hipStream_t stream);
+// RectangularizeMasks on device masks (elementwise.hip): masked count per row; apply the host's picks [R | rows | offsets | to_value | picks] in place
+int launch_mask_row_counts(const uint8_t* mask, int B, int Nt, int* counts, hipStream_t stream);
+int launch_mask_flip_picks(uint8_t* mask, int Nt, const int* table, int n_rows, hipStream_t stream);
 
 struct PatchGatherParams {
     const float* x;  // frames; element (b,c,t,y,x) at b*sb + c*sc + t*st + y*W + x

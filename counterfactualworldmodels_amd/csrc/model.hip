@@ -264,10 +264,18 @@ static int forward_lane(cwm_model* m, const cwm_forward_args* a, int b0, int B, 
     return CWM_OK;
 }
 
-extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a) {
-    CWM_REQUIRE(m && a, "cwm_forward: null argument");
-    CWM_REQUIRE(a->struct_size >= offsetof(cwm_forward_args, stream) + sizeof(void*), "cwm_forward: args->struct_size = %u is smaller than cwm_forward_args (set it to sizeof(cwm_forward_args))",
-                a->struct_size);
+extern "C" int cwm_forward(cwm_model* m, const cwm_forward_args* a_in) {
+    CWM_REQUIRE(m && a_in, "cwm_forward: null argument");
+    // the caller's struct may end before fields a later version appends: copy what it has, the rest stays zero (= not requested).  The upper bound
+    // catches a caller built against the 0.5 header (no struct_size: the low half of its x_dev pointer lands here).
+    CWM_REQUIRE(a_in->struct_size >= offsetof(cwm_forward_args, stream) + sizeof(void*) && a_in->struct_size <= 4096,
+                "cwm_forward: args->struct_size = %u is not a cwm_forward_args (set it to sizeof(cwm_forward_args); callers built against the 0.5 header must be rebuilt)",
+                a_in->struct_size);
+    cwm_forward_args a_copy;
+    memset(&a_copy, 0, sizeof(a_copy));
+    memcpy(&a_copy, a_in, std::min<size_t>(a_in->struct_size, sizeof(a_copy)));
+    const cwm_forward_args* a = &a_copy;
+    if (int rc = cwm_require_device(m->eng.device, "cwm_forward")) return rc;
     CWM_REQUIRE(a->x_dev && a->mask_dev && a->y_tokens_dev, "cwm_forward: x_dev, mask_dev and y_tokens_dev are required");
     CWM_REQUIRE(a->mode == CWM_MODE_FAST || a->mode == CWM_MODE_PARITY, "cwm_forward: bad mode %d", a->mode);
     const cwm_config& c = m->cfg;
@@ -341,7 +349,9 @@ extern "C" int cwm_model_set_lanes(cwm_model* m, int lanes) {
 
 extern "C" int cwm_model_set_option(cwm_model* m, const char* key, int value) {
     CWM_REQUIRE(m && key, "cwm_model_set_option: null argument");
-    CWM_REQUIRE(tuning_set(m->eng.tune, key, value) == 0, "cwm_model_set_option: unknown option %s", key);
+    const int rc = tuning_set_production(m->eng.tune, key, value);
+    CWM_REQUIRE(rc != -2, "cwm_model_set_option: gemm_debug bits 1, 2 and 8 are timing-only ablations (wrong outputs): development library only (cwm_debug_set)");
+    CWM_REQUIRE(rc == 0, "cwm_model_set_option: unknown option %s", key);
     return CWM_OK;
 }
 
@@ -557,10 +567,20 @@ extern "C" int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const 
     return CWM_OK;
 }
 
+extern "C" int cwm_mask_row_counts(const uint8_t* mask_dev, int B, int Nt, int32_t* counts_dev, void* stream) {
+    CWM_REQUIRE(mask_dev && counts_dev && B > 0 && Nt > 0, "cwm_mask_row_counts: bad argument");
+    return launch_mask_row_counts(mask_dev, B, Nt, counts_dev, (hipStream_t)stream);
+}
+
+extern "C" int cwm_mask_flip_picks(uint8_t* mask_dev, int B, int Nt, const int32_t* table_dev, int n_rows, void* stream) {
+    CWM_REQUIRE(mask_dev && table_dev && B > 0 && Nt > 0 && n_rows >= 0 && n_rows <= B, "cwm_mask_flip_picks: bad argument");
+    return launch_mask_flip_picks(mask_dev, Nt, table_dev, n_rows, (hipStream_t)stream);
+}
+
 extern "C" int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int P, int frame, int S, int fix_passive,
                                  const uint8_t* active_dev, const uint8_t* masks_dev, const int32_t* shifts_dev, float* x_out_dev,
                                  uint8_t* mask_out_dev, void* stream) {
-    CWM_REQUIRE(x_dev && active_dev && masks_dev && shifts_dev && x_out_dev && mask_out_dev, "cwm_shift_prompts: null argument");
+    CWM_REQUIRE(active_dev && masks_dev && shifts_dev && (x_out_dev || mask_out_dev) && (x_dev || !x_out_dev), "cwm_shift_prompts: null argument");
     CWM_REQUIRE(B > 0 && S > 0 && T > 0 && C > 0 && P > 0, "cwm_shift_prompts: bad sizes");
     ShiftPromptParams p;
     memset(&p, 0, sizeof(p));

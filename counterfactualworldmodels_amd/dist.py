@@ -8,14 +8,17 @@ process per GPU, weights replicated.  Around the path there are exactly two coll
      (1.2 MB + 4 KB + S*Nt bytes).  The masks travel because `RectangularizeMasks` is the only cross-row operation before the
      path: rank 0 applies it once to all S rows -- the same rows, the same torch-RNG draws as the single-process call
      (segmentation.py:342) -- so sharding cannot change which patches are un-masked.
-  2. ONE all-gather of the per-rank prediction blocks straight into the pre-sized result (blocks may differ by a row:
-     grouped per-root broadcasts, no padding copies).
+  2. the all-gather of the per-rank prediction blocks, issued per chunk of 32 rows: ALWAYS the plain equal-block all-gather
+     (`ncclAllGather`, the tuned ring collective) -- in place in the result when every rank has one equal chunk (8 ranks x 32),
+     otherwise through a [world, chunk, ...] staging block per chunk that one strided copy places into the result (2 / 4 ranks:
+     4 / 2 chunks per rank; ragged shards send a padded block).
 
 On GPUs the collectives are RCCL called directly through the C ABI (`cwm_comm_*`, `cwm_broadcast`, `cwm_allgatherv` in
 include/cwm_hip.h; `RcclComm`); the launcher's `torch.distributed` group is used only to hand the 128-byte RCCL id to the
 other ranks.  `TorchComm` runs the same logic on any torch.distributed backend -- it is what the world_size > 1 CPU tests
-use (gloo).  Per-rank fixed cost at 8 ranks: prompt build + one host read-back on rank 0, the broadcast, one
-4-byte header read on the other ranks, the gather; the predictor calls in between queue without host synchronisation.
+use (gloo).  Per-rank fixed cost at 8 ranks: on rank 0 the MASKS of all S prompts (S*Nt bytes; the frames of a
+prompt are built only by the rank that predicts it) + one host read-back for the rectangulariser, the broadcast, one 8-byte
+header read on the other ranks, the gather; the predictor calls in between queue without host synchronisation.
 """
 from __future__ import annotations
 
@@ -64,6 +67,13 @@ class LocalComm:
         """In place: rows [offsets[r], offsets[r] + counts[r]) of `out` are valid on rank r before the call and on every rank
         after it.  The per-chunk form of the gather (`sharded_counterfactual_predictions`) calls this once per chunk."""
         return out
+
+    def all_gather_stage(self, stage: torch.Tensor) -> torch.Tensor:
+        """In place on a contiguous staging block `stage` [world, n, ...]: `stage[rank]` is valid on this rank before the call, all of it on every
+        rank after it.  Equal blocks back to back by construction: the plain all-gather on every backend (`ncclAllGather` on RCCL)."""
+        assert stage.shape[0] == self.world and stage.is_contiguous()
+        n = stage.shape[1]
+        return self.all_gather_rows(stage.view((self.world * n,) + tuple(stage.shape[2:])), [r * n for r in range(self.world)], [n] * self.world)
 
     def all_reduce_sum(self, t: torch.Tensor) -> None:
         pass
@@ -242,7 +252,9 @@ def pack_inputs(x: torch.Tensor, table: torch.Tensor, masks: torch.Tensor, n_mas
     o_x, o_t, o_m, total = _layout(x.shape, table.shape, masks.shape[1])
     buf = torch.zeros(total, dtype=torch.uint8, device=device)
     head = torch.tensor([_MAGIC, *x.shape, *table.shape, masks.shape[1], n_masked] + [0] * (_HEADER_WORDS - 10), dtype=torch.int64)
-    buf[: _HEADER_WORDS * 8] = head.view(torch.uint8).to(device)
+    if torch.device(device).type == "cuda":  # (a pageable host -> device copy synchronises; 128 bytes from pinned memory do not)
+        head = head.pin_memory()
+    buf[: _HEADER_WORDS * 8].copy_(head.view(torch.uint8), non_blocking=True)
     buf[o_x : o_x + 4 * x.numel()] = x.to(device=device, dtype=torch.float32).contiguous().view(-1).view(torch.uint8)
     buf[o_t : o_t + 4 * table.numel()] = table.to(device=device, dtype=torch.int32).contiguous().view(-1).view(torch.uint8)
     buf[o_m : o_m + masks.numel()] = masks.to(device=device).contiguous().view(-1).view(torch.uint8)
@@ -322,7 +334,7 @@ def _side_stream(comm, device):
 def sharded_counterfactual_predictions(
     x: Optional[torch.Tensor],
     prompts: Optional[torch.Tensor],
-    build_fn: Callable[[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],
+    build_fn: Callable[..., Tuple[Optional[torch.Tensor], torch.Tensor]],
     rect_fn: Callable[[torch.Tensor], Tuple[torch.Tensor, int]],
     predict_fn: Callable[[torch.Tensor, torch.Tensor, int, int], torch.Tensor],
     device,
@@ -335,25 +347,36 @@ def sharded_counterfactual_predictions(
     """S prompts over ONE frame pair, sharded over the ranks of `comm`.
 
     x [1,T,C,H,W], prompts [S,K] int32: valid on rank 0 (ignored elsewhere).
-      build_fn(x, prompt_rows) -> (x_rows [n,T,C,H,W], mask_rows [n,Nt])   device-side prompt construction, NOT rectangularised
+      build_fn(x, prompt_rows, frames=True) -> (x_rows [n,T,C,H,W] | None, mask_rows [n,Nt])
+                                                                            device-side prompt construction, NOT rectangularised;
+                                                                            frames=False: masks only (x_rows is None)
       rect_fn(masks [S,Nt])    -> (masks, n_masked)                         rank 0 only, once for all S rows (global RNG order kept)
       predict_fn(x_rows, mask_rows, n_masked, chunk) -> y [n, ...]          the predictor over `chunk` rows per call, no host sync
     shapes = (x.shape, prompts.shape, Nt), if known on every rank, lets the receivers size the packed buffer without a
     metadata collective.  Returns all S predictions in prompt order on every rank (only the local block with gather=False).
 
-    The gather is issued PER CHUNK: as soon as a rank's chunk c is queued, the all-gather of every rank's chunk c is queued on a side
-    stream behind it and runs under chunk c + 1 (2 / 4 ranks: 4 / 2 chunks per rank); with one chunk per rank (8 ranks, 256 prompts)
-    that is a single `ncclAllGather` of equal blocks.  A failure on rank 0 before the broadcast reaches the other ranks as a status
+    With more than one rank, rank 0 builds the MASKS of all S prompts (the rectangulariser is the only cross-row step: S*Nt bytes) and, like every
+    other rank, the frames of its own rows only -- the reference builds every prompt's frames in one place (segmentation.py:324-342) because it
+    predicts them in one place; here 7/8 of that work would sit on every rank's critical path (the peers wait for the broadcast) to be thrown away.
+
+    The gather is issued PER CHUNK: as soon as a rank's chunk c is queued, the all-gather of every rank's chunk c is queued on a side stream behind
+    it and runs under chunk c + 1.  It is always the equal-block all-gather (`all_gather_stage` / `ncclAllGather`): with one equal chunk per rank
+    (8 ranks, 256 prompts) in place in the result; otherwise every rank's chunk c lands in a [world, chunk, ...] staging block that one strided copy
+    (side stream too) moves to rows `lo_r + c*chunk` of the result.  A failure on rank 0 before the broadcast reaches the other ranks as a status
     word in the packed header (they raise `RemoteRankError`)."""
     comm = comm or get_comm(device)
     rank, world = comm.rank, comm.world
     T = times if times is not None else _NoTimes()
     failure = None
+    x_all = None
     if rank == 0:
         try:
             with T.span("build"):
                 xb, table = x.to(device), prompts.to(device)
-                x_all, masks = build_fn(xb, table)
+                if world == 1:
+                    x_all, masks = build_fn(xb, table)
+                else:
+                    _, masks = build_fn(xb, table, frames=False)
                 masks, n_masked = rect_fn(masks)
                 if world > 1:
                     buf = pack_inputs(xb, table, masks, n_masked, device)
@@ -391,7 +414,7 @@ def sharded_counterfactual_predictions(
     lo, hi = bounds[rank]
     if hi > lo:
         with T.span("own_prompts"):
-            x_own = x_all[lo:hi] if rank == 0 else build_fn(xb, table[lo:hi])[0]
+            x_own = x_all[lo:hi] if x_all is not None else build_fn(xb, table[lo:hi])[0]
     if not gather or world == 1:
         if hi > lo:
             with T.span("predict"):
@@ -400,8 +423,10 @@ def sharded_counterfactual_predictions(
         return predict_fn(build_fn(xb, table[:1])[0], masks[:1], n_masked, chunk)[:0]
     # ---- chunk c of every rank is gathered while chunk c + 1 is predicted
     on_gpu = torch.device(device).type == "cuda"
-    n_chunks = max(1, -(-max(h - l for l, h in bounds) // chunk))
-    out = None
+    sizes = [h - l for l, h in bounds]
+    n_chunks = max(1, -(-max(sizes) // chunk))
+    in_place = n_chunks == 1 and min(sizes) == max(sizes)  # one equal block per rank: they already sit back to back in the result
+    out = stage = None
     if on_gpu:
         main, side = torch.cuda.current_stream(device), _side_stream(comm, device)
     for c in range(n_chunks):
@@ -413,20 +438,46 @@ def sharded_counterfactual_predictions(
             y = predict_fn(build_fn(xb, table[:1])[0], masks[:1], n_masked, chunk)[:0]
         if out is None:
             out = torch.empty((S,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
-        if b > a:
-            out[a:b].copy_(y)
+            if not in_place:  # (freed after the final join below: the side stream is done with it by then)
+                stage = torch.empty((n_chunks, world * min(chunk, max(sizes))) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
         offs = [min(l + c * chunk, h) for l, h in bounds]
         cnts = [min(l + (c + 1) * chunk, h) - o for (l, h), o in zip(bounds, offs)]
+        if in_place:
+            out[a:b].copy_(y)
+        else:
+            width = max(cnts)            # ragged shards: every rank sends `width` rows, the surplus rows are never copied out
+            block = stage[c, : world * width].view((world, width) + tuple(y.shape[1:]))  # equal blocks, back to back
+            if b > a:
+                block[rank, : b - a].copy_(y)
         if on_gpu and n_chunks > 1:
             side.wait_stream(main)
-            with torch.cuda.stream(side), T.span("gather", side):
+        with (torch.cuda.stream(side) if on_gpu and n_chunks > 1 else _null()), T.span("gather", side if on_gpu and n_chunks > 1 else None):
+            if in_place:
                 comm.all_gather_rows(out, offs, cnts)
-        else:
-            with T.span("gather"):
-                comm.all_gather_rows(out, offs, cnts)
+            else:
+                comm.all_gather_stage(block)
+                _place(out, block, offs, cnts, sizes, c * chunk)
     if on_gpu and n_chunks > 1:
         main.wait_stream(side)
     return out
+
+
+def _null():
+    import contextlib
+
+    return contextlib.nullcontext()
+
+
+def _place(out: torch.Tensor, block: torch.Tensor, offs: Sequence[int], cnts: Sequence[int], sizes: Sequence[int], start: int) -> None:
+    """Rows [0, cnts[r]) of `block[r]` -> rows [offs[r], offs[r] + cnts[r]) of `out`: ONE strided copy when the shards and this chunk's blocks are
+    equal (the result viewed as [world, rows per rank, ...]), one copy per rank otherwise."""
+    world, n = len(cnts), cnts[0]
+    if n > 0 and all(k == n for k in cnts) and all(k == sizes[0] for k in sizes):
+        out.view((world, sizes[0]) + tuple(out.shape[1:]))[:, start : start + n].copy_(block[:, :n])
+        return
+    for r in range(world):
+        if cnts[r]:
+            out[offs[r] : offs[r] + cnts[r]].copy_(block[r, : cnts[r]])
 
 
 def prompt_hooks(G, frame: Optional[int] = -1):
@@ -434,19 +485,24 @@ def prompt_hooks(G, frame: Optional[int] = -1):
     (active_h, active_w, dy, dx): one active patch of frame 1 moved by (dy, dx) patches, nothing passive (cfg 4)."""
     from .prediction import _RectBatch
 
-    def build(xb, rows):
+    cache = {}
+
+    def build(xb, rows, frames=True):
         n_rows = rows.shape[0]
         T = 2
         xb = xb[:, :1]
         G.inp_shape = (1, T) + tuple(xb.shape[2:])
         _, gh, gw = G.mask_shape
         n = gh * gw
-        frame1 = torch.arange(T * n, device=xb.device) >= n
-        passive = frame1[None].expand(n_rows, -1)
-        cell = n + rows[:, 0].long() * gw + rows[:, 1].long()
-        active = passive.clone()
-        active[torch.arange(n_rows, device=xb.device), cell] = False
-        return G._shift_rows(xb.expand(-1, T, -1, -1, -1), passive, active, rows[:, 2:4], 1, True, samples_per_movie=n_rows)
+        key = (n_rows, n, xb.device)
+        if key not in cache:  # (the passive mask -- frame 0 visible, frame 1 masked -- and the cell weights depend on the grid alone: built once, not per call on
+            cache.clear()     # rank 0's critical path; one entry: the loop alternates between at most "all rows" and "my rows")
+            cache[key] = ((torch.arange(T * n, device=xb.device) >= n)[None].expand(n_rows, -1).contiguous(),
+                          torch.tensor([gw, 1], dtype=torch.int64, device=xb.device))
+        passive, weights = cache[key]
+        cell = (rows[:, :2].long() * weights).sum(1, keepdim=True) + n
+        active = passive.scatter(1, cell, False)
+        return G._shift_rows(xb.expand(-1, T, -1, -1, -1), passive, active, rows[:, 2:4], 1, True, samples_per_movie=n_rows, frames=frames)
 
     def rect(masks):
         masks = G.mask_rectangularizer(masks)

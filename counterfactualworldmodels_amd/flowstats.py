@@ -83,7 +83,9 @@ def transform_features(x: torch.Tensor, do_spearman=False, thresh=None, binarize
         mode, t = (2 if binarize else 1), float(thresh)
     elif range_thresh is not None:
         mode, t = 3, float(range_thresh)
-    work = torch.empty((B, S, 4), device=x.device, dtype=torch.float32) if (mode == 3 or normalize or zscore) else None
+    work = None
+    if mode == 3 or normalize or zscore:  # the column statistics + the partials of the chunked column pass
+        work = torch.empty(int(_lib.get_lib().cwm_flow_transform_work_bytes(B, P, S)), device=x.device, dtype=torch.uint8)
     with torch.cuda.device(x.device):
         _lib.check(_lib.get_lib().cwm_flow_transform(x.data_ptr(), B, P, S, int(bool(do_spearman)), mode, t, int(bool(normalize)), int(bool(zscore)),
                                                     float(eps), _lib.ptr(work), _lib.current_stream_handle(x.device)))

@@ -20,32 +20,86 @@ class RectangularizeMasks:
         assert truncation_mode in ["min", "max", "mean", "full", "none", None], truncation_mode
         self._mode = truncation_mode
         self.last_num_masked = None
-        self.spin_wait = os.environ.get("CWM_SPIN_WAIT", "1") != "0"  # poll for the device -> host copy of the masks instead of blocking on it (see _to_host)
+        self.spin_wait = os.environ.get("CWM_SPIN_WAIT", "1") != "0"  # poll for the device -> host copy of the row counts instead of blocking on it (see _counts_to_host)
         self._event = None
 
     def set_mode(self, mode):
         self._mode = mode
 
-    def _to_host(self, masks):
-        """Device masks -> a persistent pinned staging buffer (one synchronous copy; no allocation, no page faults per call)."""
-        n = masks.numel()
-        if getattr(self, "_stage", None) is None or self._stage.numel() < n:
-            self._stage = torch.empty(max(n, 1 << 16), dtype=torch.bool, pin_memory=True)
-        host = self._stage[:n].view(masks.shape)
+    def _counts_to_host(self, masks: torch.Tensor):
+        """Masked count of every row of the device masks [B, Nt] (library: cwm_mask_row_counts) -> a persistent pinned staging buffer: 4 bytes per row come
+        back instead of the masks themselves."""
+        from . import _lib
+
+        B, Nt = masks.shape
+        dev = masks.device
+        if getattr(self, "_stage", None) is None or self._stage.numel() < B:
+            self._stage = torch.empty(max(B, 1024), dtype=torch.int32, pin_memory=True)
+        if getattr(self, "_counts_dev", None) is None or self._counts_dev.numel() < B or self._counts_dev.device != dev:
+            self._counts_dev = torch.empty(max(B, 1024), dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.get_lib().cwm_mask_row_counts(masks.data_ptr(), B, Nt, self._counts_dev.data_ptr(), stream.cuda_stream))
+        host = self._stage[:B]
         if self.spin_wait:
             # The copy waits for everything queued on the stream (the previous call's forward: milliseconds).  A blocking wait parks the thread,
             # and the host code that follows it -- all of it between this read-back and the call's first kernel launch -- then runs on a core
             # that has just left a sleep state: measured 190 us for what takes 40 us on a busy core (tools/wrap_host_profile.py), an idle GPU
             # for as long.  Polling the event keeps the core awake; `spin_wait = False` restores the blocking copy.
-            host.copy_(masks, non_blocking=True)
+            host.copy_(self._counts_dev[:B], non_blocking=True)
             if self._event is None:
                 self._event = torch.cuda.Event()
-            self._event.record(torch.cuda.current_stream(masks.device))
+            self._event.record(stream)
             while not self._event.query():
                 time.sleep(0)  # (gives the GIL away between two polls -- other Python threads of the process keep running -- without parking the core)
         else:
-            host.copy_(masks)
-        return host
+            host.copy_(self._counts_dev[:B])
+        return host.tolist()
+
+    def _target(self, counts):
+        if self._mode == "min":
+            return min(counts)
+        if self._mode == "max":
+            return max(counts)
+        # "mean": the reference takes torch.mean of the float32 counts and truncates (masking.py:108-111)
+        return int(torch.tensor(counts, dtype=torch.float32).mean().long())
+
+    def _call_device(self, masks: torch.Tensor) -> torch.Tensor:
+        """Device masks [B, Nt] (contiguous, in place).  The reference edits a changed row at `torch.where(row)[0][torch.randperm(n)[:surplus]]`: the draw needs
+        only n = the row's count, so the host reads back the COUNTS (4 B per row, one synchronisation), draws the same `torch.randperm(n)` from the global
+        CPU generator for the same rows in the same order, and sends the picks -- "the k-th masked / visible token of row r" -- to `cwm_mask_flip_picks`, which
+        applies them to the rows on the device.  (Until round 5 the whole mask tensor came to the host and went back: 400 KB each way for 256 prompts.)"""
+        from . import _lib
+
+        B, Nt = masks.shape
+        counts = self._counts_to_host(masks)
+        target = self._target(counts)
+        self.last_num_masked = int(target)
+        rows, offsets, to_value, picks = [], [0], [], []
+        for b, n_b in enumerate(counts):
+            surplus = n_b - target
+            if surplus == 0:
+                continue
+            # one randperm per changed row, in row order: over the masked tokens to un-mask `surplus` of them, or over the visible ones to mask `-surplus`
+            k = torch.randperm(n_b)[:surplus] if surplus > 0 else torch.randperm(Nt - n_b)[:-surplus]
+            rows.append(b)
+            to_value.append(0 if surplus > 0 else 1)
+            picks.append(k)
+            offsets.append(offsets[-1] + k.numel())
+        if rows:
+            table = torch.cat([torch.tensor([len(rows)] + rows + offsets + to_value, dtype=torch.int32)] + [k.to(torch.int32) for k in picks])
+            n = table.numel()
+            if getattr(self, "_table_host", None) is None or self._table_host.numel() < n:
+                self._table_host = torch.empty(max(n, 4096), dtype=torch.int32, pin_memory=True)
+            if getattr(self, "_table_event", None) is not None:
+                self._table_event.synchronize()  # the previous call's copy out of the pinned buffer has run (it may have been queued on another stream)
+            self._table_host[:n].copy_(table)
+            table_dev = self._table_host[:n].to(masks.device, non_blocking=True)
+            self._table_event = torch.cuda.Event()
+            self._table_event.record(torch.cuda.current_stream(masks.device))
+            with torch.cuda.device(masks.device):
+                _lib.check(_lib.get_lib().cwm_mask_flip_picks(masks.data_ptr(), B, Nt, table_dev.data_ptr(), len(rows), _lib.current_stream_handle(masks.device)))
+        return masks
 
     def __call__(self, masks: torch.Tensor) -> torch.Tensor:
         self.last_num_masked = None
@@ -55,19 +109,22 @@ class RectangularizeMasks:
         if self._mode == "full":
             return torch.ones_like(masks)
         shape = masks.shape
+        if masks.is_cuda and masks.dtype == torch.bool and masks.shape[0] > 0 and masks[0].numel() <= 16384:
+            flat = masks.flatten(1)
+            if flat.is_contiguous() and flat.data_ptr() == masks.data_ptr():
+                self._call_device(flat)
+            else:  # a strided view: the kernels work on a packed copy, the result goes back in place like the reference's row assignments
+                work = flat.contiguous()
+                self._call_device(work)
+                masks.copy_(work.view(shape))
+            return masks
         masks = masks.flatten(1)
-        # Device masks: ONE device -> host copy of the whole (tiny: B x Nt bytes) tensor replaces the per-row device round trips of the
-        # reference loop -- the row edits below then run on the host copy and go back in one copy.  The random choices are unchanged:
-        # `torch.randperm(n)` draws from the global CPU generator wherever the mask lives, and `torch.where` lists the same positions.
-        work = self._to_host(masks) if masks.is_cuda else masks
+        work = masks
+        if masks.is_cuda:  # (non-bool or very long rows: through the host)
+            work = masks.cpu()
         rows = work.numpy()  # (shares memory with `work`; the row edits are index arithmetic on <= Nt bytes: numpy, no thread-pool spin-up)
-        counts = rows.view(np.uint8).sum(axis=1, dtype=np.int32).tolist()  # (bool rows as bytes: half the time of count_nonzero(axis=1))
-        if self._mode == "min":
-            target = min(counts)
-        elif self._mode == "max":
-            target = max(counts)
-        else:  # "mean": the reference takes torch.mean of the float32 counts and truncates (masking.py:108-111)
-            target = int(torch.tensor(counts, dtype=torch.float32).mean().long())
+        counts = rows.view(np.uint8).sum(axis=1, dtype=np.int32).tolist() if rows.dtype == np.bool_ else (rows != 0).sum(axis=1).tolist()
+        target = self._target(counts)
         # every row now gets exactly `target` masked tokens: callers that need the count (the predictor's n_vis) read it here
         # instead of paying a second device round trip
         self.last_num_masked = int(target)

@@ -426,11 +426,13 @@ class PredictorBasedGenerator(nn.Module):
             if dy + dx != 0:
                 return (dy, dx)
 
-    def _shift_rows(self, x, passive, active, shifts, frame, fix_passive, samples_per_movie=1):
+    def _shift_rows(self, x, passive, active, shifts, frame, fix_passive, samples_per_movie=1, frames=True, masks=True):
         """Device-side prompt construction for R = B * samples_per_movie rows (library: cwm_shift_prompts; reference:
         PatchPerturbation.forward + ShiftPatchesAndMask.perturb, perturbation.py:99-113, 245-289).  x [B,T,C,H,W]; passive /
         active [R,Nt] bool (0 = patch stays visible / 0 = patch is moved); shifts int32 [R,2] (dy,dx) in patch units.
-        Returns (x_shift [R,T,C,H,W], mask_shift [R,Nt]) before rectangularisation."""
+        Returns (x_shift [R,T,C,H,W], mask_shift [R,Nt]) before rectangularisation; `frames=False` / `masks=False` skips that output (None): the
+        sharded loop needs the masks of all prompts on rank 0 but frames only for the rows a rank predicts (dist.py)."""
+        assert frames or masks
         _lib.require_gpu()
         if not x.is_cuda:
             raise RuntimeError("counterfactual prompts are built on the GPU (no CPU fallback); got a %s tensor" % x.device)
@@ -441,13 +443,13 @@ class PredictorBasedGenerator(nn.Module):
         passive = passive.to(device=dev, dtype=torch.bool).contiguous()
         active = active.to(device=dev, dtype=torch.bool).contiguous()
         shifts = shifts.to(device=dev, dtype=torch.int32).contiguous()
-        x_shift = torch.empty((R, T, Cc, H, W), device=dev, dtype=torch.float32)
-        mask_shift = torch.empty((R, N), device=dev, dtype=torch.bool)
+        x_shift = torch.empty((R, T, Cc, H, W), device=dev, dtype=torch.float32) if frames else None
+        mask_shift = torch.empty((R, N), device=dev, dtype=torch.bool) if masks else None
         with torch.cuda.device(dev):
             _lib.check(_lib.get_lib().cwm_shift_prompts(
                 x.data_ptr(), B, T, Cc, H, W, self.patch_size[-1], frame % T, samples_per_movie,
                 2 if fix_passive == "make_static" else int(bool(fix_passive)),
-                active.data_ptr(), passive.data_ptr(), shifts.data_ptr(), x_shift.data_ptr(), mask_shift.data_ptr(),
+                active.data_ptr(), passive.data_ptr(), shifts.data_ptr(), _lib.ptr(x_shift), _lib.ptr(mask_shift),
                 _lib.current_stream_handle(dev)))
         return x_shift, mask_shift
 

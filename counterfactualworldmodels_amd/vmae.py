@@ -211,11 +211,12 @@ class PretrainVisionTransformer(WeightSync, nn.Module):
 
     def set_option(self, key: str, value: int):
         """One execution option of THIS model (include/cwm_hip.h cwm_model_set_option: "attn_kernel", "gemm_tile", "prune_last_block" ...): per handle, never
-        process-wide.  Options set before the first forward are applied when the handle is created."""
-        opts = self.__dict__.setdefault("_options", {})
-        opts[key] = int(value)
-        if getattr(self, "_handle", None) is not None:
+        process-wide.  Options set before the first forward are applied when the handle is created.  An unknown key / a refused value raises and leaves nothing behind."""
+        if getattr(self, "_handle", None) is not None:  # the library validates; remembered (for a re-created handle) only once it accepted
             self._check(self._library().cwm_model_set_option(self._handle, key.encode(), int(value)))
+        else:
+            _lib.validate_option(key, int(value))
+        self.__dict__.setdefault("_options", {})[key] = int(value)
 
     def _ensure_handle(self, device: torch.device) -> int:
         lib = self._library()

@@ -70,7 +70,8 @@ CWM_API int cwm_model_missing_weights(cwm_model* m, char* buf, int buflen);
 
 typedef struct cwm_forward_args {
     uint32_t struct_size;    /* sizeof(cwm_forward_args) of the header the CALLER was compiled against: fields added at the end by later versions
-                              * are read only when the size covers them; a size below the first version's is CWM_ERR_INVALID */
+                              * are read only when the size covers them; a size below the first version's or above 4096 is CWM_ERR_INVALID (0.6 inserted this
+                              * field FIRST: an ABI break against 0.5, whose callers must be rebuilt -- their x_dev pointer fails the upper bound) */
     /* frames: element (b, c, t, y, x) at x_dev[b*x_stride_b + c*x_stride_c + t*x_stride_t + y*W + x]
      * (so both [B,C,T,H,W] and the wrapper's [B,T,C,H,W] layouts are accepted without a copy) */
     const float* x_dev;
@@ -101,17 +102,17 @@ CWM_API int cwm_forward(cwm_model* m, const cwm_forward_args* args);
  * batch >= 2 whose halves keep >= 3000 encoder rows (ViT-B/8: batch >= 8; ViT-L/4: batch >= 2) runs as two half batches, the first on args->stream and the second on a stream owned by the model, forked and joined
  * with events inside cwm_forward, so the caller sees ordinary stream semantics; results are those of the single-lane call up to the
  * kernel choice per GEMM shape (fp32 re-association, < 1e-5).  lanes = 1: everything on args->stream. */
-CWM_API int cwm_model_set_lanes(cwm_model* m, int lanes); /* 1 .. 4; more than two lanes measured slower on MI355X */
+CWM_API int cwm_model_set_lanes(cwm_model* m, int lanes); /* 1 .. 4 (lane l owns batch rows [ceil(B l / n), ceil(B (l + 1) / n)); fewer lanes are used when a lane would keep < 3000 encoder rows); more than two lanes measured slower on MI355X */
 
 /* Execution options of ONE model handle (no counterpart in the reference).  The defaults are the measured best and what production callers run;
  * the other values exist for same-box A/B measurements and for the bitwise cross-checks of the test suite.  Options are per handle: two models in
  * one process never see each other's settings (until round 4 these were process-wide switches).  Unknown key -> CWM_ERR_INVALID.  Results do not
- * depend on an option beyond fp32 re-association (< 1e-5), except the timing-only ablation bits of "gemm_debug".
+ * depend on an option beyond fp32 re-association (< 1e-5).  (The timing-only ablation bits 1 / 2 / 8 of "gemm_debug" -- skip the epilogue's stores / the
+ * epilogue / every LayerNorm: wrong outputs -- are REFUSED here with CWM_ERR_INVALID; the development library sets them through cwm_debug_set.)
  *   "gemm_tile"    0 automatic per shape, 1: 128x128 tiles, 4: 256x256 8-phase kernel, 6: 8-phase rounds + 128x128 remainder rows
  *   "gemm_direct"  1: bf16-output epilogues store 16 bytes per lane straight from the accumulators; 2: the fp32-output ones too; 0: LDS-staged
  *   "gemm_staged"  0: the per-fragment epilogue of round 1
- *   "gemm_debug"   bit mask: 1 skip the epilogue's global stores (timing only), 2 skip the epilogue (timing only), 4 no 4-stage ring for small launches,
- *                  8 skip every LayerNorm launch (timing only), 32 no split-K, 128 the one-lane tile choice also inside a two-lane call, 256 small launches
+ *   "gemm_debug"   bit mask of result-preserving A/B switches: 4 no 4-stage ring for small launches, 32 no split-K, 128 the one-lane tile choice also inside a two-lane call, 256 small launches
  *                  keep 128-row tiles, 512 bf16-output GEMMs with K < 512 stay on 128x128 tiles, 1024 no half-width column tiles in the 8-phase kernel
  *   "attn_kernel"  0 automatic, 1: 4-wave kernel, 3: software-pipelined kernel
  *   "attn_remap"   0: plain workgroup order instead of one XCD per (batch, head) with the ragged query tiles last
@@ -170,7 +171,7 @@ typedef struct cwm_conj_forward_args {
 
 /* replaces: `self.predictor(self._preprocess(x), mask, x_context=..., mask_context=...)` (prediction.py:419-422) */
 CWM_API int cwm_conj_forward(cwm_conj_model* m, const cwm_conj_forward_args* args);
-CWM_API int cwm_conj_set_lanes(cwm_conj_model* m, int lanes); /* as cwm_model_set_lanes (here the halves must keep >= 12000 encoder rows: batch >= 8); the halves keep the call's n_vis_max / n_vis_ctx_max */
+CWM_API int cwm_conj_set_lanes(cwm_conj_model* m, int lanes); /* 1 or 2 (anything else: CWM_ERR_INVALID) -- as cwm_model_set_lanes (here the halves must keep >= 12000 encoder rows: batch >= 8); the halves keep the call's n_vis_max / n_vis_ctx_max */
 CWM_API int cwm_conj_set_option(cwm_conj_model* m, const char* key, int value); /* as cwm_model_set_option */
 CWM_API int cwm_conj_timing_enable(cwm_conj_model* m, int kclass, int enable);
 CWM_API int cwm_conj_timing_collect(cwm_conj_model* m, int kclass, struct cwm_kernel_stats* out);
@@ -219,6 +220,17 @@ CWM_API int cwm_mask_to_perm(const uint8_t* mask_dev, int B, int Nt, int n_vis, 
 CWM_API int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const uint8_t* mask_dev, int B, int T, int C, int H, int W,
                 int P, int n_vis, float* out_dev, void* stream);
 
+/* `RectangularizeMasks` (masking.py:90-132) on device masks without reading them back.  The reference equalises the masked count of
+ * the rows of a batch by un-masking / masking `torch.randperm(#candidates)[:surplus]` of a row's masked / visible tokens (one draw of the global CPU
+ * generator per changed row, in row order).  The draws depend on the per-row COUNTS alone, so:
+ *   cwm_mask_row_counts  counts_dev[b] = number of masked (non-zero) tokens of row b                       (the host reads back 4 B per row)
+ *   cwm_mask_flip_picks  applies the host's picks in place.  table_dev (int32): [R | rows[R] | offsets[R+1] | to_value[R] | picks[offsets[R]]] --
+ *                        for changed row rows[i], every pick k in picks[offsets[i] .. offsets[i+1]) sets the k-th token (ascending position, 0-based,
+ *                        counted on the row as it was BEFORE the call) whose state is not to_value[i] (0 = un-mask a masked token, 1 = mask a
+ *                        visible one) to to_value[i].  n_rows = R.  Rows of at most 16384 tokens.  Both asynchronous on `stream`. */
+CWM_API int cwm_mask_row_counts(const uint8_t* mask_dev, int B, int Nt, int32_t* counts_dev, void* stream);
+CWM_API int cwm_mask_flip_picks(uint8_t* mask_dev, int B, int Nt, const int32_t* table_dev, int n_rows, void* stream);
+
 /* Motion-counterfactual prompt construction for B*S prompts at once.
  * replaces: the per-sample loop of FlowGenerator.create_motion_counterfactuals (segmentation.py:324-338)
  *           = PatchPerturbation.forward + ShiftPatchesAndMask.perturb (perturbation.py:99-113, 245-289)
@@ -226,7 +238,9 @@ CWM_API int cwm_unembed(const float* y_tokens_dev, const float* x_dev, const uin
  *           when fix_passive=2 (perturbation.py:120-145 as called at prediction.py:802-803: the patches `masks`
  *           leaves visible take their frame-0 pixels), BEFORE the final mask_rectangularizer call (host).  x [B,T,C,H,W]; active/masks [B*S,Nt] bool ('(b s)' order,
  *           0 = active patch / 0 = passive visible patch); shifts [B*S,2] (dy,dx) in patch units;
- *           outputs x_out [B*S,T,C,H,W], mask_out [B*S,Nt].  Asynchronous on `stream`. */
+ *           outputs x_out [B*S,T,C,H,W], mask_out [B*S,Nt]; either one may be NULL (masks only: what rank 0 of the sharded loop needs
+ *           for all prompts before the rectangulariser; frames only: the rows a rank predicts -- x_dev may be NULL with x_out_dev).
+ *           Asynchronous on `stream`. */
 CWM_API int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int P, int frame, int S, int fix_passive,
                       const uint8_t* active_dev, const uint8_t* masks_dev, const int32_t* shifts_dev, float* x_out_dev,
                       uint8_t* mask_out_dev, void* stream);
@@ -253,7 +267,9 @@ CWM_API int cwm_flow_features(const float* flows_dev, const int64_t* strides, in
  *                     (segmentation.py:519-538; x[b] is its [P, S] matrix): spearman: every row -> argsort over its samples (as floats);
  *                     thresh_mode 1: x * (x > thresh), 2: (x > thresh), 3: ((x - min_P) > thresh * (max_P - min_P)) ("range_thresh");
  *                     normalize: x / max(max_P, eps); zscore: (x - mean_P) / max(std_P, eps), statistics over the P positions per sample.
- *                     stats_work_dev: [B][S][4] floats (needed by mode 3, normalize, zscore) */
+ *                     stats_work_dev: cwm_flow_transform_work_bytes(B, P, S) bytes, 16-byte aligned (needed by mode 3, normalize, zscore): the [B][S] column
+ *                     statistics and the per-chunk partials of the one-pass column reduction */
+CWM_API size_t cwm_flow_transform_work_bytes(int B, int P, int S);
 CWM_API int cwm_flow_transform(float* x_dev, int B, int P, int S, int spearman, int thresh_mode, float thresh, int normalize, int zscore, float eps,
                        float* stats_work_dev, void* stream);
 CWM_API int cwm_flow_cov(const float* x_dev, int B, int P, int S, int row0, int nrows, int use_covariance, float* xc_work_dev,

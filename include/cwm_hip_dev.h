@@ -24,13 +24,12 @@ CWM_API int cwm_gemm_tile_override(int M, int N, int K, int epi, int overlapped,
  * Runs `iters` back-to-back launches after 3 warm-up launches and returns the mean launch time. */
 CWM_API int cwm_bench_gemm(int M, int N, int K, int mode, int epi, int iters, double* avg_us);
 CWM_API int cwm_bench_attention(int B, int H, int N, int mode, int iters, double* avg_us);
-/* duty-cycle probe: the same GEMM with an idle gap of gap_us after every launch; mean duration of the GEMM launches alone
- * (is the chip's clock under MFMA load set by the instantaneous or by the time-averaged power?  tools/power_probe.py) */
-CWM_API int cwm_bench_gemm_gapped(int M, int N, int K, int mode, int epi, int iters, int gap_us, double* avg_us);
 /* Sets one execution option (the keys of cwm_model_set_option, cwm_hip.h) in THIS THREAD's copy of the options: the stand-alone entry points
  * (cwm_linear, cwm_attention, cwm_bench_* ...) called on the thread afterwards use it, and model handles created on the thread afterwards start from it.
  * A model that already exists is changed with cwm_model_set_option / cwm_conj_set_option.  Also the profiling queries "attn_prof" / "gemm_prof"
- * (per-workgroup timers of builds with -DCWM_ATTN_PROF / -DCWM_GEMM_PROF). */
+ * (per-workgroup timers of builds with -DCWM_ATTN_PROF / -DCWM_GEMM_PROF), and
+ * "pretend_device" = d: this thread's wrong-device checks (cwm_forward, cwm_conj_forward, cwm_*_load_weight, the collectives) see device d as current instead of
+ * hipGetDevice's answer (-1: off) -- how the refusal is tested on a one-GPU box. */
 CWM_API int cwm_debug_set(const char* key, int value);
 /* The value of an option in this thread's copy (what a handle created on this thread now would start from). */
 CWM_API int cwm_debug_get(const char* key, int* value);

@@ -225,6 +225,9 @@ def test_context_side_stream_is_bitwise_neutral():
         m.set_option("conj_ctx_stream", 1)
         for rep in range(4):
             assert torch.equal(m(x, mask, x_context=imu, mask_context=mc), ref), (lanes, rep)
+    for lanes in (0, 3, 4):   # the conjoined model runs one or two lanes (each lane carries a context stream: four queues); the setter accepts nothing else
+        with pytest.raises(RuntimeError, match="lanes must be 1 or 2"):
+            m.set_lanes(lanes)
 
 
 def test_forward_args_struct_size_versions():

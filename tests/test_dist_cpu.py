@@ -19,10 +19,16 @@ from counterfactualworldmodels_amd.masking import RectangularizeMasks  # noqa: E
 NT = 8
 
 
-def _build(x, prompts):
+FRAME_ROWS = []  # rows whose frames each build call produced (this process): rank 0 must not build the frames of rows it does not predict
+
+
+def _build(x, prompts, frames=True):
     # toy prompt construction: per-prompt input = frame pair + prompt-dependent offset; masks with DIFFERENT masked counts per row
     b = prompts.shape[0]
-    xs = x.expand(b, -1, -1, -1, -1) + prompts[:, 0].float().view(b, 1, 1, 1, 1)
+    xs = None
+    if frames:
+        FRAME_ROWS.append(b)
+        xs = x.expand(b, -1, -1, -1, -1) + prompts[:, 0].float().view(b, 1, 1, 1, 1)
     ms = torch.arange(NT).view(1, NT) <= (prompts[:, 1].view(b, 1) % 5 + 2)
     return xs, ms
 
@@ -67,9 +73,13 @@ def _worker(rank, world, port, S, chunk, hint, out_dir):
     x, prompts = _inputs(S) if rank == 0 else (None, None)
     torch.manual_seed(123 if rank == 0 else 999 + rank)   # only rank 0's RNG may matter
     shapes = ((1, 2, 3, 8, 8), (S, 2), NT) if hint else None
+    FRAME_ROWS.clear()
     y = cdist.sharded_counterfactual_predictions(x, prompts, _build, _rect, _predict, "cpu", chunk=chunk, shapes=shapes)
     assert isinstance(cdist.get_comm("cpu"), cdist.TorchComm)
     used = cdist.get_comm("cpu").last_collective
+    lo, hi = cdist.shard_range(S, rank, world)
+    # every rank -- rank 0 too -- builds frames for the rows it predicts and nothing else (an empty shard: one row for the trailing shape)
+    assert FRAME_ROWS == ([hi - lo] if hi > lo else [1]), (rank, FRAME_ROWS)
     y_loc = cdist.sharded_counterfactual_predictions(x, prompts, _build, _rect, _predict, "cpu", chunk=chunk, gather=False, shapes=shapes)
     torch.save((y, y_loc, used), os.path.join(out_dir, "y%d.pt" % rank))
     dist.barrier()
@@ -95,9 +105,8 @@ def test_sharded_prompts_match_single_process(tmp_path, world, S, chunk, hint):
         assert torch.equal(y, ref), (r, S, chunk)              # all S rows, prompt order, on every rank
         lo, hi = cdist.shard_range(S, r, world)
         assert y_loc.shape == (hi - lo, 1)                      # gather=False keeps the local block (possibly empty)
-        # equal blocks, one chunk per rank (the 8-rank / 256-prompt shape) take the plain all-gather; per-chunk and ragged gathers the general form
-        equal_one_chunk = S % world == 0 and S // world <= chunk
-        assert used == ("all_gather_into_tensor" if equal_one_chunk else "all_gather(padded)"), (used, world, S, chunk)
+        # every layout -- one chunk or several, equal or ragged shards -- goes through the plain equal-block all-gather
+        assert used == "all_gather_into_tensor", (used, world, S, chunk)
 
 
 def _failing_worker(rank, world, port, hint, out_dir):
@@ -156,8 +165,10 @@ def test_chunks_are_row_ranges_of_the_local_block():
 
 def test_gather_pointer_arithmetic_for_every_rank_of_the_8_gpu_layout():
     """`RcclComm.gather_args` (the pointer arithmetic behind cwm_allgather / cwm_allgatherv) for every rank of the layouts the multi-GPU node will
-    see first: 256 prompts on 2 / 4 / 8 ranks in chunks of 32 (equal blocks back to back -> ncclAllGather in place: send == recv + rank * bytes,
-    everything inside the result), and ragged layouts (250 prompts, empty shards) -> per-rank byte offsets that never overlap."""
+    see first: 256 prompts in chunks of 32 on 8 ranks (one equal block per rank, back to back in the result -> ncclAllGather in place: send ==
+    recv + rank * bytes, everything inside the result) and on 2 / 4 ranks (chunk c of every rank -> a [world, 32] staging block, the same in-place
+    ncclAllGather, then `_place` moves block r to rows r * 256 / world + 32 c); ragged layouts keep the per-rank byte offsets of cwm_allgatherv
+    (the flow-statistics gathers)."""
     row, base = 3 * 224 * 224 * 4, 0x7F0000000000
     for world in (2, 4, 8):
         bounds = [cdist.shard_range(256, r, world) for r in range(world)]
@@ -168,16 +179,14 @@ def test_gather_pointer_arithmetic_for_every_rank_of_the_8_gpu_layout():
             cnts = [min(l + (c + 1) * 32, h) - o for (l, h), o in zip(bounds, offs)]
             assert cnts == [32] * world
             for r in range(world):
-                args = cdist.RcclComm.gather_args(base, row, offs, cnts, r)
-                if world == 8:  # one chunk per rank: the blocks are back to back -> the ring collective, in place
-                    kind, send, recv, nbytes = args
-                    assert kind == "allgather" and nbytes == 32 * row
-                    assert send == recv + r * nbytes and recv == base
+                if world == 8:  # one chunk per rank: the blocks are back to back in the RESULT -> the ring collective, in place
+                    kind, send, recv, nbytes = cdist.RcclComm.gather_args(base, row, offs, cnts, r)
                     assert recv + world * nbytes == base + 256 * row
-                else:           # chunk c of every rank: equal blocks 256 / world rows apart -> per-root broadcasts at byte offsets
-                    kind, send, recv, o, n = args
-                    assert kind == "allgatherv" and recv == base and n == [32 * row] * world
-                    assert o == [(q * (256 // world) + 32 * c) * row for q in range(world)] and send == base + o[r]
+                else:           # chunk c of every rank: the staging block [world, 32] (what `all_gather_stage` passes on)
+                    kind, send, recv, nbytes = cdist.RcclComm.gather_args(base, row, [32 * q for q in range(world)], [32] * world, r)
+                    assert recv + world * nbytes == base + world * 32 * row
+                assert kind == "allgather" and nbytes == 32 * row
+                assert send == recv + r * nbytes and recv == base
     for total, world in ((250, 8), (3, 8), (33, 4)):
         bounds = [cdist.shard_range(total, r, world) for r in range(world)]
         offs, cnts = [l for l, _ in bounds], [h - l for l, h in bounds]
@@ -186,6 +195,26 @@ def test_gather_pointer_arithmetic_for_every_rank_of_the_8_gpu_layout():
             assert kind == "allgatherv" and recv == base and n == [k * row for k in cnts] and o == [k * row for k in offs]
             assert (send is None) == (cnts[r] == 0) and (send is None or send == base + offs[r] * row)
             assert sum(n) == total * row and max(a + b for a, b in zip(o, n)) == total * row
+
+
+@pytest.mark.parametrize("total,world,chunk", [(256, 2, 32), (256, 4, 32), (256, 8, 32), (250, 8, 32), (13, 2, 4), (3, 4, 1), (33, 4, 32), (16, 4, 3)])
+def test_staged_gather_places_every_row(total, world, chunk):
+    """The staging layout of the per-chunk gather without any process group: what every rank writes into its slot of chunk c's [world, width] block,
+    followed by `_place`, must put prompt i's row at row i of the result -- for equal shards (one strided copy) and ragged ones (a copy per rank)."""
+    bounds = [cdist.shard_range(total, r, world) for r in range(world)]
+    sizes = [h - l for l, h in bounds]
+    n_chunks = max(1, -(-max(sizes) // chunk))
+    out = torch.full((total, 2), -1.0)
+    for c in range(n_chunks):
+        offs = [min(l + c * chunk, h) for l, h in bounds]
+        cnts = [min(l + (c + 1) * chunk, h) - o for (l, h), o in zip(bounds, offs)]
+        width = max(cnts)
+        assert 0 < width <= min(chunk, max(sizes))
+        block = torch.full((world, width, 2), float("nan"))          # the surplus rows of a ragged block hold garbage: never copied out
+        for r in range(world):                                        # (what the all-gather leaves on every rank)
+            block[r, : cnts[r]] = torch.arange(offs[r], offs[r] + cnts[r], dtype=torch.float32).view(-1, 1).expand(-1, 2)
+        cdist._place(out, block, offs, cnts, sizes, c * chunk)
+    assert torch.equal(out, torch.arange(total, dtype=torch.float32).view(-1, 1).expand(-1, 2))
 
 
 def test_shard_range_partitions():

@@ -146,6 +146,16 @@ def test_user_distance_func_and_nan_columns():
     xz = FS.transform_features(x.cuda().clone(), zscore=True).cpu()
     ref = (x[0] - x[0].mean(0)[None]) / x[0].std(0).clamp(min=1e-12)[None]
     assert torch.equal(torch.isnan(xz[0]), torch.isnan(ref)) and (torch.nan_to_num(xz[0]) - torch.nan_to_num(ref)).abs().max().item() <= 1e-5
+    # a NaN-free column holding +inf AND -inf: its mean is NaN, but amax is +inf (x / inf = 0, inf / inf = NaN) -- the NaN is tracked, not read off the mean
+    xi = torch.randn(1, 6, 9, generator=g)
+    xi[0, 1, 3], xi[0, 4, 3] = float("inf"), float("-inf")
+    xin = FS.transform_features(xi.cuda().clone(), normalize=True).cpu()
+    ref = xi[0] / xi[0].amax(0, True).clamp(min=1e-12)
+    assert torch.equal(torch.isnan(xin[0]), torch.isnan(ref)) and torch.equal(torch.nan_to_num(xin[0]), torch.nan_to_num(ref))
+    assert not torch.isnan(xin[0, 0, 3]) and xin[0, 0, 3] == 0 and torch.isnan(xin[0, 1, 3])
+    xir = FS.transform_features(xi.cuda().clone(), range_thresh=0.5).cpu()   # segmentation.py:529-532 on that column: nothing exceeds an infinite / NaN range
+    sh = xi[0] - xi[0].amin(0, True)
+    assert torch.equal(xir[0], (sh > 0.5 * sh.amax(0, True)).float())
     one = FS.transform_features(torch.randn(1, 1, 5, generator=g).cuda(), zscore=True)                                # P = 1: std = NaN
     assert torch.isnan(one).all()
     c = FS.compute_flow_corrs(torch.randn(1, 2, 1, 1, 5, generator=g).cuda(), zscore=True, use_covariance=True)      # ... and the matrix is 0

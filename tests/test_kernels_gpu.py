@@ -174,6 +174,44 @@ def test_mask_to_perm_bit_exact_and_errors(gu):
     assert e.value.code == _lib.ERR_MASK
 
 
+def test_mask_row_counts_and_flip_picks_bit_exact(gu):
+    """The two entry points behind `RectangularizeMasks` on device masks (cwm_mask_row_counts, cwm_mask_flip_picks) against numpy: counts of ragged rows,
+    and picks applied to the row as it was before the call -- many picks per row, both directions, a row with no pick, row lengths that are not a multiple
+    of the workgroup, the first and the last candidate, rows left untouched."""
+    lib = _lib.get_lib()
+    d = gu.dev()
+    g = torch.Generator().manual_seed(5)
+    for (B, Nt) in [(5, 40), (3, 257), (8, 1568), (4, 6336), (2, 16384)]:
+        mask = torch.rand(B, Nt, generator=g) < 0.6
+        mask[0, :] = True          # a fully masked row
+        md = mask.to(d)
+        counts = torch.empty(B, dtype=torch.int32, device=d)
+        _lib.check(lib.cwm_mask_row_counts(md.data_ptr(), B, Nt, counts.data_ptr(), gu.stream()))
+        assert torch.equal(counts.cpu().long(), mask.sum(1))
+        ref = mask.clone().numpy()
+        rows, offsets, to_value, picks = [], [0], [], []
+        for b in range(B):
+            if b == 1 and B > 2:
+                continue            # untouched row
+            to = b % 2              # even rows: un-mask masked tokens; odd rows: mask visible ones
+            cand = np.flatnonzero(ref[b] != bool(to))
+            if cand.size == 0:
+                continue
+            n_pick = [1, cand.size, min(7, cand.size), cand.size // 2 + 1][b % 4]
+            k = torch.randperm(cand.size, generator=g)[:n_pick]
+            if b % 4 == 2:
+                k[0], k[-1] = 0, cand.size - 1    # the first and the last candidate
+                k = torch.unique(k)
+            ref[b, cand[k.numpy()]] = bool(to)
+            rows.append(b); to_value.append(to); picks.append(k.to(torch.int32)); offsets.append(offsets[-1] + k.numel())
+        table = torch.cat([torch.tensor([len(rows)] + rows + offsets + to_value, dtype=torch.int32)] + picks).to(d)
+        _lib.check(lib.cwm_mask_flip_picks(md.data_ptr(), B, Nt, table.data_ptr(), len(rows), gu.stream()))
+        assert np.array_equal(md.cpu().numpy(), ref), (B, Nt)
+    with pytest.raises(_lib.CwmHipError):
+        big = torch.zeros(1, 16385, dtype=torch.bool, device=d)
+        _lib.check(lib.cwm_mask_flip_picks(big.data_ptr(), 1, 16385, table.data_ptr(), 1, gu.stream()))
+
+
 def test_unembed_bit_exact_golden(gu):
     g = np.load(os.path.join(GOLDEN, "index_ops.npz"))
     lib = _lib.get_lib()
@@ -191,7 +229,7 @@ def test_gemm_tile_configurations_agree(gud, tile):
     """All output-tile configurations of the GEMM (128x128, 256x256 8-phase, 8-phase rounds + 128x128 remainder rows) give the same result."""
     lib = gud.lib
     try:
-        _lib.check(lib.cwm_debug_set(b"gemm_tile", tile))
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", tile), lib)
         for mode in ("parity", "fast"):
             for (M, N, K) in [(300, 768, 192), (1000, 1152, 384), (77, 48, 512), (700, 256, 64), (513, 384, 1536)]:
                 a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
@@ -204,7 +242,7 @@ def test_gemm_tile_configurations_agree(gud, tile):
         assert torch.equal(gud.linear(a, w, None, mode="parity"), a @ w.t())
         assert torch.equal(gud.linear(a, w, None, mode="fast"), a @ w.t())
     finally:
-        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0), lib)
 
 
 def test_gemm_mixed_tiling_is_bitwise_equal_to_simple_kernel(gud):
@@ -215,13 +253,13 @@ def test_gemm_mixed_tiling_is_bitwise_equal_to_simple_kernel(gud):
         for mode in ("parity", "fast"):
             for (M, N, K) in [(25344, 768, 192), (20000, 512, 128)]:
                 a, w, b, r = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5), rnd(N, seed=43), rnd(M, N, seed=44)
-                _lib.check(lib.cwm_debug_set(b"gemm_tile", 1))
+                _lib.check(lib.cwm_debug_set(b"gemm_tile", 1), lib)
                 ref = gud.linear(a, w, b, resid=r, mode=mode)
-                _lib.check(lib.cwm_debug_set(b"gemm_tile", 6))
+                _lib.check(lib.cwm_debug_set(b"gemm_tile", 6), lib)
                 out = gud.linear(a, w, b, resid=r, mode=mode)
                 assert torch.equal(out, ref), (mode, M, N, K, (out - ref).abs().max().item())
     finally:
-        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0), lib)
 
 
 def test_gemm_8phase_is_bitwise_equal_to_simple_kernel_under_repetition(gud):
@@ -232,19 +270,23 @@ def test_gemm_8phase_is_bitwise_equal_to_simple_kernel_under_repetition(gud):
     lib = gud.lib
     shapes = [(256, 256, 64), (300, 272, 128), (1000, 1152, 192), (513, 512, 384), (2049, 768, 768), (4096, 1024, 3072)]
     try:
-        _lib.check(lib.cwm_debug_set(b"gemm_debug", 32))  # (no split-K in the reference kernel: a split re-associates the fp32 sums)
+        _lib.check(lib.cwm_debug_set(b"gemm_debug", 32), lib)  # (no split-K in the reference kernel: a split re-associates the fp32 sums)
         for mode in ("parity", "fast"):
             for (M, N, K) in shapes:
                 a, w, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13)
-                _lib.check(lib.cwm_debug_set(b"gemm_tile", 1))
+                _lib.check(lib.cwm_debug_set(b"gemm_tile", 1), lib)
                 ref = gud.linear(a, w, b, mode=mode)
-                _lib.check(lib.cwm_debug_set(b"gemm_tile", 4))
-                for rep in range(8):
-                    out = gud.linear(a, w, b, mode=mode)
-                    assert torch.equal(out, ref), (mode, M, N, K, rep, (out - ref).abs().max().item())
+                for tile in (4,):   # 256x256 tiles (half-width instance for a last column tile of <= 128 columns)
+                    _lib.check(lib.cwm_debug_set(b"gemm_tile", tile), lib)
+                    for rep in range(8):
+                        out = gud.linear(a, w, b, mode=mode)
+                        assert torch.equal(out, ref), (mode, tile, M, N, K, rep, (out - ref).abs().max().item())
+                    gl = gud.linear(a, w, b, gelu=True, mode=mode)   # (bf16 + GELU epilogue: the direct form with permuted W rows)
+                    _lib.check(lib.cwm_debug_set(b"gemm_tile", 1), lib)
+                    assert torch.equal(gl, gud.linear(a, w, b, gelu=True, mode=mode)), (mode, tile, M, N, K)
     finally:
-        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
-        _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0), lib)
+        _lib.check(lib.cwm_debug_set(b"gemm_debug", 0), lib)
 
 
 def test_gemm_deep_ring_and_split_k_small_launches(gud):
@@ -257,19 +299,19 @@ def test_gemm_deep_ring_and_split_k_small_launches(gud):
         for mode in ("parity", "fast"):
             for (M, N, K) in shapes:
                 a, w, b, r = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5), rnd(N, seed=33), rnd(M, N, seed=34)
-                _lib.check(lib.cwm_debug_set(b"gemm_tile", 1))
-                _lib.check(lib.cwm_debug_set(b"gemm_debug", 4))          # double-buffered kernel, no deep ring, no split
+                _lib.check(lib.cwm_debug_set(b"gemm_tile", 1), lib)
+                _lib.check(lib.cwm_debug_set(b"gemm_debug", 4), lib)          # double-buffered kernel, no deep ring, no split
                 ref = (gud.linear(a, w, b, resid=r, mode=mode), gud.linear(a, w, b, gelu=True, mode=mode))
-                _lib.check(lib.cwm_debug_set(b"gemm_debug", 32))         # deep ring (8 waves), no split: same product sequence
+                _lib.check(lib.cwm_debug_set(b"gemm_debug", 32), lib)         # deep ring (8 waves), no split: same product sequence
                 for rep in range(3):
                     out = (gud.linear(a, w, b, resid=r, mode=mode), gud.linear(a, w, b, gelu=True, mode=mode))
                     assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), (mode, M, N, K, rep)
                 # (these shapes leave half of the CUs without a 128x128 tile, so the deep ring above ran its 64x128 tile; bit 8 keeps 128 rows)
                 for bits, what in ((32 + 256, "128-row tiles, 8 waves"),):
-                    _lib.check(lib.cwm_debug_set(b"gemm_debug", bits))
+                    _lib.check(lib.cwm_debug_set(b"gemm_debug", bits), lib)
                     out = (gud.linear(a, w, b, resid=r, mode=mode), gud.linear(a, w, b, gelu=True, mode=mode))
                     assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), (mode, M, N, K, what)
-                _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))          # default: + split-K where the heuristic takes it
+                _lib.check(lib.cwm_debug_set(b"gemm_debug", 0), lib)          # default: + split-K where the heuristic takes it
                 first = (gud.linear(a, w, b, resid=r, mode=mode), gud.linear(a, w, b, gelu=True, mode=mode))
                 for rep in range(6):
                     out = (gud.linear(a, w, b, resid=r, mode=mode), gud.linear(a, w, b, gelu=True, mode=mode))
@@ -277,8 +319,8 @@ def test_gemm_deep_ring_and_split_k_small_launches(gud):
                 assert (first[0] - ref[0]).abs().max().item() <= (2e-5 if mode == "parity" else 2e-3), (mode, M, N, K)
                 assert (first[0] - (F.linear(a, w, b) + r)).abs().max().item() <= TOL[mode]
     finally:
-        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
-        _lib.check(lib.cwm_debug_set(b"gemm_debug", 0))
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0), lib)
+        _lib.check(lib.cwm_debug_set(b"gemm_debug", 0), lib)
 
 
 @pytest.mark.parametrize("tile", [1, 4])
@@ -290,14 +332,14 @@ def test_gemm_epilogue_forms_are_bitwise_equal(gud, tile):
     lib = gud.lib
     cases = [(300, 272, 128), (1000, 1152, 192), (77, 48, 512), (513, 400, 384), (2049, 768, 768)]
     try:
-        _lib.check(lib.cwm_debug_set(b"gemm_tile", tile))
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", tile), lib)
         for mode in ("parity", "fast"):
             for (M, N, K) in cases:
                 a, w, b, r = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23), rnd(M, N, seed=24)
                 outs = []
                 for staged, direct in ((0, 0), (1, 0), (1, 1), (1, 2)):
-                    _lib.check(lib.cwm_debug_set(b"gemm_staged", staged))
-                    _lib.check(lib.cwm_debug_set(b"gemm_direct", direct))
+                    _lib.check(lib.cwm_debug_set(b"gemm_staged", staged), lib)
+                    _lib.check(lib.cwm_debug_set(b"gemm_direct", direct), lib)
                     outs.append((gud.linear(a, w, b, mode=mode), gud.linear(a, w, b, resid=r, mode=mode), gud.linear(a, w, b, gelu=True, mode=mode),
                                  gud.linear(a, w, None, mode=mode)))
                 for other in outs[1:]:
@@ -305,9 +347,9 @@ def test_gemm_epilogue_forms_are_bitwise_equal(gud, tile):
                         assert torch.equal(o0, o1), (tile, mode, M, N, K)
                 assert (outs[1][1] - (F.linear(a, w, b) + r)).abs().max().item() <= TOL[mode]
     finally:
-        _lib.check(lib.cwm_debug_set(b"gemm_staged", 1))
-        _lib.check(lib.cwm_debug_set(b"gemm_direct", 1))
-        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0))
+        _lib.check(lib.cwm_debug_set(b"gemm_staged", 1), lib)
+        _lib.check(lib.cwm_debug_set(b"gemm_direct", 1), lib)
+        _lib.check(lib.cwm_debug_set(b"gemm_tile", 0), lib)
 
 
 @pytest.mark.parametrize("kern", [3])
@@ -323,23 +365,23 @@ def test_attention_variants_are_bitwise_equal_to_4wave_kernel(gud, kern):
         # (the key-split schedule of a ragged last query tile, attention_tail.h, re-associates the key sum and exists in the 4-wave
         # workgroups only: this cross-check runs every tile on the regular schedule; the split has its own test below.  Likewise the key-split
         # tail round of the pipelined kernel, "attn_ksplit")
-        _lib.check(lib.cwm_debug_set(b"attn_tail", 0))
-        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 0))
+        _lib.check(lib.cwm_debug_set(b"attn_tail", 0), lib)
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 0), lib)
         for mode in ("parity", "fast"):
             for (B, N, H) in cases:
                 qkv = rnd(B, N, 3 * H * 64, seed=N + 1)
                 if N >= 300:
                     qkv[0, N - 5, H * 64:H * 64 + 64] = qkv[0, 7, :64] * 6.0  # late spike: the running max jumps in the last tile
-                _lib.check(lib.cwm_debug_set(b"attn_kernel", 1))
+                _lib.check(lib.cwm_debug_set(b"attn_kernel", 1), lib)
                 ref = gud.attention(qkv, H, mode=mode)
-                _lib.check(lib.cwm_debug_set(b"attn_kernel", kern))
+                _lib.check(lib.cwm_debug_set(b"attn_kernel", kern), lib)
                 for rep in range(4):
                     out = gud.attention(qkv, H, mode=mode)
                     assert torch.equal(out, ref), (mode, B, N, H, rep, (out - ref).abs().max().item())
     finally:
-        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))
-        _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
-        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1))
+        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0), lib)
+        _lib.check(lib.cwm_debug_set(b"attn_tail", 1), lib)
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1), lib)
 
 
 def test_attention_key_split_of_the_ragged_last_tile(gud):
@@ -351,7 +393,7 @@ def test_attention_key_split_of_the_ragged_last_tile(gud):
     lib = gud.lib
     cases = [(2, 129, 1), (1, 160, 2), (2, 785, 1), (2, 792, 12), (1, 1568, 6), (8, 792, 12), (1, 897, 2), (1, 3104, 1)]
     try:
-        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 0))   # (the other key split, of a whole tail ROUND, would take over where this one is switched off)
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 0), lib)   # (the other key split, of a whole tail ROUND, would take over where this one is switched off)
         for mode in ("parity", "fast"):
             for (B, N, H) in cases:
                 qkv = rnd(B, N, 3 * H * 64, seed=N + 3)
@@ -360,9 +402,9 @@ def test_attention_key_split_of_the_ragged_last_tile(gud):
                 tail0 = (N // 128) * 128 if N % 128 else N
                 outs = {}
                 for kern in (1, 3):
-                    _lib.check(lib.cwm_debug_set(b"attn_kernel", kern))
+                    _lib.check(lib.cwm_debug_set(b"attn_kernel", kern), lib)
                     for tail in (0, 1):
-                        _lib.check(lib.cwm_debug_set(b"attn_tail", tail))
+                        _lib.check(lib.cwm_debug_set(b"attn_tail", tail), lib)
                         outs[kern, tail] = gud.attention(qkv, H, mode=mode)
                 assert torch.equal(outs[1, 1], outs[3, 1]), (mode, B, N, H)
                 assert torch.equal(gud.attention(qkv, H, mode=mode), outs[3, 1])           # deterministic
@@ -376,9 +418,9 @@ def test_attention_key_split_of_the_ragged_last_tile(gud):
                 err = (outs[3, 1] - ref_attention(qkv, H)).abs().max().item()
                 assert err <= (5e-4 if mode == "parity" else 5e-2), (mode, B, N, H, err)
     finally:
-        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))
-        _lib.check(lib.cwm_debug_set(b"attn_tail", 1))
-        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1))
+        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0), lib)
+        _lib.check(lib.cwm_debug_set(b"attn_tail", 1), lib)
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1), lib)
 
 
 def test_attention_key_split_tail_round(gud):
@@ -395,10 +437,10 @@ def test_attention_key_split_tail_round(gud):
                 qkv = rnd(B, N, 3 * H * 64, seed=N + 5)
                 qkv[0, N - 5, H * 64:H * 64 + 64] = qkv[0, 7, :64] * 6.0  # late spike: the last key range holds the maximum of query 7
                 if mode == "fast":
-                    _lib.check(lib.cwm_debug_set(b"attn_kernel", 3))       # (fast mode takes the pipelined kernel from 2048 tokens on)
+                    _lib.check(lib.cwm_debug_set(b"attn_kernel", 3), lib)       # (fast mode takes the pipelined kernel from 2048 tokens on)
                 outs = []
                 for ks in (0, 1):
-                    _lib.check(lib.cwm_debug_set(b"attn_ksplit", ks))
+                    _lib.check(lib.cwm_debug_set(b"attn_ksplit", ks), lib)
                     outs.append(gud.attention(qkv, H, mode=mode))
                 assert torch.equal(gud.attention(qkv, H, mode=mode), outs[1])            # deterministic
                 d = (outs[0] - outs[1]).abs()
@@ -408,13 +450,13 @@ def test_attention_key_split_tail_round(gud):
                 assert 0 < changed <= rem * 128, (mode, B, N, H, changed)
                 err = (outs[1] - ref_attention(qkv, H)).abs().max().item()
                 assert err <= (5e-4 if mode == "parity" else 5e-2), (mode, B, N, H, err)
-        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))
+        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0), lib)
         B, N, H = 8, 6272, 8
         qkv = rnd(B, N, 3 * H * 64, seed=77)
         for mode in ("parity", "fast"):
             outs = []
             for ks in (0, 1):
-                _lib.check(lib.cwm_debug_set(b"attn_ksplit", ks))
+                _lib.check(lib.cwm_debug_set(b"attn_ksplit", ks), lib)
                 outs.append(gud.attention(qkv, H, mode=mode))
             d = (outs[0] - outs[1]).abs()
             assert d.max().item() <= (1e-4 if mode == "parity" else 1e-2), (mode, d.max().item())
@@ -424,5 +466,5 @@ def test_attention_key_split_tail_round(gud):
             err = (outs[1][3:4, :, 5 * 64:6 * 64] - ref).abs().max().item()
             assert err <= (5e-4 if mode == "parity" else 5e-2), (mode, err)
     finally:
-        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1))
-        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))
+        _lib.check(lib.cwm_debug_set(b"attn_ksplit", 1), lib)
+        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0), lib)

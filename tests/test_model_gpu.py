@@ -357,7 +357,47 @@ def test_options_are_per_model_handle():
     assert (ya - yb).abs().max().item() <= 5e-5
     with pytest.raises(RuntimeError):
         b.set_option("no_such_option", 1)
+    assert "no_such_option" not in b.__dict__.get("_options", {}) and torch.equal(b(xp, mk), yb)
+    # a refused option leaves nothing behind: the handle can be re-created (device move / use_library replay the stored options)
+    b._release()
     assert torch.equal(b(xp, mk), yb)
+    # ... also when there is no handle yet (the key list is checked on the host)
+    c = build(TINY, seed)
+    c._release()
+    with pytest.raises(RuntimeError):
+        c.set_option("no_such_option", 1)
+    with pytest.raises(RuntimeError, match="timing-only"):
+        c.set_option("gemm_debug", 8)
+    assert not c.__dict__.get("_options") and torch.equal(c(xp, mk), yb)
+    # the production setters refuse the timing-only ablation bits (they would return wrong outputs with CWM_OK); the result-preserving bits pass
+    with pytest.raises(RuntimeError, match="timing-only"):
+        c.set_option("gemm_debug", 2)
+    c.set_option("gemm_debug", 32)
+    assert (c(xp, mk) - yb).abs().max().item() <= 5e-5
+
+
+def test_forward_from_another_current_device_is_refused():
+    """A handle belongs to the device it was created on (weights, workspace, lane streams).  `cwm_forward` / `cwm_*_load_weight` called while another
+    device is current return CWM_ERR_INVALID instead of launching on the wrong GPU.  One GPU here: the development library's "pretend_device" makes this
+    thread's checks see device 1 as current (the handle lives on device 0)."""
+    g = np.load(os.path.join(GOLDEN, "tiny_8x8_k4.npz"))
+    seed, x, mask = case_inputs(g, TINY)
+    dlib = _lib.get_dev_lib()
+    m = build(TINY, seed)
+    m.use_library(dlib)
+    G = prediction.PredictorBasedGenerator(predictor=m, imagenet_normalize_inputs=True, temporal_dim=2)
+    xp, mk = G._preprocess(x.cuda()), mask.cuda()
+    y = m(xp, mk)
+    _lib.check(dlib.cwm_debug_set(b"pretend_device", 1), dlib)
+    try:
+        with pytest.raises(RuntimeError, match="created on HIP device 0 but the calling thread's current device is 1"):
+            m(xp, mk)
+        with pytest.raises(RuntimeError, match="current device is 1"):
+            m.sync_weights(torch.device("cuda:0"), force=True)
+    finally:
+        _lib.check(dlib.cwm_debug_set(b"pretend_device", -1), dlib)
+    m.sync_weights(torch.device("cuda:0"), force=True)
+    assert torch.equal(m(xp, mk), y)
 
 
 def test_nothing_masked_returns_all_tokens():
@@ -448,6 +488,51 @@ def test_two_lanes_match_one_lane_and_report_mask_errors_of_both():
         tail = ys[B - 1].clone()                               # last row = end of the second lane
     s.synchronize()
     assert torch.equal(tail, y2[B - 1])
+
+
+@pytest.mark.parametrize("lanes", [3, 4])
+def test_three_and_four_lanes_batch32(lanes):
+    """cwm_model_set_lanes accepts 1 .. 4 (include/cwm_hip.h): every accepted value runs.  The bench batch (ViT-B/8, 32 frame pairs) on 3 lanes (11 + 11 + 10
+    rows) and 4 lanes (8 each): rows 0-1 against the reference's golden pair, bit-stable run to run, <= 5e-5 from the one-lane call (per-shape kernel choice
+    re-associates fp32 sums), the fused video path too, a bad mask row in EVERY lane raises the reference's error, and the handle falls back to fewer
+    lanes by itself when a batch is too small to keep 3000 encoder rows per lane."""
+    g = np.load(os.path.join(GOLDEN, "base8_k8_b2.npz"))
+    cfg = C.CONFIGS["base_8x8patch_2frames_1tube"]
+    m = build(cfg, 0, "parity")
+    B, n_vis = 32, 792
+    xr = torch.from_numpy(S.synthetic_frames(B, cfg, 0)).cuda()
+    x = O.preprocess(xr.cpu()).cuda()
+    mask = torch.from_numpy(S.synthetic_masks(B, cfg, 8, 0)).cuda()
+    m.sync_weights(torch.device("cuda:0"))
+    m.set_lanes(1)
+    y1 = m(x, mask, n_vis=n_vis)
+    m.set_lanes(lanes)
+    yl = m(x, mask, n_vis=n_vis)
+    err = np.abs(yl[:2].cpu().numpy() - g["y_tokens"]).max()
+    e1 = (yl - y1).abs().max().item()
+    print(f"[lanes={lanes}] rows 0-1 vs reference {err:.2e}; vs one lane {e1:.2e}")
+    assert err <= PARITY_TOL and e1 <= 5e-5
+    for rep in range(5):
+        assert torch.equal(m(x, mask, n_vis=n_vis), yl), rep
+    yv, video = m.predict_video(xr, mask, n_vis=n_vis)
+    m.set_lanes(1)
+    yv1, video1 = m.predict_video(xr, mask, n_vis=n_vis)
+    m.set_lanes(lanes)
+    assert (yv - yl).abs().max().item() <= 5e-5 and (video - video1).abs().max().item() <= 5e-5
+    first = [(B * l + lanes - 1) // lanes for l in range(lanes + 1)]       # lane l owns rows [first[l], first[l+1]) (model.hip cwm_forward)
+    for l in range(lanes):
+        bad = mask.clone()
+        row = first[l + 1] - 1
+        bad[row, int(torch.nonzero(~bad[row])[0])] = True                  # one visible token fewer in the last row of lane l
+        with pytest.raises(RuntimeError, match="is invalid for"):
+            m(x, bad, n_vis=n_vis)
+    assert torch.equal(m(x, mask, n_vis=n_vis), yl)                        # usable afterwards
+    ys = m(x[:9], mask[:9], n_vis=n_vis)                                   # 9 rows: two lanes at most (3 x 3 rows would leave 2376 < 3000 encoder rows per lane)
+    assert (ys - yl[:9]).abs().max().item() <= 5e-5
+    with pytest.raises(RuntimeError):
+        m.set_lanes(5)
+    with pytest.raises(RuntimeError):
+        m.set_lanes(0)
 
 
 @pytest.mark.parametrize("B", [8, 9, 13])

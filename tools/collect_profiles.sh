@@ -34,5 +34,16 @@ for mode in fast parity; do
 done
 # batch-1 latency (the small-launch kernels: 4-stage ring, split-K)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b1 -- python3 tools/latency_b1.py 1 > $OUT/stats_b1.log 2>&1
+# the kernels either side of the predictor path: kernel stats + FETCH / WRITE passes of the two edge workloads
+for wl in flowstats prompt_build; do
+  BENCH="python3 bench.py --workload $wl --steps 5 --no-cpu-baseline"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_${wl}_f32 -- $BENCH > $OUT/stats_${wl}_f32.log 2>&1
+  grep '^{"metric"' $OUT/stats_${wl}_f32.log | tail -1 > $OUT/bench_under_rocprof_${wl}_f32.json
+  [ -s $OUT/bench_under_rocprof_${wl}_f32.json ] || { echo "NO BENCH LINE for $wl (see $OUT/stats_${wl}_f32.log)"; fail=1; }
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$wl -- $BENCH > $OUT/pmc_fetch_$wl.log 2>&1 || fail=1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$wl -- $BENCH > $OUT/pmc_write_$wl.log 2>&1 || fail=1
+done
 find $OUT -name "*.csv" | wc -l
+# a Python traceback in any log of the set = the set is not evidence (round 5 committed one as a "per-shape kernel rate" log)
+if grep -l "Traceback (most recent call last)" $OUT/*.log 2>/dev/null; then echo "TRACEBACK in the logs listed above"; fail=1; fi
 exit $fail

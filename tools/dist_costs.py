@@ -17,7 +17,8 @@ def timeit(fn, n=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): out = fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3, out
-t, (xa, ma) = timeit(lambda: build(x0, table)); print("rank 0: build all 256 prompts (frames + masks)      %.3f ms" % t)
+t, (xa, ma) = timeit(lambda: build(x0, table)); print("one rank: build all 256 prompts (frames + masks)    %.3f ms" % t)
+t, _ = timeit(lambda: build(x0, table, frames=False)); print("rank 0: build the MASKS of all 256 prompts (world > 1)   %.3f ms" % t)
 t, (mr, nm) = timeit(lambda: rect(ma.clone())); print("rank 0: rectangularise 256 rows (one host read-back) %.3f ms" % t)
 t, buf = timeit(lambda: cdist.pack_inputs(x0, table, mr, nm, dev)); print("rank 0: pack {header|frame|table|masks} = %d bytes  %.3f ms" % (buf.numel(), t))
 t, _ = timeit(lambda: cdist.unpack_inputs(buf)); print("rank r: unpack (128-byte header read-back)            %.3f ms" % t)

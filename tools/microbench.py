@@ -2,6 +2,7 @@
 
     python tools/microbench.py gemm      # GEMM shapes of the B/8 batch-32 and L/4 batch-8 forward
     python tools/microbench.py attn
+    python tools/microbench.py attn_sweep   # 4-wave vs software-pipelined kernel from 40 to 6336 tokens (the fast-mode selection rule of attention.hip)
 """
 import ctypes as C
 import os
@@ -62,7 +63,7 @@ ATTN_SHAPES = [("b8.enc", 32, 12, 792), ("b8.dec", 32, 6, 1568), ("l4.enc", 8, 1
 
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-    variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,3,4").split(",")]
+    variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,4,6").split(",")]
     torch.cuda.init()
     lib = _lib.get_dev_lib()
     us = C.c_double()
@@ -71,26 +72,30 @@ def main():
             for mode in ("fast", "parity"):
                 row = []
                 for v in variants:
-                    _lib.check(lib.cwm_debug_set(b"gemm_tile", v))
+                    _lib.check(lib.cwm_debug_set(b"gemm_tile", v), lib)
                     best = 1e30
                     for _ in range(3):
-                        _lib.check(lib.cwm_bench_gemm(M, N, K, _lib.mode_id(mode), epi, 20, C.byref(us)))
+                        _lib.check(lib.cwm_bench_gemm(M, N, K, _lib.mode_id(mode), epi, 20, C.byref(us)), lib)
                         best = min(best, us.value)
                     row.append("t%d %7.1f us %6.1f TF" % (v, best, 2.0 * M * N * K / best / 1e6))
                 print("%-12s %-6s M=%d N=%d K=%d  %s" % (name, mode, M, N, K, " | ".join(row)), flush=True)
     else:
-        for name, B, H, N in ATTN_SHAPES:
+        shapes = ATTN_SHAPES
+        if what == "attn_sweep":  # ~1.6e9 score elements per launch at every length (B*H*N*N), like the B/8 encoder launch of the bench batch
+            shapes = [("n%d" % n, max(1, min(4096, int(round(2.4e8 / (n * n) / 12 * 12)))), 12, n) for n in (40, 64, 100, 128, 196, 256, 392, 512, 792, 1024, 1568, 2048)]
+            shapes = [(nm, max(1, b // 12), 12, n) for nm, b, _, n in shapes]
+        for name, B, H, N in shapes:
             for mode in ("fast", "parity"):
                 row = []
                 for kern in [int(v) for v in os.environ.get("ATTN_KERNELS", "1,3").split(",")]:
-                    _lib.check(lib.cwm_debug_set(b"attn_kernel", kern))
+                    _lib.check(lib.cwm_debug_set(b"attn_kernel", kern), lib)
                     best = 1e30
                     for _ in range(3):
-                        _lib.check(lib.cwm_bench_attention(B, H, N, _lib.mode_id(mode), 10, C.byref(us)))
+                        _lib.check(lib.cwm_bench_attention(B, H, N, _lib.mode_id(mode), 10, C.byref(us)), lib)
                         best = min(best, us.value)
                     row.append("k%d %8.1f us %7.1f TF" % (kern, best, 4.0 * B * H * N * N * 64 / best / 1e6))
                 print("%-8s %-6s B=%d H=%d N=%d  %s" % (name, mode, B, H, N, " | ".join(row)), flush=True)
-        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0))
+        _lib.check(lib.cwm_debug_set(b"attn_kernel", 0), lib)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 # Final measurement set of a round (GPU box): python tests, benches of every BASELINE config, latency table, microbenchmarks.
-#   gpurun --timeout 3000 -- 'bash tools/run_final.sh r5 > gpurun_out/final_r5.log 2>&1'
-TAG=${1:-r5}
+#   gpurun --timeout 3000 -- 'bash tools/run_final.sh r6 > gpurun_out/final_r6.log 2>&1'
+TAG=${1:-r6}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1; tail -1 $OUT/pytest_gpu.log
@@ -11,6 +11,8 @@ timeout 600 python bench.py --workload large4 --mode fast --steps 8 --warmup 2 -
 timeout 600 python bench.py --workload imu4 --steps 8 --warmup 2 > $OUT/bench_imu4.json 2> $OUT/bench_imu4.err
 timeout 600 python bench.py --workload imu4 --mode fast --steps 8 --warmup 2 > $OUT/bench_imu4_fast.json 2>/dev/null
 timeout 600 python bench.py --workload prompts256 --steps 8 --warmup 2 > $OUT/bench_prompts256.json 2>/dev/null
+timeout 300 python bench.py --workload flowstats --steps 10 > $OUT/bench_flowstats.json 2> $OUT/bench_flowstats.err
+timeout 300 python bench.py --workload prompt_build --steps 20 > $OUT/bench_prompt_build.json 2> $OUT/bench_prompt_build.err
 timeout 600 python tools/latency.py > $OUT/latency.log 2>&1
 timeout 600 python tools/microbench.py gemm > $OUT/microbench_gemm_b8.log 2>&1
 timeout 600 python tools/microbench.py attn > $OUT/microbench_attn.log 2>&1
@@ -29,3 +31,5 @@ for line in open(sys.argv[1]):
 PY
 done
 cat $OUT/latency.log
+# a Python traceback in any output of the set = the set is not evidence
+if grep -l "Traceback (most recent call last)" $OUT/*.log $OUT/*.err 2>/dev/null; then echo "TRACEBACK in the files listed above"; exit 1; fi

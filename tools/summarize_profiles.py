@@ -93,6 +93,34 @@ for wl in WORKLOADS:
         "hbm_bytes_per_launch": {k: t["hbm_bytes_per_launch_corrected"] for k, t in kernels.items() if t.get("hbm_bytes_per_launch_corrected")},
         "mfma_busy": {k: t["mfma_busy"] for k, t in kernels.items() if t.get("mfma_busy")}}
 
+# the edge workloads (bench.py --workload flowstats / prompt_build): kernel stats, the bench line of that run, HBM bytes per launch of every kernel
+for wl in ("flowstats", "prompt_build"):
+    f = one("stats_%s_f32/**/*kernel_stats.csv" % wl)
+    if f:
+        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_bench_%s.csv" % (tag, wl)))
+    f = os.path.join(src, "bench_under_rocprof_%s_f32.json" % wl)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        shutil.copy(f, os.path.join(dst, "%s_bench_under_rocprof_%s.json" % (tag, wl)))
+    kernels = {}
+    for d, name in (("pmc_fetch_" + wl, "FETCH_SIZE"), ("pmc_write_" + wl, "WRITE_SIZE")):
+        agg, dur = counters(d)
+        for (k, c), v in agg.items():
+            if c == name and "cwm::" in k:
+                t = kernels.setdefault(k, {})
+                t["launches"] = len(v)
+                t[name + "_KiB_mean_raw"] = sum(v) / len(v)
+                # (these workloads launch one kernel at several sizes -- S = 256 and S = 24 -- so the LARGEST dispatches are reported beside the mean)
+                big = sorted(v)[-max(1, len(v) // 4):]
+                t[name + "_KiB_top_quartile_raw"] = sum(big) / len(big)
+                t["avg_us_in_pmc_pass"] = sum(dur[k].values()) / max(len(dur[k]), 1) / 1e3
+    for k, t in kernels.items():
+        t["hbm_bytes_per_launch_corrected"] = (2.0 * t.get("FETCH_SIZE_KiB_mean_raw", 0.0) + t.get("WRITE_SIZE_KiB_mean_raw", 0.0)) * 1024.0
+        t["hbm_bytes_per_launch_corrected_top_quartile"] = (2.0 * t.get("FETCH_SIZE_KiB_top_quartile_raw", 0.0) + t.get("WRITE_SIZE_KiB_top_quartile_raw", 0.0)) * 1024.0
+    if kernels:
+        out["workloads"][wl] = kernels
+        latest["entries"]["%s/f32" % wl] = {"tag": tag, "source": "profiles/%s_pmc_summary.json" % tag,
+                                            "hbm_bytes_per_launch": {k: t["hbm_bytes_per_launch_corrected_top_quartile"] for k, t in kernels.items()}, "mfma_busy": {}}
+
 for mode in ("fast", "parity"):
     agg, dur = counters("pmc_attn_l4dec_" + mode)
     # (the key-split tail round adds attention_combine_kernel dispatches: the measured kernel is the main one)
