@@ -332,24 +332,36 @@ def run_imu(args, rank, local_rank, world, distributed):
 PEAK_F32_MFMA_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md (exact fp32 products: what torch.cov computes)
 
 
-def _stage_ms(fn, steps):
+_HOST_ISSUE_MS = {}
+
+
+def _stage_ms(fn, steps, key=None):
     """Mean device time of `fn` over `steps` calls between two HIP events on torch's current stream -- the stream every C-ABI call of these workloads
-    launches on (`_lib.current_stream_handle`)."""
+    launches on (`_lib.current_stream_handle`).  The host's time to ISSUE the calls is kept beside it (`key`): a stage of a few small kernels is bound by the
+    Python / ctypes call overhead, and then the event span measures the host, not the kernels (rocprofv3's per-kernel durations under profiles/ are the kernel rates)."""
     fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     a.record()
+    t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    issue = time.perf_counter() - t0
     b.record()
     torch.cuda.synchronize()
+    if key is not None:
+        _HOST_ISSUE_MS[key] = 1e3 * issue / steps
     return a.elapsed_time(b) / steps
 
 
-def _hbm_entry(bytes_per_call, ms, kernels):
+def _hbm_entry(bytes_per_call, ms, kernels, key=None):
     gbs = bytes_per_call / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "avg_us": 1e3 * ms, "bytes_per_call": bytes_per_call,
-            "kernels": kernels}
+    e = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "avg_us": 1e3 * ms, "bytes_per_call": bytes_per_call,
+         "kernels": kernels}
+    if key in _HOST_ISSUE_MS:
+        e["host_issue_us"] = 1e3 * _HOST_ISSUE_MS[key]
+        e["issue_bound"] = bool(_HOST_ISSUE_MS[key] > 0.8 * ms)  # the host needs as long to issue the stage's calls as the events saw: the span is not kernel time
+    return e
 
 
 def aux_traffic(workload, key):
@@ -373,20 +385,21 @@ def flowstats_measure(S_samples, steps, dev, cpu=False):
     stages = {}
     f_bytes = flows.numel() * 4
     x_bytes = x.numel() * 4
-    ms = _stage_ms(lambda: FS.flow_features(flows, ds), steps)
-    stages["features"] = _hbm_entry(f_bytes + x_bytes, ms, ["flow_features_kernel"])
-    ms = _stage_ms(lambda: FS.transform_features(x.clone(), zscore=True), steps) - _stage_ms(lambda: x.clone(), steps)
-    stages["zscore_prologue"] = _hbm_entry(4 * x_bytes, ms, ["flow_colstats_kernel (2 passes over x)", "flow_apply_kernel (read + write)"])
-    ms_cov = _stage_ms(lambda: FS.feature_cov_rows(x, 0, P, True), steps)
+    ms = _stage_ms(lambda: FS.flow_features(flows, ds), steps, "features")
+    stages["features"] = _hbm_entry(f_bytes + x_bytes, ms, ["flow_features_kernel"], "features")
+    xz = x.clone()
+    ms = _stage_ms(lambda: FS.transform_features(xz, zscore=True), steps, "zscore")  # (in place, again and again on the same buffer: the values do not matter here)
+    stages["zscore_prologue"] = _hbm_entry(3 * x_bytes, ms, ["flow_colpartial_kernel (one pass over x)", "flow_colfinish_kernel", "flow_apply_kernel (read + write)"], "zscore")
+    ms_cov = _stage_ms(lambda: FS.feature_cov_rows(x, 0, P, True), steps, "cov")
     out_bytes = P * P * 4
     flops = 2.0 * P * P * S_samples
-    cov = _hbm_entry(out_bytes + 3 * x_bytes, ms_cov, ["flow_center_kernel", "flow_cov_kernel"])
+    cov = _hbm_entry(out_bytes + 3 * x_bytes, ms_cov, ["flow_center_kernel", "flow_cov_kernel"], "cov")
     tf = flops / (ms_cov * 1e-3) / 1e12
     cov["as_mfma"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS, "flops_per_call": flops,
                       "note": "fp32-input MFMA (exact fp32 products); the algorithmic count is the full [P, P] product 2 P^2 S that torch.cov performs"}
     stages["covariance"] = cov
-    ms = _stage_ms(lambda: FS.compute_mean_motion_map(flows, normalize_per_sample=True), steps)
-    stages["motion_map"] = _hbm_entry(2 * f_bytes + H * W * 4 * 3, ms, ["flow_mag_minmax_kernel", "flow_motion_sum_kernel", "flow_map_finish_kernel"])
+    ms = _stage_ms(lambda: FS.compute_mean_motion_map(flows, normalize_per_sample=True), steps, "motion")
+    stages["motion_map"] = _hbm_entry(2 * f_bytes + H * W * 4 * 3, ms, ["flow_mag_minmax_*_kernel", "flow_motion_sum_*_kernel", "flow_map_finish_kernel"], "motion")
 
     def chain():
         FS.compute_flow_corrs(flows, downsample=ds, use_covariance=True)

@@ -168,6 +168,7 @@ SIGNATURES = {
     ),
     "cwm_mask_row_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cwm_mask_flip_picks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "cwm_prompt_table_expand": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4),
     "cwm_shift_prompts": (
         C.c_int,
         [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p] * 6,

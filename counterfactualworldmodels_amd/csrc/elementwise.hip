@@ -600,6 +600,29 @@ __global__ __launch_bounds__(256) void shift_prompts_mask_kernel(const ShiftProm
     p.mask_out[gid] = (m1 && mp) ? 1 : 0;
 }
 
+// The prompt table of the counterfactual batch (BASELINE configs[3]; interface.py:370-377: one active patch of frame `frame` per prompt, moved by (dy, dx)
+// patches, nothing passive) -> the dense operands of the kernels above: passive[i] = "frame 0 visible, every later frame masked", active[i] = passive[i] with the
+// prompt's patch cleared, shifts[i] = (dy, dx).  One launch instead of the ten tensor operations that built them on rank 0's critical path (dist.py prompt_hooks).
+__global__ __launch_bounds__(256) void prompt_table_expand_kernel(const int* __restrict__ table, int S, int n, int gw, int T, int frame, uint8_t* __restrict__ active,
+                                                                  uint8_t* __restrict__ passive, int* __restrict__ shifts) {
+    const int Nt = T * n;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)S * Nt) return;
+    const int i = (int)(gid / Nt), tau = (int)(gid - (int64_t)i * Nt);
+    const int h = table[4 * i], w = table[4 * i + 1];
+    const uint8_t pas = tau >= n ? 1 : 0;
+    passive[gid] = pas;
+    active[gid] = (tau == frame * n + h * gw + w) ? 0 : pas;
+    if (tau < 2) shifts[2 * i + tau] = table[4 * i + 2 + tau];
+}
+
+int launch_prompt_table_expand(const int* table, int S, int n, int gw, int T, int frame, uint8_t* active, uint8_t* passive, int* shifts, hipStream_t stream) {
+    const int64_t total = (int64_t)S * T * n;
+    hipLaunchKernelGGL(prompt_table_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, table, S, n, gw, T, frame, active, passive, shifts);
+    CWM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_shift_prompts(const ShiftPromptParams& p, hipStream_t stream) {
     CWM_REQUIRE(p.P % 4 == 0 && p.W % 4 == 0 && p.H % p.P == 0 && p.W % p.P == 0, "shift_prompts: bad patch/image size");
     CWM_REQUIRE(p.frame >= 0 && p.frame < p.T, "shift_prompts: frame out of range");

@@ -41,6 +41,32 @@ __global__ void flow_features_kernel(const float* __restrict__ f, int64_t sb, in
     x[i] = sqrtf(acc / (float)C);
 }
 
+// the same with the sample axis innermost (ss == 1) and S a multiple of 4: four samples per thread, 16-byte loads (a quarter of the load instructions)
+__global__ void flow_features4_kernel(const float* __restrict__ f, int64_t sb, int64_t sc, int64_t sh, int64_t sw, int B, int C, int H, int W, int S, int ds,
+                                      float* __restrict__ x) {
+    const int Wd = W / ds, P = (H / ds) * Wd, S4 = S / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * P * S4) return;
+    const int s = (int)(i % S4) * 4;
+    const int64_t bp = i / S4;
+    const int pidx = (int)(bp % P), b = (int)(bp / P);
+    const int py = pidx / Wd, px = pidx - py * Wd;
+    const float inv_area = 1.0f / (float)(ds * ds);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+        const float* fc = f + b * sb + c * sc + s;
+        f32x4 pool = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dy = 0; dy < ds; ++dy)
+            for (int dx = 0; dx < ds; ++dx) pool += *reinterpret_cast<const f32x4*>(fc + (int64_t)(py * ds + dy) * sh + (int64_t)(px * ds + dx) * sw);
+        pool = pool * inv_area;
+        acc += pool * pool;
+    }
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = sqrtf(acc[r] / (float)C);
+    *reinterpret_cast<f32x4*>(x + ((size_t)b * P + pidx) * S + s) = o;
+}
+
 // ---- centre the rows; inverse standard deviations for the correlation form ----------------------------------------------
 // one wave per row (b, p): xc = x - mean_S(x); inv_std = 1 / sqrt(sum xc^2 / (S - 1))  (the scale of torch.corrcoef)
 __global__ void flow_center_kernel(const float* __restrict__ x, int rows, int S, float* __restrict__ xc, float* __restrict__ inv_std) {
@@ -75,24 +101,42 @@ constexpr int kCovBK = 32;     // samples staged per step
 constexpr int kCovPitch = 36;  // floats per staged operand row: 16-byte aligned rows, and rows r, r + 1 sit 36 mod 64 banks apart (fragment reads conflict-free)
 constexpr int kCovEpiPitch = 68;
 
-__device__ __forceinline__ void cov_load_step(const float* __restrict__ xb, int P, int S, int r0, int k0, int tid, bool vec, f32x4 (&v)[4]) {
+// FULL: all 128 rows and all 32 samples of the step are in range (a workgroup-uniform condition: every step of every tile at P = 12544, S = 256) -- eight plain
+// 16-byte loads, nothing between them.  Otherwise out-of-range elements are zero.  (With the bounds checks around every load hipcc put an `s_waitcnt vmcnt(0)`
+// between consecutive loads -- the zeroing writes the load's own destination registers --: eight serialised L2 round trips per K step and the matrix pipe 47 % busy,
+// profiles/r6_pmc_flow_cov_before.txt.)
+template <bool VEC, bool FULL>
+__device__ __forceinline__ void cov_load_step(const float* __restrict__ xb, int P, int S, int r0, int k0, int tid, f32x4 (&v)[4]) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int e = tid + 256 * n, r = e >> 3, k = k0 + (e & 7) * 4;
         const int row = r0 + r;
-        f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (row < P) {
-            const float* src = xb + (size_t)row * S + k;
-            if (vec) {
-                if (k < S) q = *reinterpret_cast<const f32x4*>(src);  // (S % 4 == 0: the four samples are in range together)
-            } else {
+        if constexpr (FULL && VEC) {
+            v[n] = *reinterpret_cast<const f32x4*>(xb + (size_t)row * S + k);
+        } else {
+            f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < P) {
+                const float* src = xb + (size_t)row * S + k;
+                if (VEC) {
+                    if (k < S) q = *reinterpret_cast<const f32x4*>(src);  // (S % 4 == 0: the four samples are in range together)
+                } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (k + c < S) q[c] = src[c];
+                    for (int c = 0; c < 4; ++c)
+                        if (k + c < S) q[c] = src[c];
+                }
             }
+            v[n] = q;
         }
-        v[n] = q;
     }
+}
+
+// MODE 2: the launch has only whole tiles and whole steps (P % 128 == 0, S % 32 == 0, slabs starting on a tile row: decided on the host) -- the kernel contains
+// no bounds path at all (a run-time choice between the two forms inside one kernel merges their registers at the join, and the copies there wait for the loads);
+// MODE 1: 16-byte loads with bounds; MODE 0: S is not a multiple of 4.
+template <int MODE>
+__device__ __forceinline__ void cov_load_pair(const float* __restrict__ xb, int P, int S, int i0, int j0, int k0, int tid, f32x4 (&vi)[4], f32x4 (&vj)[4]) {
+    cov_load_step<(MODE >= 1), (MODE == 2)>(xb, P, S, i0, k0, tid, vi);
+    cov_load_step<(MODE >= 1), (MODE == 2)>(xb, P, S, j0, k0, tid, vj);
 }
 
 __device__ __forceinline__ void cov_store_step(float* lds, int tid, const f32x4 (&v)[4]) {
@@ -103,7 +147,7 @@ __device__ __forceinline__ void cov_store_step(float* lds, int tid, const f32x4 
     }
 }
 
-template <bool SYM>
+template <bool SYM, int MODE>
 __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__ xc, const float* __restrict__ inv_std, int P, int S, int row0, int nrows,
                                                        int use_cov, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 128 * kCovPitch];  // operand tiles i | j; the epilogue's four wave buffers afterwards
@@ -127,7 +171,6 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const float* xb = xc + (size_t)b * P * S;
-    const bool vec = (S & 3) == 0;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -136,18 +179,16 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
         for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x4 vi[4], vj[4];
-    cov_load_step(xb, P, S, i0, 0, tid, vec, vi);
-    cov_load_step(xb, P, S, j0, 0, tid, vec, vj);
+    cov_load_pair<MODE>(xb, P, S, i0, j0, 0, tid, vi, vj);
     cov_store_step(lds_i, tid, vi);
     cov_store_step(lds_j, tid, vj);
     __syncthreads();
     for (int k0 = 0; k0 < S; k0 += kCovBK) {
         const bool more = k0 + kCovBK < S;
         if (more) {  // next step's operands: in flight under this step's MFMAs
-            cov_load_step(xb, P, S, i0, k0 + kCovBK, tid, vec, vi);
-            cov_load_step(xb, P, S, j0, k0 + kCovBK, tid, vec, vj);
+            cov_load_pair<MODE>(xb, P, S, i0, j0, k0 + kCovBK, tid, vi, vj);
         }
-#pragma unroll
+#pragma unroll 2
         for (int kk = 0; kk < kCovBK; kk += 4) {
             const int kq = kk + (lane >> 4);
             float av[4], bv[4];
@@ -183,7 +224,7 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
             for (int r = 0; r < 4; ++r) {
                 float c = acc[fi][fj][r] * inv_n1;
                 if (!use_cov && j + r < P) {
-                    c = c * si * inv_std[(size_t)b * P + j + r];
+                    c = c * (si * inv_std[(size_t)b * P + j + r]);  // (s_i s_j first: the same bits for (i, j) and (j, i) -- the matrix is exactly symmetric)
                     // torch.corrcoef clips to [-1, 1] and keeps a NaN (a constant row: 0 * inf) a NaN; fminf / fmaxf would turn it into -1
                     if (c == c) c = fminf(1.0f, fmaxf(-1.0f, c));
                 }
@@ -224,7 +265,7 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
                     const f32x4 v = *reinterpret_cast<const f32x4*>(buf + rr * kCovEpiPitch + c4);
                     float* dst = out + ((size_t)b * nrows + (row - r_off)) * P + col;
                     if (row_vec) {
-                        *reinterpret_cast<f32x4*>(dst) = v;
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));  // (629 MB at P = 12544, written once: a streaming store)
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
@@ -304,20 +345,28 @@ __global__ __launch_bounds__(256) void flow_colpartial_kernel(const float* __res
     const bool in = s < S;
     const int p0 = chunk * kColChunkRows, p1 = min(P, p0 + kColChunkRows);
     const float* xb = x + (size_t)b * P * S + (in ? s : 0);
+    // float64 sums of (v - K) and (v - K)^2 about the thread's first value K: no division per element, and the shift keeps M2 = sum2 - sum^2 / n free of
+    // cancellation at float64 (the values of a column are within a few orders of magnitude of each other)
     double n = 0.0, mean = 0.0, m2 = 0.0;
     float mn = INFINITY, mx = -INFINITY;
     int has_nan = 0;
-    if (in)
+    if (in && p0 + rg < p1) {
+        const double K = (double)xb[(size_t)(p0 + rg) * S];
+        double sum = 0.0, sum2 = 0.0;
         for (int p = p0 + rg; p < p1; p += 4) {
             const float v = xb[(size_t)p * S];
             has_nan |= (v != v) ? 1 : 0;
             mn = fminf(mn, v);
             mx = fmaxf(mx, v);
             n += 1.0;
-            const double d = (double)v - mean;
-            mean += d / n;
-            m2 += d * ((double)v - mean);
+            const double d = (double)v - K;
+            sum += d;
+            sum2 += d * d;
         }
+        mean = K + sum / n;
+        m2 = sum2 - sum * sum / n;
+        if (m2 < 0.0) m2 = 0.0;
+    }
     rn[rg][c] = n; rmean[rg][c] = mean; rm2[rg][c] = m2;
     rmn[rg][c] = mn; rmx[rg][c] = mx; rnan[rg][c] = has_nan;
     __syncthreads();
@@ -334,18 +383,34 @@ __global__ __launch_bounds__(256) void flow_colpartial_kernel(const float* __res
     }
 }
 
-__global__ void flow_colfinish_kernel(const ColPartial* __restrict__ part, int P, int S, int n_chunks, float4* __restrict__ st) {
-    const int b = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
+// 64 columns x 16 chunk groups per workgroup: group g merges its chunks in ascending order, then group 0 merges the 16 group results in ascending order -- the
+// same association for every launch (deterministic).  (One thread per column walking all 112 chunks: 43 us of dependent loads, profiles/r6_kernel_stats_bench_flowstats*.csv.)
+__global__ __launch_bounds__(1024) void flow_colfinish_kernel(const ColPartial* __restrict__ part, int P, int S, int n_chunks, float4* __restrict__ st) {
+    __shared__ double gn[16][64], gmean[16][64], gm2[16][64];
+    __shared__ float gmn[16][64], gmx[16][64];
+    __shared__ int gnan[16][64];
+    const int b = blockIdx.y, c = threadIdx.x & 63, g = threadIdx.x >> 6, s = blockIdx.x * 64 + c;
+    const int per = (n_chunks + 15) / 16;
     double n = 0.0, mean = 0.0, m2 = 0.0;
     float mn = INFINITY, mx = -INFINITY;
     int has_nan = 0;
-    for (int ch = 0; ch < n_chunks; ++ch) {  // chunks in ascending order: the result does not depend on the launch
-        const ColPartial q = part[((size_t)b * n_chunks + ch) * S + s];
-        col_merge(n, mean, m2, q.n, q.mean, q.m2);
-        mn = fminf(mn, q.mn);
-        mx = fmaxf(mx, q.mx);
-        has_nan |= q.nan;
+    if (s < S)
+        for (int ch = g * per; ch < min(n_chunks, (g + 1) * per); ++ch) {
+            const ColPartial q = part[((size_t)b * n_chunks + ch) * S + s];
+            col_merge(n, mean, m2, q.n, q.mean, q.m2);
+            mn = fminf(mn, q.mn);
+            mx = fmaxf(mx, q.mx);
+            has_nan |= q.nan;
+        }
+    gn[g][c] = n; gmean[g][c] = mean; gm2[g][c] = m2;
+    gmn[g][c] = mn; gmx[g][c] = mx; gnan[g][c] = has_nan;
+    __syncthreads();
+    if (g != 0 || s >= S) return;
+    for (int k = 1; k < 16; ++k) {
+        col_merge(n, mean, m2, gn[k][c], gmean[k][c], gm2[k][c]);
+        mn = fminf(mn, gmn[k][c]);
+        mx = fmaxf(mx, gmx[k][c]);
+        has_nan |= gnan[k][c];
     }
     const double var = m2 / (double)(P - 1);  // P == 1: 0 / 0 = NaN, as torch.std
     const float qn = __builtin_nanf("");
@@ -509,11 +574,175 @@ __global__ __launch_bounds__(256) void flow_motion_sum_packed_kernel(const float
     sum[(size_t)b * HW + pix0 + threadIdx.x] = acc;
 }
 
-// map = sum * scale; if normalize: (map - min) / max(max - min, eps) over (H, W) per b.  One workgroup per b.
-__global__ void flow_map_finish_kernel(float* __restrict__ map, int HW, float scale, int normalize, float eps) {
+// ---- the same two passes for S = 64, 128 or a multiple of 256 (the counterfactual batch of BASELINE configs[3]: S = 256): no LDS tile at all --------------
+// Q lanes own one pixel's samples as 16-byte loads (Q = 16 / 32 / 64 lanes x 4 samples; S = 256 k: k such loads per pixel): a pixel's channel values arrive as
+// ONE coalesced 1-KB wave load per channel, the per-sample range sits in the lane's registers for the whole launch (the lane's samples never change), and the sum
+// over the samples is a DPP / shuffle reduction over the Q lanes.  Every wave walks 16 pixels, four at a time (8 independent loads in flight per lane).
+// (The LDS-tile form above at S = 256: 64 x 257 x 4 B = 66 KB per workgroup -> two workgroups per CU, and a 64-thread serial tail: 253 us for 2 x 103 MB.)
+constexpr int kRowPixPerWave = 16;
+
+template <int Q>
+__device__ __forceinline__ float group_sum(float v) {  // sum over aligned groups of Q lanes; every lane of the group gets it
+#pragma unroll
+    for (int off = 1; off < Q; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void flow_mag_minmax_rows_kernel(const float* __restrict__ f, int64_t sb, int64_t sc, int C, int HW, int S,
+                                                                   unsigned* __restrict__ mn_bits, unsigned* __restrict__ mx_bits) {
+    __shared__ float red_mn[4][256], red_mx[4][256];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PPL = 64 / Q;                  // pixels per wave load
+    const int sub = lane / Q, s4 = (lane % Q) * 4;
+    const int chunks = Q == 64 ? S / 256 : 1;    // 256-sample pieces per pixel
+    const int pix0 = (blockIdx.x * 4 + wave) * kRowPixPerWave;
+    const float* fb = f + b * sb;
+    for (int ch = 0; ch < chunks; ++ch) {
+        f32x4 mn = f32x4{INFINITY, INFINITY, INFINITY, INFINITY}, mx = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 4
+        for (int i = 0; i < kRowPixPerWave; i += PPL) {
+            const int pix = pix0 + i + sub;
+            if (pix < HW) {
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < C; ++c) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(fb + c * sc + (int64_t)pix * S + ch * 256 + s4);
+                    a += v * v;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m = sqrtf(a[r]);
+                    mn[r] = fminf(mn[r], m);
+                    mx[r] = fmaxf(mx[r], m);
+                }
+            }
+        }
+        // lanes that hold the same samples for other pixels of the wave load (Q < 64), then the four waves: LDS; then one atomic pair per sample and workgroup
+#pragma unroll
+        for (int off = Q; off < 64; off <<= 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mn[r] = fminf(mn[r], __shfl_xor(mn[r], off, 64));
+                mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], off, 64));
+            }
+        if (lane < Q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red_mn[wave][s4 + r] = mn[r];
+                red_mx[wave][s4 + r] = mx[r];
+            }
+        __syncthreads();
+        const int ns = Q * 4;  // samples of this piece
+        for (int s = threadIdx.x; s < ns; s += 256) {
+            const float lo = fminf(fminf(red_mn[0][s], red_mn[1][s]), fminf(red_mn[2][s], red_mn[3][s]));
+            const float hi = fmaxf(fmaxf(red_mx[0][s], red_mx[1][s]), fmaxf(red_mx[2][s], red_mx[3][s]));
+            if (lo != INFINITY) atomicMin(&mn_bits[(size_t)b * S + ch * 256 + s], __float_as_uint(lo));
+            if (hi != -INFINITY) atomicMax(&mx_bits[(size_t)b * S + ch * 256 + s], __float_as_uint(hi));
+        }
+        __syncthreads();
+    }
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void flow_motion_sum_rows_kernel(const float* __restrict__ f, int64_t sb, int64_t sc, int C, int HW, int S,
+                                                                   const unsigned* __restrict__ mn_bits, const unsigned* __restrict__ mx_bits, float eps,
+                                                                   float* __restrict__ sum) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PPL = 64 / Q;
+    const int sub = lane / Q, s4 = (lane % Q) * 4;
+    const int chunks = Q == 64 ? S / 256 : 1;
+    const int pix0 = (blockIdx.x * 4 + wave) * kRowPixPerWave;
+    const float* fb = f + b * sb;
+    auto range_of = [&](int ch, f32x4& lo, f32x4& range) {
+        lo = f32x4{0.f, 0.f, 0.f, 0.f};
+        range = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (mn_bits) {
+            const u32x4 l = *reinterpret_cast<const u32x4*>(mn_bits + (size_t)b * S + ch * 256 + s4), h = *reinterpret_cast<const u32x4*>(mx_bits + (size_t)b * S + ch * 256 + s4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lo[r] = __uint_as_float(l[r]);
+                range[r] = fmaxf(__uint_as_float(h[r]) - lo[r], eps);
+            }
+        }
+    };
+    auto piece = [&](int pix, int ch, const f32x4& lo, const f32x4& range) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(fb + c * sc + (int64_t)pix * S + ch * 256 + s4);
+            a += v * v;
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = sqrtf(a[r]);
+            if (mn_bits) m = (m - lo[r]) / range[r];
+            part += m;
+        }
+        return part;
+    };
+    f32x4 lo0, range0;
+    range_of(0, lo0, range0);  // (one piece per pixel -- S <= 256 -- : the lane's ranges stay in registers for the whole launch)
+#pragma unroll 4
+    for (int i = 0; i < kRowPixPerWave; i += PPL) {
+        const int pix = pix0 + i + sub;
+        float part = 0.f;
+        if (pix < HW) {
+            part = piece(pix, 0, lo0, range0);
+            for (int ch = 1; ch < chunks; ++ch) {
+                f32x4 lo, range;
+                range_of(ch, lo, range);
+                part += piece(pix, ch, lo, range);
+            }
+        }
+        const float tot = group_sum<Q>(part);
+        if ((lane % Q) == 0 && pix < HW) sum[(size_t)b * HW + pix] = tot;
+    }
+}
+
+// map = sum * scale; if normalize: (map - min) / max(max - min, eps) over (H, W) per b.  One workgroup of 1024 threads per b.
+// Maps of up to 65536 pixels whose size is a multiple of 4 (224 x 224 = 50176) stay in registers between the range pass and the normalisation: every thread issues its
+// <= 16 independent 16-byte loads at once, one pass over memory (round 6; the two-pass loop below took 25 us for 200 KB -- a chain of 49 dependent 4-byte loads per thread, twice).
+__global__ __launch_bounds__(1024) void flow_map_finish_kernel(float* __restrict__ map, int HW, float scale, int normalize, float eps) {
     __shared__ float red[32];
     float* m = map + (size_t)blockIdx.x * HW;
     float mn = INFINITY, mx = -INFINITY;
+    if ((HW & 3) == 0 && HW <= 1024 * 4 * 16 && (((uintptr_t)m) & 15) == 0) {
+        f32x4 v[16];
+        const int n4 = HW / 4;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = threadIdx.x + 1024 * k;
+            if (e < n4) v[k] = *reinterpret_cast<const f32x4*>(m + 4 * (size_t)e);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = threadIdx.x + 1024 * k;
+            if (e < n4) {
+                v[k] = v[k] * scale;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    mn = fminf(mn, v[k][r]);
+                    mx = fmaxf(mx, v[k][r]);
+                }
+            }
+        }
+        float d = 1.f;
+        if (normalize) {
+            block_minmax(mn, mx, red);
+            d = fmaxf(mx - mn, eps);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = threadIdx.x + 1024 * k;
+            if (e < n4) {
+                if (normalize)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[k][r] = (v[k][r] - mn) / d;
+                *reinterpret_cast<f32x4*>(m + 4 * (size_t)e) = v[k];
+            }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < HW; e += blockDim.x) {
         const float v = m[e] * scale;
         m[e] = v;
@@ -535,6 +764,14 @@ extern "C" int cwm_flow_features(const float* flows_dev, const int64_t* strides,
     CWM_REQUIRE(flows_dev && strides && x_dev && B > 0 && C > 0 && H > 0 && W > 0 && S > 0, "cwm_flow_features: bad argument");
     CWM_REQUIRE(downsample >= 1 && H % downsample == 0 && W % downsample == 0, "cwm_flow_features: downsample=%d must divide H=%d and W=%d",
                 downsample, H, W);
+    if (strides[4] == 1 && S % 4 == 0 && ((uintptr_t)flows_dev & 15) == 0 && ((uintptr_t)x_dev & 15) == 0 && strides[0] % 4 == 0 && strides[1] % 4 == 0 && strides[2] % 4 == 0 &&
+        strides[3] % 4 == 0) {
+        const int64_t total4 = (int64_t)B * (H / downsample) * (W / downsample) * (S / 4);
+        hipLaunchKernelGGL(flow_features4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flows_dev, strides[0], strides[1], strides[2],
+                           strides[3], B, C, H, W, S, downsample, x_dev);
+        CWM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const int64_t total = (int64_t)B * (H / downsample) * (W / downsample) * S;
     hipLaunchKernelGGL(flow_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flows_dev, strides[0],
                        strides[1], strides[2], strides[3], strides[4], B, C, H, W, S, downsample, x_dev);
@@ -550,13 +787,23 @@ extern "C" int cwm_flow_cov(const float* x_dev, int B, int P, int S, int row0, i
     const int rows = B * P;
     hipLaunchKernelGGL(flow_center_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x_dev, rows, S, xc_work_dev, inv_std_work_dev);
     const int T = (P + 127) / 128;
-    if (row0 == 0 && nrows == P) {  // the whole (symmetric) matrix: tiles on and above the diagonal, each off-diagonal one written twice
-        hipLaunchKernelGGL(flow_cov_kernel<true>, dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)B), dim3(256), 0, s, xc_work_dev, inv_std_work_dev, P, S, 0, P,
-                           use_covariance ? 1 : 0, out_dev);
+    const bool vec = S % 4 == 0 && ((uintptr_t)xc_work_dev & 15) == 0;
+    const bool sym = row0 == 0 && nrows == P;  // the whole (symmetric) matrix: tiles on and above the diagonal, each off-diagonal one written twice
+    const int mode = !vec ? 0 : (P % 128 == 0 && S % kCovBK == 0 && row0 % 128 == 0) ? 2 : 1;
+    const int uc = use_covariance ? 1 : 0;
+    const dim3 grid = sym ? dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)B) : dim3((unsigned)T, (unsigned)((nrows + 127) / 128), (unsigned)B);
+#define CWM_COV_LAUNCH(SYM_, MODE_) \
+    hipLaunchKernelGGL((flow_cov_kernel<SYM_, MODE_>), grid, dim3(256), 0, s, xc_work_dev, inv_std_work_dev, P, S, row0, nrows, uc, out_dev)
+    if (sym) {
+        if (mode == 2) CWM_COV_LAUNCH(true, 2);
+        else if (mode == 1) CWM_COV_LAUNCH(true, 1);
+        else CWM_COV_LAUNCH(true, 0);
     } else {
-        const dim3 grid((unsigned)T, (unsigned)((nrows + 127) / 128), (unsigned)B);
-        hipLaunchKernelGGL(flow_cov_kernel<false>, grid, dim3(256), 0, s, xc_work_dev, inv_std_work_dev, P, S, row0, nrows, use_covariance ? 1 : 0, out_dev);
+        if (mode == 2) CWM_COV_LAUNCH(false, 2);
+        else if (mode == 1) CWM_COV_LAUNCH(false, 1);
+        else CWM_COV_LAUNCH(false, 0);
     }
+#undef CWM_COV_LAUNCH
     CWM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -577,7 +824,7 @@ extern "C" int cwm_flow_transform(float* x_dev, int B, int P, int S, int spearma
     const dim3 agrid((unsigned)((S + 63) / 64), (unsigned)((P + 4 * kApplyRows - 1) / (4 * kApplyRows)), (unsigned)B);
     auto colstats = [&]() {
         hipLaunchKernelGGL(flow_colpartial_kernel, pgrid, dim3(256), 0, s, x_dev, P, S, n_chunks, part);
-        hipLaunchKernelGGL(flow_colfinish_kernel, fgrid, dim3(64), 0, s, part, P, S, n_chunks, st);
+        hipLaunchKernelGGL(flow_colfinish_kernel, fgrid, dim3(1024), 0, s, part, P, S, n_chunks, st);
     };
     if (spearman) {
         const size_t smem = (size_t)4 * S * sizeof(float);
@@ -616,7 +863,28 @@ extern "C" int cwm_flow_motion_sum(const float* flows_dev, const int64_t* stride
     hipStream_t s = (hipStream_t)stream;
     // the reference's layout (sample axis innermost, (H, W, S) packed): the coalesced kernels; any other strides: the strided ones
     const size_t smem = (size_t)kMagPix * (S + 1) * sizeof(float);
-    if (strides[4] == 1 && strides[3] == S && strides[2] == (int64_t)W * S && smem <= 150 * 1024) {
+    const bool packed = strides[4] == 1 && strides[3] == S && strides[2] == (int64_t)W * S;
+    const int q = S == 64 ? 16 : S == 128 ? 32 : (S % 256 == 0 ? 64 : 0);  // lanes per pixel of the register form (0: the LDS-tile form)
+    if (packed && q && strides[0] % 4 == 0 && strides[1] % 4 == 0 && ((uintptr_t)flows_dev & 15) == 0 && (!normalize_per_sample || ((uintptr_t)minmax_work_dev & 15) == 0)) {
+        const int HW = H * W;
+        const dim3 grid((unsigned)((HW + 4 * kRowPixPerWave - 1) / (4 * kRowPixPerWave)), (unsigned)B);
+        unsigned *mn = nullptr, *mx = nullptr;
+        if (normalize_per_sample) {  // work buffer [B][S][2] floats used as [B][S] min bits | [B][S] max bits
+            mn = reinterpret_cast<unsigned*>(minmax_work_dev);
+            mx = mn + (size_t)B * S;
+            CWM_HIP_CHECK(hipMemsetAsync(mn, 0xFF, (size_t)B * S * sizeof(unsigned), s));
+            CWM_HIP_CHECK(hipMemsetAsync(mx, 0x00, (size_t)B * S * sizeof(unsigned), s));
+            if (q == 16) hipLaunchKernelGGL(flow_mag_minmax_rows_kernel<16>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx);
+            else if (q == 32) hipLaunchKernelGGL(flow_mag_minmax_rows_kernel<32>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx);
+            else hipLaunchKernelGGL(flow_mag_minmax_rows_kernel<64>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx);
+        }
+        if (q == 16) hipLaunchKernelGGL(flow_motion_sum_rows_kernel<16>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx, eps, sum_dev);
+        else if (q == 32) hipLaunchKernelGGL(flow_motion_sum_rows_kernel<32>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx, eps, sum_dev);
+        else hipLaunchKernelGGL(flow_motion_sum_rows_kernel<64>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx, eps, sum_dev);
+        CWM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (packed && smem <= 150 * 1024) {
         const int HW = H * W;
         const dim3 grid((unsigned)((HW + kMagPix - 1) / kMagPix), (unsigned)B);
         unsigned *mn = nullptr, *mx = nullptr;

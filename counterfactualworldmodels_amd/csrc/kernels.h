@@ -190,6 +190,7 @@ struct ShiftPromptParams {
 };
 
 int launch_shift_prompts(const ShiftPromptParams& p, hipStream_t stream);
+int launch_prompt_table_expand(const int* table, int S, int n, int gw, int T, int frame, uint8_t* active, uint8_t* passive, int* shifts, hipStream_t stream);
 
 // ---- IMU-conditioned conjoined predictor (conj_kernels.hip) ------------------------------------------
 struct SmallAttnParams {

@@ -577,6 +577,13 @@ extern "C" int cwm_mask_flip_picks(uint8_t* mask_dev, int B, int Nt, const int32
     return launch_mask_flip_picks(mask_dev, Nt, table_dev, n_rows, (hipStream_t)stream);
 }
 
+extern "C" int cwm_prompt_table_expand(const int32_t* table_dev, int S, int T, int grid_h, int grid_w, int frame, uint8_t* active_dev, uint8_t* passive_dev,
+                                       int32_t* shifts_dev, void* stream) {
+    CWM_REQUIRE(table_dev && active_dev && passive_dev && shifts_dev, "cwm_prompt_table_expand: null argument");
+    CWM_REQUIRE(S > 0 && T >= 2 && grid_h > 0 && grid_w > 0 && frame >= 1 && frame < T, "cwm_prompt_table_expand: bad sizes (S %d, T %d, grid %d x %d, frame %d)", S, T, grid_h, grid_w, frame);
+    return launch_prompt_table_expand(table_dev, S, grid_h * grid_w, grid_w, T, frame, active_dev, passive_dev, shifts_dev, (hipStream_t)stream);
+}
+
 extern "C" int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int P, int frame, int S, int fix_passive,
                                  const uint8_t* active_dev, const uint8_t* masks_dev, const int32_t* shifts_dev, float* x_out_dev,
                                  uint8_t* mask_out_dev, void* stream) {

@@ -284,19 +284,27 @@ class PhaseTimes:
     def __init__(self, device):
         self.device = torch.device(device)
         self.spans: List[Tuple[str, object, object]] = []
+        self.host: dict = {}  # {phase: milliseconds the HOST spent inside the phase's spans} (issue time; `result()` reports it as "<phase>_host")
 
     class _Span:
         def __init__(self, owner, phase, stream):
             self.owner, self.phase, self.stream = owner, phase, stream
 
         def __enter__(self):
+            import time
+
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record(self.stream or torch.cuda.current_stream(self.owner.device))
+            self.t0 = time.perf_counter()
 
         def __exit__(self, *exc):
+            import time
+
+            host = time.perf_counter() - self.t0
             b = torch.cuda.Event(enable_timing=True)
             b.record(self.stream or torch.cuda.current_stream(self.owner.device))
             self.owner.spans.append((self.phase, self.a, b))
+            self.owner.host[self.phase] = self.owner.host.get(self.phase, 0.0) + 1e3 * host
             return False
 
     def span(self, phase: str, stream=None):
@@ -308,6 +316,8 @@ class PhaseTimes:
         out: dict = {}
         for phase, a, b in self.spans:
             out[phase] = out.get(phase, 0.0) + a.elapsed_time(b)
+        for phase, ms in self.host.items():
+            out[phase + "_host"] = ms
         return out
 
 
@@ -485,24 +495,27 @@ def prompt_hooks(G, frame: Optional[int] = -1):
     (active_h, active_w, dy, dx): one active patch of frame 1 moved by (dy, dx) patches, nothing passive (cfg 4)."""
     from .prediction import _RectBatch
 
-    cache = {}
-
     def build(xb, rows, frames=True):
+        """The prompt rows -> (frames [n,T,C,H,W] | None, masks [n,Nt]): `cwm_prompt_table_expand` (table -> dense active / passive masks + shifts, one launch) and
+        `cwm_shift_prompts` on the image as a static two-frame movie (only frame 0 exists in memory)."""
+        from . import _lib
+
         n_rows = rows.shape[0]
         T = 2
         xb = xb[:, :1]
         G.inp_shape = (1, T) + tuple(xb.shape[2:])
         _, gh, gw = G.mask_shape
-        n = gh * gw
-        key = (n_rows, n, xb.device)
-        if key not in cache:  # (the passive mask -- frame 0 visible, frame 1 masked -- and the cell weights depend on the grid alone: built once, not per call on
-            cache.clear()     # rank 0's critical path; one entry: the loop alternates between at most "all rows" and "my rows")
-            cache[key] = ((torch.arange(T * n, device=xb.device) >= n)[None].expand(n_rows, -1).contiguous(),
-                          torch.tensor([gw, 1], dtype=torch.int64, device=xb.device))
-        passive, weights = cache[key]
-        cell = (rows[:, :2].long() * weights).sum(1, keepdim=True) + n
-        active = passive.scatter(1, cell, False)
-        return G._shift_rows(xb.expand(-1, T, -1, -1, -1), passive, active, rows[:, 2:4], 1, True, samples_per_movie=n_rows, frames=frames)
+        dev = xb.device
+        if not xb.is_cuda:
+            raise RuntimeError("counterfactual prompts are built on the GPU (no CPU fallback); got a %s tensor" % dev)
+        rows = rows.to(device=dev, dtype=torch.int32).contiguous()
+        active = torch.empty((n_rows, T * gh * gw), device=dev, dtype=torch.bool)
+        passive = torch.empty_like(active)
+        shifts = torch.empty((n_rows, 2), device=dev, dtype=torch.int32)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.get_lib().cwm_prompt_table_expand(rows.data_ptr(), n_rows, T, gh, gw, 1, active.data_ptr(), passive.data_ptr(), shifts.data_ptr(),
+                                                             _lib.current_stream_handle(dev)))
+        return G._shift_rows(xb, passive, active, shifts, 1, True, samples_per_movie=n_rows, frames=frames, num_frames=T)
 
     def rect(masks):
         masks = G.mask_rectangularizer(masks)

@@ -87,13 +87,16 @@ class RectangularizeMasks:
             picks.append(k)
             offsets.append(offsets[-1] + k.numel())
         if rows:
-            table = torch.cat([torch.tensor([len(rows)] + rows + offsets + to_value, dtype=torch.int32)] + [k.to(torch.int32) for k in picks])
-            n = table.numel()
+            head = [len(rows)] + rows + offsets + to_value
+            n = len(head) + offsets[-1]
             if getattr(self, "_table_host", None) is None or self._table_host.numel() < n:
                 self._table_host = torch.empty(max(n, 4096), dtype=torch.int32, pin_memory=True)
             if getattr(self, "_table_event", None) is not None:
                 self._table_event.synchronize()  # the previous call's copy out of the pinned buffer has run (it may have been queued on another stream)
-            self._table_host[:n].copy_(table)
+            # written straight into the pinned buffer: the header through numpy, the picks with ONE concatenation (32 changed rows used to cost 32 casts + a 33-way cat)
+            th = self._table_host.numpy()
+            th[: len(head)] = head
+            self._table_host[len(head) : n].copy_(torch.cat(picks) if len(picks) > 1 else picks[0])
             table_dev = self._table_host[:n].to(masks.device, non_blocking=True)
             self._table_event = torch.cuda.Event()
             self._table_event.record(torch.cuda.current_stream(masks.device))

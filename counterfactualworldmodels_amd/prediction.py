@@ -426,7 +426,7 @@ class PredictorBasedGenerator(nn.Module):
             if dy + dx != 0:
                 return (dy, dx)
 
-    def _shift_rows(self, x, passive, active, shifts, frame, fix_passive, samples_per_movie=1, frames=True, masks=True):
+    def _shift_rows(self, x, passive, active, shifts, frame, fix_passive, samples_per_movie=1, frames=True, masks=True, num_frames=None):
         """Device-side prompt construction for R = B * samples_per_movie rows (library: cwm_shift_prompts; reference:
         PatchPerturbation.forward + ShiftPatchesAndMask.perturb, perturbation.py:99-113, 245-289).  x [B,T,C,H,W]; passive /
         active [R,Nt] bool (0 = patch stays visible / 0 = patch is moved); shifts int32 [R,2] (dy,dx) in patch units.
@@ -438,8 +438,14 @@ class PredictorBasedGenerator(nn.Module):
             raise RuntimeError("counterfactual prompts are built on the GPU (no CPU fallback); got a %s tensor" % x.device)
         dev = x.device
         B, T, Cc, H, W = x.shape
+        if num_frames is not None and num_frames != T:
+            # a static movie given as its first frame alone (`make_static_movie`, prediction.py:731-739, is frame 0 repeated): with fix_passive=True the kernel
+            # reads frame 0 for every output frame, so the T-fold copy need not exist
+            if not (T == 1 and fix_passive is True):
+                raise RuntimeError("num_frames=%d needs a one-frame movie and fix_passive=True" % num_frames)
+            T = int(num_frames)
         R, N = passive.shape
-        x = x.to(torch.float32).contiguous()
+        x = x.to(torch.float32).contiguous() if frames else None  # (masks only: the frames are not read; no 1.2-MB materialisation of an expanded movie on rank 0's path)
         passive = passive.to(device=dev, dtype=torch.bool).contiguous()
         active = active.to(device=dev, dtype=torch.bool).contiguous()
         shifts = shifts.to(device=dev, dtype=torch.int32).contiguous()
@@ -447,7 +453,7 @@ class PredictorBasedGenerator(nn.Module):
         mask_shift = torch.empty((R, N), device=dev, dtype=torch.bool) if masks else None
         with torch.cuda.device(dev):
             _lib.check(_lib.get_lib().cwm_shift_prompts(
-                x.data_ptr(), B, T, Cc, H, W, self.patch_size[-1], frame % T, samples_per_movie,
+                _lib.ptr(x), B, T, Cc, H, W, self.patch_size[-1], frame % T, samples_per_movie,
                 2 if fix_passive == "make_static" else int(bool(fix_passive)),
                 active.data_ptr(), passive.data_ptr(), shifts.data_ptr(), _lib.ptr(x_shift), _lib.ptr(mask_shift),
                 _lib.current_stream_handle(dev)))

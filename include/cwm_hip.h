@@ -241,6 +241,12 @@ CWM_API int cwm_mask_flip_picks(uint8_t* mask_dev, int B, int Nt, const int32_t*
  *           outputs x_out [B*S,T,C,H,W], mask_out [B*S,Nt]; either one may be NULL (masks only: what rank 0 of the sharded loop needs
  *           for all prompts before the rectangulariser; frames only: the rows a rank predicts -- x_dev may be NULL with x_out_dev).
  *           Asynchronous on `stream`. */
+/* The prompt table of a counterfactual batch -> the dense operands of cwm_shift_prompts, in one launch (no counterpart in the reference, which builds the
+ * masks prompt by prompt on the host: interface.py:370-377, segmentation.py:324-338).  table_dev int32 [S,4] rows (active_h, active_w, dy, dx): ONE active
+ * patch of frame `frame` (>= 1) per prompt, moved by (dy, dx) patches, nothing passive.  Writes passive [S,Nt] (frame 0 visible, later frames masked),
+ * active [S,Nt] (= passive with the prompt's patch cleared) and shifts [S,2].  Cells outside the grid clear nothing.  Asynchronous on `stream`. */
+CWM_API int cwm_prompt_table_expand(const int32_t* table_dev, int S, int T, int grid_h, int grid_w, int frame, uint8_t* active_dev, uint8_t* passive_dev,
+                            int32_t* shifts_dev, void* stream);
 CWM_API int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, int W, int P, int frame, int S, int fix_passive,
                       const uint8_t* active_dev, const uint8_t* masks_dev, const int32_t* shifts_dev, float* x_out_dev,
                       uint8_t* mask_out_dev, void* stream);

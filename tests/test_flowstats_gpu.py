@@ -67,6 +67,83 @@ def test_sample_major_layout_and_ragged_sizes_match_oracle():
     assert (out - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("S,H,W", [(24, 28, 36), (64, 20, 28), (128, 12, 20), (256, 16, 12), (512, 8, 12), (100, 10, 14), (1, 9, 7), (700, 6, 6)])
+def test_motion_map_kernel_forms_match_oracle(S, H, W):
+    """`compute_mean_motion_map` picks its kernels by layout and sample count: the register form (S = 64 / 128: 16 / 32 lanes per pixel; S a multiple of 256: whole-wave
+    16-byte loads), the LDS-tile form (any other S of the packed [B, C, H, W, S] layout), the strided form (sample-major views, rows too long for the tile).  Every
+    form, with and without the per-sample range normalisation, against the oracle's restatement of segmentation.py:250-276; pixel counts that do not fill the last
+    workgroup; two movies; three channels."""
+    g = torch.Generator().manual_seed(100 + S)
+    for C_ in (2, 3):
+        fl = torch.randn(2, C_, H, W, S, generator=g) * 1.5
+        dev = fl.cuda()
+        for nps in (False, True):
+            for nm in (False, True):
+                out = FS.compute_mean_motion_map(dev, normalize_per_sample=nps, normalize=nm).cpu()
+                ref = FO.compute_mean_motion_map(fl, normalize_per_sample=nps, normalize=nm)
+                tol = max(TOL, 4e-8 * S)   # (an fp32 sum over S samples, in whichever order the kernel form adds them)
+                assert out.shape == ref.shape and (out - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (S, C_, nps, nm)
+        # the same samples as a sample-major strided view (the flow model's output order): the strided kernels
+        sm = fl.permute(0, 4, 1, 2, 3).contiguous().cuda().permute(0, 2, 3, 4, 1)
+        assert S == 1 or not sm.is_contiguous()
+        out = FS.compute_mean_motion_map(sm, normalize_per_sample=True).cpu()
+        assert (out - FO.compute_mean_motion_map(fl, normalize_per_sample=True)).abs().max().item() <= max(TOL, 4e-8 * S)
+
+
+@pytest.mark.parametrize("S", [8, 24, 37, 256])
+def test_pooled_features_vector_and_scalar_forms(S):
+    """`flow_features` (segmentation.py:503-513): the 16-byte form (sample axis innermost, S a multiple of 4) and the strided scalar form against the oracle, for every
+    pooling factor the interface uses; a sample-major view of the same samples takes the scalar form and must agree with the packed layout."""
+    g = torch.Generator().manual_seed(S)
+    fl = torch.randn(2, 2, 16, 24, S, generator=g)
+    sm = fl.permute(0, 4, 1, 2, 3).contiguous().cuda().permute(0, 2, 3, 4, 1)
+    for ds in (1, 2, 4):
+        out = FS.flow_features(fl.cuda(), ds)
+        ref = FO.flow_features(fl, ds)
+        assert out.shape == ref.shape and (out.cpu() - ref).abs().max().item() <= 1e-6
+        assert (FS.flow_features(sm, ds) - out).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("P,S", [(12544, 256), (12544, 24), (300, 70), (113, 5), (1, 8)])
+def test_column_statistics_at_full_size(P, S):
+    """The z-score / normalise / range prologues reduce over the P positions of every sample column: chunked one-pass Welford in float64, merged in a fixed order
+    (flowstats.hip flow_colpartial_kernel).  Against torch in float64 at the bench size (P = 12544: 112 chunks), at sizes that end inside a chunk, and run to run."""
+    g = torch.Generator().manual_seed(P + S)
+    x = (torch.randn(1, P, S, generator=g) * 3 + 1.5).abs()
+    xd = x.cuda()
+    z = FS.transform_features(xd.clone(), zscore=True)
+    assert torch.equal(torch.nan_to_num(z), torch.nan_to_num(FS.transform_features(xd.clone(), zscore=True)))      # deterministic
+    x64 = x[0].double()
+    if P > 1:
+        ref = ((x64 - x64.mean(0)[None]) / x64.std(0).clamp(min=1e-12)[None]).float()
+        assert (z[0].cpu() - ref).abs().max().item() <= 2e-5
+    else:
+        assert torch.isnan(z).all()
+    n = FS.transform_features(xd.clone(), normalize=True)[0].cpu()
+    assert (n - x[0] / x[0].amax(0, True).clamp(min=1e-12)).abs().max().item() <= 1e-6
+    r = FS.transform_features(xd.clone(), range_thresh=0.3)[0].cpu()
+    sh = x[0] - x[0].amin(0, True)
+    assert torch.equal(r, (sh > 0.3 * sh.amax(0, True)).float())
+
+
+@pytest.mark.parametrize("P,S", [(200, 33), (129, 4), (384, 256), (50, 2), (130, 100)])
+def test_symmetric_covariance_tiles_match_torch(P, S):
+    """The whole-matrix call computes the 128 x 128 tiles on and above the diagonal and writes every off-diagonal tile twice (once mirrored): against torch.cov /
+    torch.corrcoef in float64 for sizes with a ragged last tile, one tile, three tile rows, S below / not a multiple of the 32-sample step -- and the row-slab
+    (rectangular-grid) kernel must give the same bits for any slab."""
+    g = torch.Generator().manual_seed(P * 7 + S)
+    x = torch.randn(2, P, S, generator=g).cuda()
+    for use_cov in (True, False):
+        full = FS.feature_cov_rows(x, 0, P, use_cov)
+        for b in range(2):
+            x64 = x[b].double().cpu()
+            ref = (torch.cov(x64) if use_cov else torch.corrcoef(x64)).float()
+            assert (full[b].cpu() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()), (P, S, use_cov)
+        assert torch.equal(full, full.transpose(1, 2))
+        for row0, nrows in ((0, min(P, 7)), (P // 3, P - P // 3), (P - 1, 1)):
+            assert torch.equal(FS.feature_cov_rows(x, row0, nrows, use_cov), full[:, row0:row0 + nrows])
+
+
 def test_option_prologues_match_reference_outputs():
     """compute_flow_corrs with its optional prologues on the device (segmentation.py:519-538; `cwm_flow_transform`): thresh, binarize,
     range_thresh, normalize, zscore and the Spearman argsort, alone and combined, against the reference's own outputs; a strided
