@@ -43,6 +43,8 @@ for wl in flowstats prompt_build; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$wl -- $BENCH > $OUT/pmc_fetch_$wl.log 2>&1 || fail=1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$wl -- $BENCH > $OUT/pmc_write_$wl.log 2>&1 || fail=1
 done
+# the covariance kernel runs on the fp32 matrix pipe: its MFMA-busy share and clock
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma_flowstats -- python3 bench.py --workload flowstats --steps 5 --no-cpu-baseline > $OUT/pmc_mfma_flowstats.log 2>&1 || fail=1
 find $OUT -name "*.csv" | wc -l
 # a Python traceback in any log of the set = the set is not evidence (round 5 committed one as a "per-shape kernel rate" log)
 if grep -l "Traceback (most recent call last)" $OUT/*.log 2>/dev/null; then echo "TRACEBACK in the logs listed above"; fail=1; fi

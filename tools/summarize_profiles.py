@@ -116,10 +116,31 @@ for wl in ("flowstats", "prompt_build"):
     for k, t in kernels.items():
         t["hbm_bytes_per_launch_corrected"] = (2.0 * t.get("FETCH_SIZE_KiB_mean_raw", 0.0) + t.get("WRITE_SIZE_KiB_mean_raw", 0.0)) * 1024.0
         t["hbm_bytes_per_launch_corrected_top_quartile"] = (2.0 * t.get("FETCH_SIZE_KiB_top_quartile_raw", 0.0) + t.get("WRITE_SIZE_KiB_top_quartile_raw", 0.0)) * 1024.0
+    if wl == "flowstats":  # the covariance kernel on the fp32 matrix pipe: busy share and clock per dispatch, split by duration (S = 256 launches vs S = 24 launches)
+        agg, dur = counters("pmc_mfma_flowstats")
+        f = one("pmc_mfma_flowstats/**/*counter_collection.csv")
+        if f:
+            per = collections.defaultdict(dict)
+            for r in csv.DictReader(open(f)):
+                if "flow_cov_kernel" in r["Kernel_Name"]:
+                    per[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+                    per[r["Dispatch_Id"]]["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                    per[r["Dispatch_Id"]]["kernel"] = kname(r["Kernel_Name"])
+            groups = collections.defaultdict(list)
+            for d in per.values():
+                if d.get("GRBM_GUI_ACTIVE"):
+                    cyc = d["GRBM_GUI_ACTIVE"] / 8.0
+                    groups[d["kernel"]].append((d["ns"] / 1e3, cyc / d["ns"], d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * 1024.0), d.get("SQ_WAIT_ANY", 0.0) / max(d.get("SQ_WAVE_CYCLES", 1.0), 1.0)))
+            for k, v in groups.items():
+                t = kernels.setdefault(k, {})
+                n = float(len(v))
+                t.update(dispatches_in_mfma_pass=len(v), avg_us_in_mfma_pass=sum(x[0] for x in v) / n, clock_GHz=sum(x[1] for x in v) / n, mfma_busy=sum(x[2] for x in v) / n,
+                         SQ_WAIT_ANY_share=sum(x[3] for x in v) / n)
     if kernels:
         out["workloads"][wl] = kernels
         latest["entries"]["%s/f32" % wl] = {"tag": tag, "source": "profiles/%s_pmc_summary.json" % tag,
-                                            "hbm_bytes_per_launch": {k: t["hbm_bytes_per_launch_corrected_top_quartile"] for k, t in kernels.items()}, "mfma_busy": {}}
+                                            "hbm_bytes_per_launch": {k: t["hbm_bytes_per_launch_corrected_top_quartile"] for k, t in kernels.items() if "hbm_bytes_per_launch_corrected_top_quartile" in t},
+                                            "mfma_busy": {k: t["mfma_busy"] for k, t in kernels.items() if "mfma_busy" in t}}
 
 for mode in ("fast", "parity"):
     agg, dur = counters("pmc_attn_l4dec_" + mode)
