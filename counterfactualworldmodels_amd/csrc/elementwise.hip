@@ -513,7 +513,10 @@ __global__ __launch_bounds__(256) void unembed3_kernel(const UnembedParams p) {
     for (int k = 0; k < 2; ++k) {
         float* dst = p.out + (((size_t)b * p.T + t) * 3 * p.H + y0 + k * hh) * p.W + x0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(dst + (size_t)c * p.H * p.W) = o[k][c];
+        for (int c = 0; c < 3; ++c) {  // (the predicted video is the call's result: written once, streaming stores)
+            const f32x4 v = f32x4{o[k][c].x, o[k][c].y, o[k][c].z, o[k][c].w};
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (size_t)c * p.H * p.W));
+        }
     }
 }
 

@@ -510,16 +510,18 @@ __global__ void flow_motion_sum_kernel(const float* __restrict__ f, int64_t sb, 
 // ---- the reference layout [B, C, H, W, S] with the sample axis innermost and (H, W, S) packed (sw == S, sh == W S, ss == 1): round 6 -----------------
 // The kernels above give a thread one pixel (or one sample) and let it walk the other axis with a stride: every 4-byte load of a wave sits in a different
 // cache line (S = 256: 388 us for 2 x 103 MB, profiles/r6_bench_flowstats_before.json).  For the packed layout a channel plane is ONE contiguous array of
-// H W S floats: a workgroup takes 64 consecutive pixels = 64 S consecutive floats per channel, loads them with coalesced 4-byte loads (lanes along the
-// sample axis), keeps the magnitudes in LDS [64][S + 1] and then reduces along whichever axis the pass needs:
-//   pass 1 (per-sample range): thread s scans the 64 pixels of its column -> one atomicMin / atomicMax per (workgroup, sample) on the float bits (magnitudes
+// H W S floats: a workgroup takes 64 - 256 consecutive pixels (mag_tile_pix) = that many times S consecutive floats per channel, loads them with coalesced 4-byte loads
+// (lanes along the sample axis), keeps the magnitudes in LDS [pixels][S + 1] and then reduces along whichever axis the pass needs:
+//   pass 1 (per-sample range): thread s scans the pixels of its column -> one atomicMin / atomicMax per (workgroup, sample) on the float bits (magnitudes
 //          are >= 0, where unsigned order = float order; min starts at 0xFFFFFFFF, max at 0);
 //   pass 2 (the sum over the samples): thread p walks the S samples of its pixel IN SAMPLE ORDER -- the same additions in the same order as the strided kernel
 //          above (bit-identical to it).
-constexpr int kMagPix = 64;
+// pixels per workgroup: 256 for S <= 32, 128 for S <= 64, else 64 (mag_tile_pix): the tile stays <= 34 KB, and at S = 24 a quarter as many workgroups hit the S range
+// atomics (784 workgroups x 24 samples on 48 addresses were the whole 24-us launch)
+static inline int mag_tile_pix(int S) { return S <= 32 ? 256 : S <= 64 ? 128 : 64; }
 
-__device__ __forceinline__ void mag_tile_to_lds(const float* __restrict__ f, int64_t sb, int64_t sc, int b, int C, int HW, int S, int pix0, float* mag) {
-    const int npix = min(kMagPix, HW - pix0);
+__device__ __forceinline__ void mag_tile_to_lds(const float* __restrict__ f, int64_t sb, int64_t sc, int b, int C, int HW, int S, int pix0, int tile_pix, float* mag) {
+    const int npix = min(tile_pix, HW - pix0);
     const int n = npix * S;
     const float* fb = f + b * sb + (int64_t)pix0 * S;
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
@@ -533,13 +535,13 @@ __device__ __forceinline__ void mag_tile_to_lds(const float* __restrict__ f, int
     }
 }
 
-__global__ __launch_bounds__(256) void flow_mag_minmax_packed_kernel(const float* __restrict__ f, int64_t sb, int64_t sc, int C, int HW, int S,
+__global__ __launch_bounds__(256) void flow_mag_minmax_packed_kernel(const float* __restrict__ f, int64_t sb, int64_t sc, int C, int HW, int S, int tile_pix,
                                                                      unsigned* __restrict__ mn_bits, unsigned* __restrict__ mx_bits) {
-    extern __shared__ float mag[];  // [64][S + 1]
-    const int b = blockIdx.y, pix0 = blockIdx.x * kMagPix;
-    mag_tile_to_lds(f, sb, sc, b, C, HW, S, pix0, mag);
+    extern __shared__ float mag[];  // [tile_pix][S + 1]
+    const int b = blockIdx.y, pix0 = blockIdx.x * tile_pix;
+    mag_tile_to_lds(f, sb, sc, b, C, HW, S, pix0, tile_pix, mag);
     __syncthreads();
-    const int npix = min(kMagPix, HW - pix0);
+    const int npix = min(tile_pix, HW - pix0);
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
         float mn = INFINITY, mx = -INFINITY;
         for (int pl = 0; pl < npix; ++pl) {
@@ -552,14 +554,14 @@ __global__ __launch_bounds__(256) void flow_mag_minmax_packed_kernel(const float
     }
 }
 
-__global__ __launch_bounds__(256) void flow_motion_sum_packed_kernel(const float* __restrict__ f, int64_t sb, int64_t sc, int C, int HW, int S,
+__global__ __launch_bounds__(256) void flow_motion_sum_packed_kernel(const float* __restrict__ f, int64_t sb, int64_t sc, int C, int HW, int S, int tile_pix,
                                                                      const unsigned* __restrict__ mn_bits, const unsigned* __restrict__ mx_bits, float eps,
                                                                      float* __restrict__ sum) {
-    extern __shared__ float mag[];  // [64][S + 1]
-    const int b = blockIdx.y, pix0 = blockIdx.x * kMagPix;
-    mag_tile_to_lds(f, sb, sc, b, C, HW, S, pix0, mag);
+    extern __shared__ float mag[];  // [tile_pix][S + 1]
+    const int b = blockIdx.y, pix0 = blockIdx.x * tile_pix;
+    mag_tile_to_lds(f, sb, sc, b, C, HW, S, pix0, tile_pix, mag);
     __syncthreads();
-    const int npix = min(kMagPix, HW - pix0);
+    const int npix = min(tile_pix, HW - pix0);
     if ((int)threadIdx.x >= npix) return;
     const float* row = mag + threadIdx.x * (S + 1);
     float acc = 0.f;
@@ -862,7 +864,8 @@ extern "C" int cwm_flow_motion_sum(const float* flows_dev, const int64_t* stride
     CWM_REQUIRE(!normalize_per_sample || minmax_work_dev, "cwm_flow_motion_sum: per-sample normalisation needs the [B][S][2] work buffer");
     hipStream_t s = (hipStream_t)stream;
     // the reference's layout (sample axis innermost, (H, W, S) packed): the coalesced kernels; any other strides: the strided ones
-    const size_t smem = (size_t)kMagPix * (S + 1) * sizeof(float);
+    const int tile_pix = mag_tile_pix(S);
+    const size_t smem = (size_t)tile_pix * (S + 1) * sizeof(float);
     const bool packed = strides[4] == 1 && strides[3] == S && strides[2] == (int64_t)W * S;
     const int q = S == 64 ? 16 : S == 128 ? 32 : (S % 256 == 0 ? 64 : 0);  // lanes per pixel of the register form (0: the LDS-tile form)
     if (packed && q && strides[0] % 4 == 0 && strides[1] % 4 == 0 && ((uintptr_t)flows_dev & 15) == 0 && (!normalize_per_sample || ((uintptr_t)minmax_work_dev & 15) == 0)) {
@@ -886,7 +889,7 @@ extern "C" int cwm_flow_motion_sum(const float* flows_dev, const int64_t* stride
     }
     if (packed && smem <= 150 * 1024) {
         const int HW = H * W;
-        const dim3 grid((unsigned)((HW + kMagPix - 1) / kMagPix), (unsigned)B);
+        const dim3 grid((unsigned)((HW + tile_pix - 1) / tile_pix), (unsigned)B);
         unsigned *mn = nullptr, *mx = nullptr;
         if (smem > 48 * 1024) {
             if (int rc = cwm_set_max_lds((const void*)flow_mag_minmax_packed_kernel, (int)smem)) return rc;
@@ -897,9 +900,9 @@ extern "C" int cwm_flow_motion_sum(const float* flows_dev, const int64_t* stride
             mx = mn + (size_t)B * S;
             CWM_HIP_CHECK(hipMemsetAsync(mn, 0xFF, (size_t)B * S * sizeof(unsigned), s));
             CWM_HIP_CHECK(hipMemsetAsync(mx, 0x00, (size_t)B * S * sizeof(unsigned), s));
-            hipLaunchKernelGGL(flow_mag_minmax_packed_kernel, grid, dim3(256), smem, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx);
+            hipLaunchKernelGGL(flow_mag_minmax_packed_kernel, grid, dim3(256), smem, s, flows_dev, strides[0], strides[1], C, HW, S, tile_pix, mn, mx);
         }
-        hipLaunchKernelGGL(flow_motion_sum_packed_kernel, grid, dim3(256), smem, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx, eps, sum_dev);
+        hipLaunchKernelGGL(flow_motion_sum_packed_kernel, grid, dim3(256), smem, s, flows_dev, strides[0], strides[1], C, HW, S, tile_pix, mn, mx, eps, sum_dev);
         CWM_HIP_CHECK(hipGetLastError());
         return 0;
     }
