@@ -177,6 +177,7 @@ SIGNATURES = {
     "cwm_flow_cov": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 4),
     "cwm_flow_transform_work_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "cwm_flow_transform": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "cwm_flow_motion_work_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "cwm_flow_motion_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)] + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cwm_flow_map_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "cwm_comm_load": (C.c_int, [C.c_char_p]),

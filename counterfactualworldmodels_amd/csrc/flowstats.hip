@@ -516,6 +516,11 @@ __global__ void flow_motion_sum_kernel(const float* __restrict__ f, int64_t sb, 
 //          are >= 0, where unsigned order = float order; min starts at 0xFFFFFFFF, max at 0);
 //   pass 2 (the sum over the samples): thread p walks the S samples of its pixel IN SAMPLE ORDER -- the same additions in the same order as the strided kernel
 //          above (bit-identical to it).
+// The per-sample range is reduced with atomicMin / atomicMax on the float bits.  Every workgroup of a pass hits the same S addresses: 784 workgroups on 512 (or 48)
+// addresses serialise at L2 (S = 24: 19.6 us of a 9.8-MB pass was the queue of 196 atomics per address).  So there are kRangeReplicas copies of the [B][S] arrays,
+// workgroup g uses copy g mod kRangeReplicas, and the consumers fold the copies (min / max are exact in any order).
+constexpr int kRangeReplicas = 8;
+
 // pixels per workgroup: 256 for S <= 32, 128 for S <= 64, else 64 (mag_tile_pix): the tile stays <= 34 KB, and at S = 24 a quarter as many workgroups hit the S range
 // atomics (784 workgroups x 24 samples on 48 addresses were the whole 24-us launch)
 static inline int mag_tile_pix(int S) { return S <= 32 ? 256 : S <= 64 ? 128 : 64; }
@@ -549,8 +554,9 @@ __global__ __launch_bounds__(256) void flow_mag_minmax_packed_kernel(const float
             mn = fminf(mn, m);
             mx = fmaxf(mx, m);
         }
-        if (mn == mn && mn != INFINITY) atomicMin(&mn_bits[(size_t)b * S + s], __float_as_uint(mn));
-        if (mx == mx && mx != -INFINITY) atomicMax(&mx_bits[(size_t)b * S + s], __float_as_uint(mx));
+        const size_t rep = (size_t)(blockIdx.x % kRangeReplicas) * gridDim.y * S;
+        if (mn == mn && mn != INFINITY) atomicMin(&mn_bits[rep + (size_t)b * S + s], __float_as_uint(mn));
+        if (mx == mx && mx != -INFINITY) atomicMax(&mx_bits[rep + (size_t)b * S + s], __float_as_uint(mx));
     }
 }
 
@@ -560,6 +566,19 @@ __global__ __launch_bounds__(256) void flow_motion_sum_packed_kernel(const float
     extern __shared__ float mag[];  // [tile_pix][S + 1]
     const int b = blockIdx.y, pix0 = blockIdx.x * tile_pix;
     mag_tile_to_lds(f, sb, sc, b, C, HW, S, pix0, tile_pix, mag);
+    float* lo_s = mag + (size_t)tile_pix * (S + 1);  // [S] range start, [S] range length: folded from the replicas once per workgroup
+    float* len_s = lo_s + S;
+    if (mn_bits)
+        for (int s = threadIdx.x; s < S; s += blockDim.x) {
+            unsigned l = 0xFFFFFFFFu, h = 0u;
+            for (int r = 0; r < kRangeReplicas; ++r) {
+                l = min(l, mn_bits[((size_t)r * gridDim.y + b) * S + s]);
+                h = max(h, mx_bits[((size_t)r * gridDim.y + b) * S + s]);
+            }
+            const float lo = __uint_as_float(l);
+            lo_s[s] = lo;
+            len_s[s] = fmaxf(__uint_as_float(h) - lo, eps);
+        }
     __syncthreads();
     const int npix = min(tile_pix, HW - pix0);
     if ((int)threadIdx.x >= npix) return;
@@ -567,10 +586,7 @@ __global__ __launch_bounds__(256) void flow_motion_sum_packed_kernel(const float
     float acc = 0.f;
     for (int s = 0; s < S; ++s) {
         float m = row[s];
-        if (mn_bits) {
-            const float lo = __uint_as_float(mn_bits[(size_t)b * S + s]), hi = __uint_as_float(mx_bits[(size_t)b * S + s]);
-            m = (m - lo) / fmaxf(hi - lo, eps);
-        }
+        if (mn_bits) m = (m - lo_s[s]) / len_s[s];
         acc += m;
     }
     sum[(size_t)b * HW + pix0 + threadIdx.x] = acc;
@@ -638,8 +654,9 @@ __global__ __launch_bounds__(256) void flow_mag_minmax_rows_kernel(const float* 
         for (int s = threadIdx.x; s < ns; s += 256) {
             const float lo = fminf(fminf(red_mn[0][s], red_mn[1][s]), fminf(red_mn[2][s], red_mn[3][s]));
             const float hi = fmaxf(fmaxf(red_mx[0][s], red_mx[1][s]), fmaxf(red_mx[2][s], red_mx[3][s]));
-            if (lo != INFINITY) atomicMin(&mn_bits[(size_t)b * S + ch * 256 + s], __float_as_uint(lo));
-            if (hi != -INFINITY) atomicMax(&mx_bits[(size_t)b * S + ch * 256 + s], __float_as_uint(hi));
+            const size_t rep = (size_t)(blockIdx.x % kRangeReplicas) * gridDim.y * S;
+            if (lo != INFINITY) atomicMin(&mn_bits[rep + (size_t)b * S + ch * 256 + s], __float_as_uint(lo));
+            if (hi != -INFINITY) atomicMax(&mx_bits[rep + (size_t)b * S + ch * 256 + s], __float_as_uint(hi));
         }
         __syncthreads();
     }
@@ -659,7 +676,16 @@ __global__ __launch_bounds__(256) void flow_motion_sum_rows_kernel(const float* 
         lo = f32x4{0.f, 0.f, 0.f, 0.f};
         range = f32x4{1.f, 1.f, 1.f, 1.f};
         if (mn_bits) {
-            const u32x4 l = *reinterpret_cast<const u32x4*>(mn_bits + (size_t)b * S + ch * 256 + s4), h = *reinterpret_cast<const u32x4*>(mx_bits + (size_t)b * S + ch * 256 + s4);
+            u32x4 l = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, h = u32x4{0u, 0u, 0u, 0u};
+            for (int rep = 0; rep < kRangeReplicas; ++rep) {
+                const size_t o = ((size_t)rep * gridDim.y + b) * S + ch * 256 + s4;
+                const u32x4 l2 = *reinterpret_cast<const u32x4*>(mn_bits + o), h2 = *reinterpret_cast<const u32x4*>(mx_bits + o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    l[r] = min(l[r], l2[r]);
+                    h[r] = max(h[r], h2[r]);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 lo[r] = __uint_as_float(l[r]);
@@ -858,51 +884,57 @@ extern "C" size_t cwm_flow_transform_work_bytes(int B, int P, int S) {
     return (size_t)16 * B * S + sizeof(ColPartial) * (size_t)B * n_chunks * S;
 }
 
+extern "C" size_t cwm_flow_motion_work_bytes(int B, int S) {
+    if (B <= 0 || S <= 0) return 0;
+    return (size_t)2 * kRangeReplicas * B * S * sizeof(float);
+}
+
 extern "C" int cwm_flow_motion_sum(const float* flows_dev, const int64_t* strides, int B, int C, int H, int W, int S, int normalize_per_sample,
                                    float eps, float* minmax_work_dev, float* sum_dev, void* stream) {
     CWM_REQUIRE(flows_dev && strides && sum_dev && B > 0 && C > 0 && H > 0 && W > 0 && S > 0, "cwm_flow_motion_sum: bad argument");
-    CWM_REQUIRE(!normalize_per_sample || minmax_work_dev, "cwm_flow_motion_sum: per-sample normalisation needs the [B][S][2] work buffer");
+    CWM_REQUIRE(!normalize_per_sample || minmax_work_dev, "cwm_flow_motion_sum: per-sample normalisation needs the work buffer (cwm_flow_motion_work_bytes)");
     hipStream_t s = (hipStream_t)stream;
     // the reference's layout (sample axis innermost, (H, W, S) packed): the coalesced kernels; any other strides: the strided ones
-    const int tile_pix = mag_tile_pix(S);
-    const size_t smem = (size_t)tile_pix * (S + 1) * sizeof(float);
+    const int tile_mm = mag_tile_pix(S), tile_sum = 64;  // (the range pass wants few workgroups -- fewer atomics --, the sum pass many)
+    const size_t smem_mm = (size_t)tile_mm * (S + 1) * sizeof(float);
+    const size_t smem_sum = ((size_t)tile_sum * (S + 1) + 2 * (size_t)S) * sizeof(float);
     const bool packed = strides[4] == 1 && strides[3] == S && strides[2] == (int64_t)W * S;
     const int q = S == 64 ? 16 : S == 128 ? 32 : (S % 256 == 0 ? 64 : 0);  // lanes per pixel of the register form (0: the LDS-tile form)
-    if (packed && q && strides[0] % 4 == 0 && strides[1] % 4 == 0 && ((uintptr_t)flows_dev & 15) == 0 && (!normalize_per_sample || ((uintptr_t)minmax_work_dev & 15) == 0)) {
+    const bool rows_form = packed && q && strides[0] % 4 == 0 && strides[1] % 4 == 0 && ((uintptr_t)flows_dev & 15) == 0 &&
+                           (!normalize_per_sample || ((uintptr_t)minmax_work_dev & 15) == 0);
+    const bool tile_form = !rows_form && packed && smem_mm <= 150 * 1024 && smem_sum <= 150 * 1024;
+    if (rows_form || tile_form) {
         const int HW = H * W;
-        const dim3 grid((unsigned)((HW + 4 * kRowPixPerWave - 1) / (4 * kRowPixPerWave)), (unsigned)B);
+        // work buffer (cwm_flow_motion_work_bytes): kRangeReplicas x [B][S] min bits, then as many max bits
         unsigned *mn = nullptr, *mx = nullptr;
-        if (normalize_per_sample) {  // work buffer [B][S][2] floats used as [B][S] min bits | [B][S] max bits
+        if (normalize_per_sample) {
+            const size_t n = (size_t)kRangeReplicas * B * S;
             mn = reinterpret_cast<unsigned*>(minmax_work_dev);
-            mx = mn + (size_t)B * S;
-            CWM_HIP_CHECK(hipMemsetAsync(mn, 0xFF, (size_t)B * S * sizeof(unsigned), s));
-            CWM_HIP_CHECK(hipMemsetAsync(mx, 0x00, (size_t)B * S * sizeof(unsigned), s));
-            if (q == 16) hipLaunchKernelGGL(flow_mag_minmax_rows_kernel<16>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx);
-            else if (q == 32) hipLaunchKernelGGL(flow_mag_minmax_rows_kernel<32>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx);
-            else hipLaunchKernelGGL(flow_mag_minmax_rows_kernel<64>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx);
+            mx = mn + n;
+            CWM_HIP_CHECK(hipMemsetAsync(mn, 0xFF, n * sizeof(unsigned), s));
+            CWM_HIP_CHECK(hipMemsetAsync(mx, 0x00, n * sizeof(unsigned), s));
         }
-        if (q == 16) hipLaunchKernelGGL(flow_motion_sum_rows_kernel<16>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx, eps, sum_dev);
-        else if (q == 32) hipLaunchKernelGGL(flow_motion_sum_rows_kernel<32>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx, eps, sum_dev);
-        else hipLaunchKernelGGL(flow_motion_sum_rows_kernel<64>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx, eps, sum_dev);
-        CWM_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
-    if (packed && smem <= 150 * 1024) {
-        const int HW = H * W;
-        const dim3 grid((unsigned)((HW + tile_pix - 1) / tile_pix), (unsigned)B);
-        unsigned *mn = nullptr, *mx = nullptr;
-        if (smem > 48 * 1024) {
-            if (int rc = cwm_set_max_lds((const void*)flow_mag_minmax_packed_kernel, (int)smem)) return rc;
-            if (int rc = cwm_set_max_lds((const void*)flow_motion_sum_packed_kernel, (int)smem)) return rc;
+        if (rows_form) {
+            const dim3 grid((unsigned)((HW + 4 * kRowPixPerWave - 1) / (4 * kRowPixPerWave)), (unsigned)B);
+            if (normalize_per_sample) {
+                if (q == 16) hipLaunchKernelGGL(flow_mag_minmax_rows_kernel<16>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx);
+                else if (q == 32) hipLaunchKernelGGL(flow_mag_minmax_rows_kernel<32>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx);
+                else hipLaunchKernelGGL(flow_mag_minmax_rows_kernel<64>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx);
+            }
+            if (q == 16) hipLaunchKernelGGL(flow_motion_sum_rows_kernel<16>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx, eps, sum_dev);
+            else if (q == 32) hipLaunchKernelGGL(flow_motion_sum_rows_kernel<32>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx, eps, sum_dev);
+            else hipLaunchKernelGGL(flow_motion_sum_rows_kernel<64>, grid, dim3(256), 0, s, flows_dev, strides[0], strides[1], C, HW, S, mn, mx, eps, sum_dev);
+        } else {
+            if (smem_mm > 48 * 1024)
+                if (int rc = cwm_set_max_lds((const void*)flow_mag_minmax_packed_kernel, (int)smem_mm)) return rc;
+            if (smem_sum > 48 * 1024)
+                if (int rc = cwm_set_max_lds((const void*)flow_motion_sum_packed_kernel, (int)smem_sum)) return rc;
+            if (normalize_per_sample)
+                hipLaunchKernelGGL(flow_mag_minmax_packed_kernel, dim3((unsigned)((HW + tile_mm - 1) / tile_mm), (unsigned)B), dim3(256), smem_mm, s, flows_dev, strides[0],
+                                   strides[1], C, HW, S, tile_mm, mn, mx);
+            hipLaunchKernelGGL(flow_motion_sum_packed_kernel, dim3((unsigned)((HW + tile_sum - 1) / tile_sum), (unsigned)B), dim3(256), smem_sum, s, flows_dev, strides[0],
+                               strides[1], C, HW, S, tile_sum, mn, mx, eps, sum_dev);
         }
-        if (normalize_per_sample) {  // work buffer [B][S][2] floats used as [B][S] min bits | [B][S] max bits
-            mn = reinterpret_cast<unsigned*>(minmax_work_dev);
-            mx = mn + (size_t)B * S;
-            CWM_HIP_CHECK(hipMemsetAsync(mn, 0xFF, (size_t)B * S * sizeof(unsigned), s));
-            CWM_HIP_CHECK(hipMemsetAsync(mx, 0x00, (size_t)B * S * sizeof(unsigned), s));
-            hipLaunchKernelGGL(flow_mag_minmax_packed_kernel, grid, dim3(256), smem, s, flows_dev, strides[0], strides[1], C, HW, S, tile_pix, mn, mx);
-        }
-        hipLaunchKernelGGL(flow_motion_sum_packed_kernel, grid, dim3(256), smem, s, flows_dev, strides[0], strides[1], C, HW, S, tile_pix, mn, mx, eps, sum_dev);
         CWM_HIP_CHECK(hipGetLastError());
         return 0;
     }

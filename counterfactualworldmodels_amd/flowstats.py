@@ -149,7 +149,7 @@ def motion_map_sum(flows: torch.Tensor, normalize_per_sample: bool = False, eps:
     flows, strides = _strides5(flows)
     B, Cc, H, W, S = flows.shape
     out = torch.empty((B, 1, H, W), device=flows.device, dtype=torch.float32)
-    mm = torch.empty((B, S, 2), device=flows.device, dtype=torch.float32) if normalize_per_sample else None
+    mm = torch.empty(int(_lib.get_lib().cwm_flow_motion_work_bytes(B, S)), device=flows.device, dtype=torch.uint8) if normalize_per_sample else None
     with torch.cuda.device(flows.device):
         _lib.check(_lib.get_lib().cwm_flow_motion_sum(flows.data_ptr(), strides, B, Cc, H, W, S, int(bool(normalize_per_sample)), float(eps),
                                                      _lib.ptr(mm), out.data_ptr(), _lib.current_stream_handle(flows.device)))

@@ -263,7 +263,7 @@ CWM_API int cwm_shift_prompts(const float* x_dev, int B, int T, int C, int H, in
  *                     over the S samples, NaN -> 0.  replaces: segmentation.py:538-546.  Work buffers: xc [B][P][S], inv_std [B][P].
  *                     Row slabs let ranks that all-gathered `x` each produce a part of the [P,P] matrix (dist.py).
  * cwm_flow_motion_sum sum[B][H*W] = sum_s |flow| (magnitude over channels), each sample first range-normalised over (H,W)
- *                     with max(range, eps) if normalize_per_sample (work buffer minmax [B][S][2]).
+ *                     with max(range, eps) if normalize_per_sample (work buffer: cwm_flow_motion_work_bytes(B, S) bytes, 16-byte aligned).
  *                     replaces: compute_flow_samples_magnitude + the `.mean(-1)` numerator (segmentation.py:250-255, :264-268)
  * cwm_flow_map_finish map = map*scale (scale = 1/S_total), then (map - min)/max(max - min, eps) per b if normalize.
  *                     replaces: segmentation.py:273-275.  Split from the sum so that sample shards can be all-reduced in between. */
@@ -280,6 +280,7 @@ CWM_API int cwm_flow_transform(float* x_dev, int B, int P, int S, int spearman, 
                        float* stats_work_dev, void* stream);
 CWM_API int cwm_flow_cov(const float* x_dev, int B, int P, int S, int row0, int nrows, int use_covariance, float* xc_work_dev,
                  float* inv_std_work_dev, float* out_dev, void* stream);
+CWM_API size_t cwm_flow_motion_work_bytes(int B, int S);
 CWM_API int cwm_flow_motion_sum(const float* flows_dev, const int64_t* strides, int B, int C, int H, int W, int S,
                         int normalize_per_sample, float eps, float* minmax_work_dev, float* sum_dev, void* stream);
 CWM_API int cwm_flow_map_finish(float* map_dev, int B, int HW, float scale, int normalize, float eps, void* stream);

@@ -24,8 +24,9 @@ WORKLOADS = ("base8", "large4", "imu4")
 
 
 def one(pattern):
+    """The NEWEST match: a second collection into the same tag leaves the first one's files (other process ids) beside its own."""
     f = glob.glob(os.path.join(src, pattern), recursive=True)
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None
 
 
 def kname(raw):
