@@ -44,7 +44,7 @@ int cwm_require_device(int handle_device, const char* what) {
                 handle_device, cur, handle_device);
     return 0;
 }
-extern "C" const char* cwm_version(void) { return "cwm_hip 0.6.0 gfx950"; }
+extern "C" const char* cwm_version(void) { return "cwm_hip 0.7.0 gfx950"; }
 #ifndef CWM_SRC_HASH
 #define CWM_SRC_HASH "unknown"
 #endif

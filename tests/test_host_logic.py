@@ -291,3 +291,24 @@ def test_counted_vmcnt_waits_match_the_lds_dma_the_compiler_emitted():
     rec = build.lint_record()
     assert rec.get("hipcc") == build.hipcc_version(), "csrc/LINT_PASSED.json names another compiler: %r" % rec.get("hipcc")
     assert build.check_lint_record(verbose=False)
+
+
+def test_option_keys_of_the_host_mirror_match_the_library_table():
+    """`_lib.OPTION_KEYS` (what `model.set_option` accepts before a handle exists) must be the key table of `tuning_field` in csrc/engine.hip, and the timing-only
+    `gemm_debug` bits the host refuses must be the ones `tuning_set_production` refuses: a key added on one side only would either be rejected by the mirror or
+    poison a later handle creation."""
+    import re
+
+    from counterfactualworldmodels_amd import _lib, build
+
+    src = open(os.path.join(build.CSRC, "engine.hip")).read()
+    table = src[src.index("static const Field fields[] = {"):src.index("for (const Field& f : fields)")]
+    keys = re.findall(r'\{"([a-z_]+)", &Tuning::', table)
+    assert keys and sorted(keys) == sorted(_lib.OPTION_KEYS)
+    m = re.search(r'strcmp\(key, "gemm_debug"\) && \(value & \(([0-9 |]+)\)\)', src)
+    assert m and eval(m.group(1)) == _lib.GEMM_DEBUG_TIMING_ONLY
+    _lib.validate_option("attn_kernel", 3)
+    for bad in (("no_such_option", 1), ("gemm_debug", 8), ("gemm_debug", 32 | 2)):
+        with pytest.raises(_lib.CwmHipError):
+            _lib.validate_option(*bad)
+    _lib.validate_option("gemm_debug", 32 | 1024)
