@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void index_gather_kernel(const PatchGatherPara
     const int L = p.perm_stride ? p.perm_stride : p.Nt;  // mask row length (padded predictors: real tokens + pad slots)
     const uint8_t* m = mask + (size_t)b * L;
     // perm / rank of the sample are written by ALL of its workgroups (every one has the whole scan anyway): thread slice t belongs to workgroup t mod nw.
-    // Until round 5 workgroup 0 wrote all L entries alone: 25 dependent rounds of scattered 4-byte stores on the critical path of a 34-us launch.
+    // Until round 5 workgroup 0 wrote all L entries alone: 25 dependent rounds of scattered 4-byte stores on the critical path of the launch.
     const int nw = min((int)gridDim.x, 256);
     const bool writer = (t % nw) == (int)blockIdx.x;
     int* pr = perm_out + (size_t)b * L;
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) void index_gather_kernel(const PatchGatherPara
     int total_vis;
     if ((L & 15) == 0 && L <= 256 * 32 && ((uintptr_t)mask & 15) == 0) {
         // Round 6: the thread's slice of the mask row -- 16 or 32 consecutive bytes -- comes in with one or two 16-byte loads and STAYS in registers for the
-        // second pass.  (Round 5: (L + 255) / 256 = 25 single-byte loads per thread at a 25-byte lane stride, twice; on the long rows of ViT-L/4 and the IMU model
-        // -- L = 6272 / 6336 -- that scan, repeated by each of the sample's ~150 workgroups, was the launch: 34 / 51 us for 10 - 19 MB.)
+        // second pass.  (Round 5: (L + 255) / 256 = 25 single-byte loads per thread at a 25-byte lane stride, twice; on the long rows of ViT-L/4
+        // -- L = 6272 -- that scan, repeated by each of the sample's ~150 workgroups, was most of the launch: 27 - 34 us for 10 MB, now 20 - 23.)
         const int per = L <= 256 * 16 ? 16 : 32;
         const int lo = t * per;
         u32x4 w0 = u32x4{0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u}, w1 = w0;  // (past the row: "masked", never counted)

@@ -4,6 +4,7 @@ TAG=${1:-r6}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1; tail -1 $OUT/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_base8.json 2> $OUT/bench_base8.err
 timeout 600 python bench.py --steps 20 --warmup 5 --lanes 1 --no-cpu-baseline --no-prompts > $OUT/bench_base8_lanes1.json 2>/dev/null
 timeout 600 python bench.py --workload large4 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_large4.json 2> $OUT/bench_large4.err
