@@ -209,7 +209,26 @@ def prompts_measure(args, rank, local_rank, world, distributed, model=None, step
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
     n_gpus = world if distributed else 1
+    # N > 1: the gathered result must be the same on every rank and equal, bit for bit, to the single-process result of the same prompts under the same torch
+    # seed (the rectangulariser's draws happen on rank 0 either way; every predictor call covers the same 32 consecutive prompts in both runs)
+    check = None
+    if distributed:
+        torch.manual_seed(4321)
+        y_sh = step()
+        mine = [float(y_sh.double().sum()), float(y_sh[::37].double().abs().sum())]
+        sums = [None] * world
+        dist.all_gather_object(sums, mine)
+        check = {"same_on_all_ranks": bool(all(v == sums[0] for v in sums))}
+        if rank == 0:
+            torch.manual_seed(4321)
+            y_ref = cdist.sharded_counterfactual_predictions(x0, table, *hooks, dev, chunk=PROMPTS["chunk"], gather=True, comm=cdist.LocalComm())
+            check["equals_single_process"] = bool(torch.equal(y_sh, y_ref))
+            check["max_abs_diff"] = float((y_sh - y_ref).abs().max())
+            del y_ref
+        del y_sh
+        dist.barrier()
     return {
+        "sharded_result_check": check,
         "per_rank_ms": per_rank,
         "metric": "predicted frames/sec (2x224x224, ViT-B/8)", "value": PROMPTS["total"] * steps / dt, "unit": "frames/s",
         "n_gpus": n_gpus, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
@@ -764,7 +783,7 @@ def main():
     if args.workload == "base8" and not args.no_prompts:
         try:
             pm = prompts_measure(args, rank, local_rank, world, distributed, model=model, steps=max(3, args.steps // 4), warmup=2)
-            out["prompts256"] = {k: pm[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "steps", "per_rank_ms")}
+            out["prompts256"] = {k: pm[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "steps", "per_rank_ms", "sharded_result_check")}
             out["prompts256"]["config"] = pm["config"]
             out["rccl_ranks"], out["collectives"] = pm["config"]["comm_world"], pm["config"]["collectives"]
         except Exception as e:  # noqa: BLE001
