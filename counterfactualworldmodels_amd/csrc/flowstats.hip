@@ -106,44 +106,48 @@ constexpr int kCovEpiPitch = 68;
 // between consecutive loads -- the zeroing writes the load's own destination registers --: eight serialised L2 round trips per K step and the matrix pipe 47 % busy,
 // profiles/r6_pmc_flow_cov_before.txt.)
 template <bool VEC, bool FULL>
-__device__ __forceinline__ void cov_load_step(const float* __restrict__ xb, int P, int S, int r0, int k0, int tid, f32x4 (&v)[4]) {
+__device__ __forceinline__ unsigned cov_load_step(const float* __restrict__ xb, int P, int S, int r0, int k0, int tid, f32x4 (&v)[4]) {
+    unsigned valid = 0xFu;  // bit n: load n is in range (VEC, not FULL: applied when the step is stored to LDS -- see cov_store_step)
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int e = tid + 256 * n, r = e >> 3, k = k0 + (e & 7) * 4;
         const int row = r0 + r;
         if constexpr (FULL && VEC) {
             v[n] = *reinterpret_cast<const f32x4*>(xb + (size_t)row * S + k);
+        } else if constexpr (VEC) {
+            // an UNCONDITIONAL load from a clamped address; whether the element counts is decided later.  (Zeroing the destination right here makes hipcc wait for
+            // the load -- `vmcnt(0)` between consecutive loads, 16 serialised L2 round trips per step: at S = 24 that was most of the launch.)
+            v[n] = *reinterpret_cast<const f32x4*>(xb + (size_t)min(row, P - 1) * S + min(k, S - 4));  // (S % 4 == 0: the four samples are in range together)
+            if (!(row < P && k < S)) valid &= ~(1u << n);
         } else {
             f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row < P) {
                 const float* src = xb + (size_t)row * S + k;
-                if (VEC) {
-                    if (k < S) q = *reinterpret_cast<const f32x4*>(src);  // (S % 4 == 0: the four samples are in range together)
-                } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (k + c < S) q[c] = src[c];
-                }
+                for (int c = 0; c < 4; ++c)
+                    if (k + c < S) q[c] = src[c];
             }
             v[n] = q;
         }
     }
+    return valid;
 }
 
 // MODE 2: the launch has only whole tiles and whole steps (P % 128 == 0, S % 32 == 0, slabs starting on a tile row: decided on the host) -- the kernel contains
 // no bounds path at all (a run-time choice between the two forms inside one kernel merges their registers at the join, and the copies there wait for the loads);
 // MODE 1: 16-byte loads with bounds; MODE 0: S is not a multiple of 4.
 template <int MODE>
-__device__ __forceinline__ void cov_load_pair(const float* __restrict__ xb, int P, int S, int i0, int j0, int k0, int tid, f32x4 (&vi)[4], f32x4 (&vj)[4]) {
-    cov_load_step<(MODE >= 1), (MODE == 2)>(xb, P, S, i0, k0, tid, vi);
-    cov_load_step<(MODE >= 1), (MODE == 2)>(xb, P, S, j0, k0, tid, vj);
+__device__ __forceinline__ unsigned cov_load_pair(const float* __restrict__ xb, int P, int S, int i0, int j0, int k0, int tid, f32x4 (&vi)[4], f32x4 (&vj)[4]) {
+    const unsigned a = cov_load_step<(MODE >= 1), (MODE == 2)>(xb, P, S, i0, k0, tid, vi);
+    const unsigned b = cov_load_step<(MODE >= 1), (MODE == 2)>(xb, P, S, j0, k0, tid, vj);
+    return a | (b << 4);
 }
 
-__device__ __forceinline__ void cov_store_step(float* lds, int tid, const f32x4 (&v)[4]) {
+__device__ __forceinline__ void cov_store_step(float* lds, int tid, const f32x4 (&v)[4], unsigned valid) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int e = tid + 256 * n;
-        *reinterpret_cast<f32x4*>(lds + (e >> 3) * kCovPitch + (e & 7) * 4) = v[n];
+        *reinterpret_cast<f32x4*>(lds + (e >> 3) * kCovPitch + (e & 7) * 4) = (valid >> n) & 1u ? v[n] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -179,14 +183,14 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
         for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x4 vi[4], vj[4];
-    cov_load_pair<MODE>(xb, P, S, i0, j0, 0, tid, vi, vj);
-    cov_store_step(lds_i, tid, vi);
-    cov_store_step(lds_j, tid, vj);
+    unsigned valid = cov_load_pair<MODE>(xb, P, S, i0, j0, 0, tid, vi, vj);
+    cov_store_step(lds_i, tid, vi, valid);
+    cov_store_step(lds_j, tid, vj, valid >> 4);
     __syncthreads();
     for (int k0 = 0; k0 < S; k0 += kCovBK) {
         const bool more = k0 + kCovBK < S;
         if (more) {  // next step's operands: in flight under this step's MFMAs
-            cov_load_pair<MODE>(xb, P, S, i0, j0, k0 + kCovBK, tid, vi, vj);
+            valid = cov_load_pair<MODE>(xb, P, S, i0, j0, k0 + kCovBK, tid, vi, vj);
         }
 #pragma unroll 2
         for (int kk = 0; kk < kCovBK; kk += 4) {
@@ -204,8 +208,8 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
         }
         __syncthreads();
         if (more) {
-            cov_store_step(lds_i, tid, vi);
-            cov_store_step(lds_j, tid, vj);
+            cov_store_step(lds_i, tid, vi, valid);
+            cov_store_step(lds_j, tid, vj, valid >> 4);
             __syncthreads();
         }
     }
@@ -254,7 +258,9 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
 #pragma unroll
                         for (int r = 0; r < 4; ++r) buf[(f * 16 + (lane >> 4) * 4 + r) * kCovEpiPitch + fi * 16 + (lane & 15)] = acc[fi][half * 2 + f][r];
             }
-            __syncthreads();
+            // (the buffer is this wave's own and a wave's LDS operations execute in order: no workgroup barrier between its writes and its reads -- with eight
+            // `__syncthreads()` per tile the epilogue cost ~100 us of the launch even with its stores removed; only the compiler must not move them across)
+            __builtin_amdgcn_wave_barrier();
             const int rbase = (orient == 0 ? ib : jb) + half * 32, cbase = orient == 0 ? jb : ib;
             const int r_end = orient == 0 ? i_end : P, r_off = orient == 0 ? row0 : 0;  // (the mirror image exists only when the call covers every row)
 #pragma unroll
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256) void flow_cov_kernel(const float* __restrict__
                     }
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
