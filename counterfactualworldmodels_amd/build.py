@@ -141,8 +141,19 @@ def _build_locked(out_path, extra, obj_dir, force, verbose):
         if s in SOURCES:
             objs.append(obj)
         if s == "engine.hip":  # carries the hash of ALL sources (cwm_source_hash): recompiled whenever anything changed
-            if force or stale_hash or not os.path.exists(obj):
+            # (`engine.hip.o.hash` = the hash THIS object was compiled with: after a build that failed on another source the object already carries the new hash while
+            # the stamp still holds the old one -- reverting the edit then made "stamp == sources" true and linked an object with the wrong hash)
+            try:
+                with open(obj + ".hash") as fh:
+                    obj_hash = fh.read().strip()
+            except OSError:
+                obj_hash = ""
+            if force or stale_hash or obj_hash != shash or not os.path.exists(obj):
                 jobs.append((base + ['-DCWM_SRC_HASH="%s"' % shash, '-DCWM_HIPCC_VERSION="%s"' % hipcc_version().replace('"', "'"), "-c", src, "-o", obj], obj))
+                try:
+                    os.remove(obj + ".hash")
+                except OSError:
+                    pass
             continue
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(src)):
             jobs.append((base + ["-c", src, "-o", obj], obj))
@@ -155,6 +166,9 @@ def _build_locked(out_path, extra, obj_dir, force, verbose):
             for obj, rc, log in ex.map(_compile_one, jobs):
                 if rc != 0:
                     raise RuntimeError("hipcc failed on %s:\n%s" % (obj, log))
+                if obj.endswith("engine.hip.o"):
+                    with open(obj + ".hash", "w") as fh:
+                        fh.write(shash)
                 if verbose and log.strip():
                     print(log, file=sys.stderr)
     tmp = "%s.tmp%d" % (out_path, os.getpid())
@@ -183,7 +197,7 @@ def clean_stale() -> list:
     `side_*` directories of one-off side builds (CWM_HIPCC_EXTRA profiling builds) -- they travelled with every push to the GPU box.  Returns what it removed."""
     root = os.path.join(PKG_DIR, "build")
     gone = []
-    keep = {s + ".o" for s in SOURCES + DEV_SOURCES} | {"source_hash.txt", ".lock"}
+    keep = {s + ".o" for s in SOURCES + DEV_SOURCES} | {"source_hash.txt", ".lock", "engine.hip.o.hash"}
     prod = os.path.join(root, "prod")
     if os.path.isdir(prod):
         for f in os.listdir(prod):
